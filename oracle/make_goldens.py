@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Golden-vector recipe: run the TRUE reference (/root/reference/llama2.ts) and record its outputs.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference and `node`); the
+GPU box never runs it -- it consumes the fixtures this script writes to tests/golden/.
+
+What it does:
+  1. in a scratch dir under /tmp, lift the self-contained sucrase bundle out of the reference's
+     own t348.mjs (lines 898-9042) and use it to strip the TypeScript types from llama2.ts
+     (line-preserving), so Node 12 can execute the reference unmodified;
+  2. insert ONE statement after the `transformer(...)` call at llama2.ts:468 that appends
+     `state.logits`, the fed `token` and (for small shapes) the RunState scratch buffers to files;
+  3. generate synthetic checkpoints with the repo's deterministic generator (oracle_cli synth);
+  4. run `node llama2.stripped.mjs <ckpt> -t 0 -s 1 -n <steps>` and reduce the dumps to small
+     fixtures: fed tokens, per-step sha256 of the raw logits, full logits at a few positions,
+     RunState buffers and KV cache for the tiny shapes.
+
+Nothing derived from the reference's source text is written into the repo -- only numbers.
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from llama2_ts_amd import configs  # noqa: E402
+
+REF = "/root/reference"
+WORK = "/tmp/l2_goldens"
+GOLD = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "oracle", "build", "oracle_cli")
+
+# name -> (steps, positions whose full logits are kept, keep RunState dumps?, prompt)
+PLAN = {
+    "tiny": (64, "all", True, None),
+    "ragged": (33, "all", True, None),
+    "stories15M": (256, [0, 1, 2, 127, 255], False, None),
+    "stories15M_prompt": (24, [3, 4, 23], False, "Once upon a time"),
+    "stories110M": (40, [0, 39], False, None),
+    "llama2_7b_L2": (6, [0, 5], False, None),
+}
+
+DUMP_STMT = (
+    "if (process.env.L2_DUMP) {"
+    " const __w = (n, a) => fs.appendFileSync(process.env.L2_DUMP + n, Buffer.from(a.buffer, a.byteOffset, a.byteLength));"
+    " __w('.logits', state.logits); __w('.tokens', new Int32Array([token]));"
+    " if (process.env.L2_DUMP_STATE) { for (const n of ['x','xb','xb2','hb','hb2','q','k','v','att']) __w('.' + n, state[n]);"
+    " if (pos == steps - 1) { __w('.key_cache', state.key_cache); __w('.value_cache', state.value_cache); } } }\n"
+)
+
+
+def build_reference():
+    os.makedirs(WORK, exist_ok=True)
+    for f in ("tokenizer.bin",):
+        shutil.copy(os.path.join(REF, f), WORK)
+    with open(os.path.join(REF, "t348.mjs")) as f:
+        lines = f.readlines()
+    assert lines[897].startswith("const transform=(()=>{"), lines[897][:40]
+    assert lines[9041].startswith("})();"), lines[9041][:40]
+    strip = "".join(lines[897:9042]) + """
+const fs=require('fs');
+fs.writeFileSync(process.argv[3],
+  transform(fs.readFileSync(process.argv[2],'utf8'),
+            {transforms:["typescript"],filePath:'llama2.ts',disableESTransforms:true}).code);
+"""
+    with open(os.path.join(WORK, "strip.cjs"), "w") as f:
+        f.write(strip)
+    out = os.path.join(WORK, "llama2.stripped.mjs")
+    subprocess.run(["node", os.path.join(WORK, "strip.cjs"), os.path.join(REF, "llama2.ts"), out], check=True)
+    with open(out) as f:
+        js = f.readlines()
+    assert "transformer(token, pos, config, state, weights);" in js[467], js[467]
+    js.insert(468, DUMP_STMT)
+    inst = os.path.join(WORK, "llama2.instrumented.mjs")
+    with open(inst, "w") as f:
+        f.writelines(js)
+    return inst
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_one(inst, name):
+    steps, keep, keep_state, prompt = PLAN[name]
+    shape = name.replace("_prompt", "")
+    hdr = configs.header(shape)
+    seed = configs.DEFAULT_SEED
+    ckpt = os.path.join(WORK, shape + ".bin")
+    if not os.path.exists(ckpt):
+        subprocess.run([CLI, "synth", *map(str, hdr), str(seed), ckpt], check=True)
+    assert os.path.getsize(ckpt) == configs.checkpoint_bytes(hdr)
+    dump = os.path.join(WORK, name + ".dump")
+    for f in os.listdir(WORK):
+        if f.startswith(name + ".dump"):
+            os.remove(os.path.join(WORK, f))
+    env = dict(os.environ, L2_DUMP=dump)
+    if keep_state:
+        env["L2_DUMP_STATE"] = "1"
+    cmd = ["node", inst, ckpt, "-t", "0", "-s", "1", "-n", str(steps)]
+    if prompt is not None:
+        cmd += ["-i", prompt]
+    r = subprocess.run(cmd, cwd=WORK, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    V = abs(hdr[5])
+    logits = np.fromfile(dump + ".logits", dtype="<f4").reshape(-1, V)
+    tokens = np.fromfile(dump + ".tokens", dtype="<i4")
+    n = logits.shape[0]
+    assert n == len(tokens)
+    meta = {
+        "config": shape, "header": list(hdr), "seed": seed, "steps_requested": steps, "steps_run": int(n),
+        "prompt": prompt, "argv": cmd[3:], "node": subprocess.run(["node", "--version"], stdout=subprocess.PIPE).stdout.decode().strip(),
+        "reference": "wizzard0/llama2.ts @ /root/reference (llama2.ts, types stripped by its bundled sucrase 3.21.0)",
+        "checkpoint_sha256": hashlib.sha256(open(ckpt, "rb").read()).hexdigest() if os.path.getsize(ckpt) < (1 << 30) else None,
+        "logits_sha256": [sha(logits[i]) for i in range(n)],
+        "tokens_fed": tokens.tolist(),
+        "argmax": [int(np.argmax(logits[i])) for i in range(n)],
+        "stdout_tail": r.stdout.decode("utf8", "replace")[-80:],
+    }
+    arrays = {}
+    if keep == "all":
+        arrays["logits"] = logits
+        meta["logit_positions"] = list(range(n))
+    else:
+        keep = [p for p in keep if p < n]
+        arrays["logits"] = logits[keep]
+        meta["logit_positions"] = keep
+    if keep_state:
+        d, h, L, H, _, _, S = hdr
+        for nm, width in (("x", d), ("xb", d), ("xb2", d), ("hb", h), ("hb2", h), ("q", d), ("k", d), ("v", d), ("att", H * S)):
+            arrays[nm] = np.fromfile(dump + "." + nm, dtype="<f4").reshape(n, width)
+        arrays["key_cache"] = np.fromfile(dump + ".key_cache", dtype="<f4")
+        arrays["value_cache"] = np.fromfile(dump + ".value_cache", dtype="<f4")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
+    with open(os.path.join(GOLD, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(name, "steps", n, "tokens", tokens[:8].tolist(), "...", "npz KB",
+          os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024)
+
+
+def main():
+    names = sys.argv[1:] or list(PLAN)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    os.makedirs(GOLD, exist_ok=True)
+    inst = build_reference()
+    for name in names:
+        run_one(inst, name)
+
+
+if __name__ == "__main__":
+    main()
