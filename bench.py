@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s + achieved HBM GB/s of the llama2.ts forward pass on MI355X.
+
+A "step" is ONE transformer() call (llama2.ts:205-303) = one decoded token, weights resident in HBM,
+greedy feed (-t 0, llama2.ts:476-478) from BOS at pos 0, synthetic seeded weights of the named shape.
+`value` times the device-resident loop (forward + on-device argmax, no host round trip); the same K
+steps through the blocking drop-in call l2_forward (logits handed to the host every token, as
+llama2.ts:468-478 consumes them) are reported next to it as `dropin_tok_s`.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config llama2_7b|stories110M|stories15M]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): Llama-2-7B is tensor-parallel (heads / FFN
+rows sharded, RCCL all-reduce of d fp64 partials twice per layer) => strong scaling;
+shapes that do not shard run as independent replicas => weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from llama2_ts_amd import configs, runtime  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def avg_bytes_per_token(hdr, steps):
+    return sum(configs.algorithmic_bytes_per_token(hdr, p) for p in range(steps)) / float(steps)
+
+
+def dominant_kernel_bytes(cfg):
+    """Algorithmic bytes of one launch of the dominant kernel: the fused rmsnorm + w1/w3 GEMV + SwiGLU
+    phase (llama2.ts:276-289): both matrices once, x and the norm weight in, hb out."""
+    d, h = cfg.dim, cfg.hidden_dim
+    return 4 * (2 * h * d + 2 * d + h)
+
+
+def cpu_baseline(name, hdr, seed):
+    """The CPU oracle (C restatement of llama2.ts, one thread like the single-threaded reference) timed on
+    this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    d, h, L, H, kv, V, S = hdr
+    if L * d * h > 4 * 768 * 2048 * 12:
+        # too big to materialise on the host in seconds: time 1-layer and 3-layer models of the same width
+        # and extrapolate linearly in the layer count (time per token is linear in bytes streamed)
+        t = {}
+        for layers in (1, 3):
+            o = O.Oracle((d, h, layers, H, kv, V, S), seed)
+            o.forward(1, 0)
+            t0 = time.perf_counter()
+            tok = 1
+            for pos in range(1, 4):
+                tok = O.argmax(o.forward(tok, pos))
+            t[layers] = (time.perf_counter() - t0) / 3.0
+            o.close()
+        per_layer = (t[3] - t[1]) / 2.0
+        sec = t[1] + (L - 1) * per_layer
+        sample = "oracle on 1- and 3-layer models of this width, 3 tokens each, extrapolated to %d layers" % L
+    else:
+        o = O.Oracle(hdr, seed)
+        steps = 8
+        sec0, _ = o.time_forward(steps)
+        steps = int(max(8, min(S, 12.0 / (sec0 / steps))))
+        o2 = O.Oracle(hdr, seed)
+        sec_total, _ = o2.time_forward(steps)
+        sec = sec_total / steps
+        sample = "oracle, %d greedy tokens from BOS on the full %s shape" % (steps, name)
+        o.close(); o2.close()
+    return {"value": round(1.0 / sec, 4), "unit": "tokens/s", "cores": 1, "kind": "port", "sample": sample}
+
+
+def run_single(args, hdr, device, tp=None):
+    cfg = runtime.Config(hdr)
+    if tp:
+        ctx = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=tp["id"])
+    else:
+        ctx = runtime.Context(hdr, device=device)
+    ctx.synth_fill(args.seed)
+    return cfg, ctx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="llama2_7b", choices=sorted(configs.CONFIGS))
+    ap.add_argument("--seed", type=int, default=configs.DEFAULT_SEED)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary stories110M line")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    hdr = configs.header(args.config)
+    K = min(args.steps, hdr[6])
+    W = min(args.warmup, hdr[6])
+    dist = None
+    tp = None
+    shards = world > 1 and args.config.startswith("llama2_7b")
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")   # rendezvous + barriers only; the data path is RCCL inside the library
+        if shards:
+            idbuf = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                import ctypes as C
+                b = C.create_string_buffer(128)
+                runtime._check(runtime.lib().l2_tp_unique_id(b))
+                idbuf = torch.frombuffer(bytearray(b.raw), dtype=torch.uint8).clone()
+            dist.broadcast(idbuf, 0)
+            tp = {"rank": rank, "size": world, "id": bytes(idbuf.numpy().tobytes())}
+
+    cfg, ctx = run_single(args, hdr, local_rank, tp)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize(local_rank)
+
+    ctx.bench_decode(1, 0, W)                  # W untimed warm-up steps (captures the graph too)
+    sync_all()
+    t0 = time.perf_counter()
+    dev_ms = ctx.bench_decode(1, 0, K)         # EXACTLY K timed steps, HIP events on the library's stream
+    sync_all()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+
+    tokens_total = K if (shards or world == 1) else K * world
+    value = tokens_total / wall
+    bpt = avg_bytes_per_token(hdr, K)
+
+    out = {
+        "metric": "decode tokens/sec + achieved HBM GB/s (% peak), 1 GPU" if world == 1 else "decode tokens/sec (whole job)",
+        "value": round(value, 3), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(1e3 * wall / K, 5), "higher_is_better": True,
+        "scaling": "strong" if shards else "weak", "vs_baseline": None, "dtype": "f32 storage, f64 accumulate",
+        "data": "synthetic (seeded hash generator, llama2.c-v0 layout)",
+        "config": {"workload": "%s batch-1 greedy decode, %d tokens from BOS (-t 0 -s 1 -n %d)" % (args.config, K, K),
+                   "header": list(hdr), "parallelism": ("tp%d" % world) if shards else ("replicas%d" % world if world > 1 else "single"),
+                   "loop": "device-resident (forward + argmax on GPU, one hipGraph replay per token)"},
+        "device_ms_per_step": round(dev_ms / K, 5),
+        "algorithmic_bytes_per_token": int(bpt),
+        "hbm_gbs_end_to_end": round(bpt * value / 1e9 / (1 if shards or world == 1 else world), 2),
+        "hbm_frac_end_to_end": round(bpt * value / 1e9 / (1 if shards or world == 1 else world) / HBM_PEAK_GBS / (world if shards else 1), 4),
+    }
+
+    if rank == 0 and world == 1:
+        # the same K steps through the blocking drop-in boundary (logits to the host every token)
+        tok = 1
+        ctx.forward(1, 0)
+        t0 = time.perf_counter()
+        for pos in range(K):
+            lg = ctx.forward(tok, pos)
+            tok = int(np.argmax(lg))
+        dt = time.perf_counter() - t0
+        out["dropin_tok_s"] = round(K / dt, 3)
+        # dominant kernel alone, HIP events on the library's stream
+        iters = 200 if cfg.dim * cfg.hidden_dim < (1 << 24) else 50
+        kms = ctx.bench_gemv(runtime.T_W1, cfg.n_layers // 2, iters)
+        kb = dominant_kernel_bytes(cfg)
+        ach = kb / (kms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "kernel": "phase_kernel<MODE_W13> (rmsnorm + w1/w3 GEMV + SwiGLU, llama2.ts:276-289)",
+                           "bytes_per_launch": kb, "avg_launch_us": round(kms * 1e3, 3)}
+        per_kernel = {}
+        for nm, kind in (("qkv", runtime.T_WQ), ("wo", runtime.T_WO), ("w13", runtime.T_W1), ("w2", runtime.T_W2), ("wcls", runtime.T_WCLS)):
+            ms = ctx.bench_gemv(kind, 0, iters)
+            d, h, V = cfg.dim, cfg.hidden_dim, cfg.vocab_size
+            nb = {"qkv": 3 * d * d, "wo": d * d, "w13": 2 * d * h, "w2": d * h, "wcls": V * d}[nm] * 4
+            per_kernel[nm] = {"us": round(ms * 1e3, 3), "GBs": round(nb / (ms * 1e-3) / 1e9, 1)}
+        out["per_kernel"] = per_kernel
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, hdr, args.seed)
+    ctx.close()
+
+    if rank == 0 and world == 1 and not args.no_extra and args.config == "llama2_7b":
+        # BASELINE.json's metric names stories110M too: same measurement, secondary line in the same JSON
+        h2 = configs.header("stories110M")
+        c2 = runtime.Context(h2, device=local_rank)
+        c2.synth_fill(args.seed)
+        K2 = min(256, h2[6])
+        c2.bench_decode(1, 0, 8)
+        t0 = time.perf_counter()
+        c2.bench_decode(1, 0, K2)
+        w2 = time.perf_counter() - t0
+        b2 = avg_bytes_per_token(h2, K2)
+        out["stories110M"] = {"value": round(K2 / w2, 2), "unit": "tokens/s", "steps": K2,
+                              "hbm_gbs_end_to_end": round(b2 * K2 / w2 / 1e9, 2),
+                              "hbm_frac_end_to_end": round(b2 * K2 / w2 / 1e9 / HBM_PEAK_GBS, 4)}
+        c2.close()
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

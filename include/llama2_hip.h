@@ -1,0 +1,133 @@
+/*
+ * llama2_hip.h -- C ABI of libllama2hip.so: the MI355X (gfx950) forward pass that drops in at the
+ * single call `transformer(token, pos, config, state, weights)` of wizzard0/llama2.ts
+ * (/root/reference/llama2.ts:468, body :205-303).
+ *
+ * The reference has no FFI/plugin interface (every function is module-private, llama2.ts:526 just
+ * calls main()), so these entry points are what an N-API / bun:ffi / ctypes binding for that call
+ * would bind; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types; every function returns 0 on success
+ * or a negative L2_E_* code (l2_last_error() gives the text); nothing throws across the ABI; a
+ * context is bound to one device, is not thread-safe, and distinct contexts are independent.  Host
+ * pointers are only read/written during the call and never retained.
+ */
+#ifndef LLAMA2_HIP_H
+#define LLAMA2_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2_ABI_VERSION 1
+
+enum {
+  L2_OK = 0,
+  L2_E_ARG = -1,     /* bad argument (null pointer, index out of range, wrong size) */
+  L2_E_CONFIG = -2,  /* unsupported header (dim % n_heads, odd head_size, non-positive sizes) */
+  L2_E_HIP = -3,     /* a HIP runtime call failed */
+  L2_E_STATE = -4,   /* call order violated (forward before all tensors uploaded, pos not sequential) */
+  L2_E_NOGPU = -5,   /* no gfx950 device visible */
+  L2_E_COMM = -6     /* RCCL failure (tensor-parallel contexts) */
+};
+
+/* Tensor kinds = fields of the reference's TransformerWeights in checkpoint order
+ * (readWeights, llama2.ts:112-129). */
+enum {
+  L2_T_TOKEN_EMBEDDING = 0, /* token_embedding_table (V,d)   llama2.ts:114 */
+  L2_T_RMS_ATT = 1,         /* rms_att_weight[l] (d)         :115 */
+  L2_T_WQ = 2,              /* wq[l] (d,d)                   :116 */
+  L2_T_WK = 3,              /* wk[l] (d,d)                   :117 */
+  L2_T_WV = 4,              /* wv[l] (d,d)                   :118 */
+  L2_T_WO = 5,              /* wo[l] (d,d)                   :119 */
+  L2_T_RMS_FFN = 6,         /* rms_ffn_weight[l] (d)         :120 */
+  L2_T_W1 = 7,              /* w1[l] (h,d)                   :121 */
+  L2_T_W2 = 8,              /* w2[l] (d,h)                   :122 */
+  L2_T_W3 = 9,              /* w3[l] (h,d)                   :123 */
+  L2_T_RMS_FINAL = 10,      /* rms_final_weight (d)          :124 */
+  L2_T_FREQ_REAL = 11,      /* freq_cis_real (S,hs/2)        :125 */
+  L2_T_FREQ_IMAG = 12,      /* freq_cis_imag (S,hs/2)        :126 */
+  L2_T_WCLS = 13,           /* wcls (V,d), only when the header's vocab_size < 0  :127 */
+  L2_T_COUNT = 14
+};
+
+/* RunState fields (llama2.ts:131-146) readable with l2_read_state. */
+enum {
+  L2_S_X = 0, L2_S_XB = 1, L2_S_XB2 = 2, L2_S_HB = 3, L2_S_HB2 = 4, L2_S_Q = 5, L2_S_K = 6, L2_S_V = 7,
+  L2_S_ATT = 8, L2_S_LOGITS = 9, L2_S_KEY_CACHE = 10, L2_S_VALUE_CACHE = 11
+};
+
+/* l2_set_option keys */
+enum {
+  L2_OPT_EXACT_ATTENTION = 1, /* 1: value-accumulate rounds to fp32 at every timestep in t order, exactly as
+                                 llama2.ts:260-265 does (bit-faithful, slower); 0 (default): fp64 partial sums */
+  L2_OPT_USE_GRAPH = 2,       /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
+  L2_OPT_MEGAKERNEL = 3       /* reserved: single persistent launch per token */
+};
+
+typedef struct l2_ctx l2_ctx;
+
+int l2_abi_version(void);
+int l2_device_count(void);                 /* number of visible HIP devices, or a negative code */
+const char* l2_last_error(void);           /* thread-local text of the last failure */
+
+/* Replaces readConfig + newRunState (llama2.ts:80-93, 147-163): `cfg` is the 7 header int32 verbatim
+ * (sign of vocab_size kept).  Allocates weights, activations and the [L][S][d] KV caches in HBM. */
+int l2_create(const int32_t cfg[7], int device, l2_ctx** out);
+void l2_destroy(l2_ctx* ctx);
+
+/* Tensor-parallel context: rank `tp_rank` of `tp_size` owns heads / FFN rows
+ * [rank*H/G, ...).  `nccl_id` is the 128-byte ncclUniqueId produced by l2_tp_unique_id on rank 0 and
+ * handed to the others by the caller (e.g. over torch.distributed).  tp_size 1 == l2_create. */
+int l2_tp_unique_id(void* id_out_128);
+int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out);
+
+/* Replaces the hand-over of one Float32Array of TransformerWeights (readWeights, llama2.ts:112-129):
+ * call once per array right after FileHandleReader.getF32Array returns it (llama2.ts:51-59).
+ * `layer` is the index into the Float32Array[] for per-layer tensors, -1 otherwise.  The bytes are
+ * copied to HBM before the call returns. */
+int l2_upload(l2_ctx* ctx, int tensor_kind, int layer, const float* host, size_t n_floats);
+
+/* Fill every tensor on the device with the repo's deterministic synthetic generator (same values as
+ * oracle/llama2_oracle.c:orc_synth_tensor); used by bench.py for shapes too large to ship. */
+int l2_synth_fill(l2_ctx* ctx, uint32_t seed);
+/* Read back part of a weight tensor (tests of l2_upload / l2_synth_fill). */
+int l2_read_tensor(l2_ctx* ctx, int tensor_kind, int layer, size_t offset, float* out, size_t n_floats);
+
+/* Replaces transformer(token, pos, p, s, w) (llama2.ts:205-303, call site :468).  Blocking: when it
+ * returns, logits_out[0..V) holds state.logits for this position and the device KV cache holds rows
+ * 0..pos.  pos must be 0 <= pos < seq_len; token in [0, V).  logits_out may be NULL (logits stay
+ * readable through l2_logits_host / l2_read_state). */
+int l2_forward(l2_ctx* ctx, int token, int pos, float* logits_out);
+/* Pinned host buffer (V floats) that l2_forward fills; a binding may wrap it as RunState.logits to
+ * skip the copy into logits_out. */
+float* l2_logits_host(l2_ctx* ctx);
+
+/* Next row of SURVEY.md 8(f1): greedy decode (`-t 0`, argmax llama2.ts:364-366: first maximum) kept on
+ * the device -- the loop llama2.ts:465-508 with temperature 0 and no prompt, minus printing.  Feeds
+ * `first_token` at pos0, then each argmax; writes the `steps` chosen tokens to tokens_out[0..steps).
+ * Does not stop at BOS (the caller truncates, llama2.ts:499). */
+int l2_decode_greedy(l2_ctx* ctx, int first_token, int pos0, int steps, int32_t* tokens_out);
+
+/* Copy a RunState buffer to the host (parity tests).  For per-layer caches `layer` selects the
+ * [S][d] slab (-1: all layers).  After a forward, X holds the final-normed x as in llama2.ts:299. */
+int l2_read_state(l2_ctx* ctx, int which, int layer, float* out, size_t n_floats);
+
+int l2_set_option(l2_ctx* ctx, int key, int value);
+int l2_get_option(l2_ctx* ctx, int key, int* value);
+
+/* Measurement hooks (bench.py): HIP events on the context's own stream. */
+int l2_timer_start(l2_ctx* ctx);
+int l2_timer_stop(l2_ctx* ctx, float* elapsed_ms);   /* synchronises */
+/* Launch only the dominant kernel (the weight-streaming GEMV of one matrix kind of one layer)
+ * `iters` times back to back and return the average device time per launch. */
+int l2_bench_gemv(l2_ctx* ctx, int tensor_kind, int layer, int iters, float* avg_ms);
+/* `steps` forwards (greedy feed, device-resident) timed with events: total device ms. */
+int l2_bench_decode(l2_ctx* ctx, int first_token, int pos0, int steps, float* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,778 @@
+// llama2_hip.hip -- host runtime + C ABI (include/llama2_hip.h) of libllama2hip.so.
+//
+// Data layout in HBM (one context = one MI355X, 288 GB: every shape of SURVEY.md section 8 fits):
+//   * one allocation per TransformerWeights field (llama2.ts:95-110), layers contiguous:
+//     w[kind][layer][rows][cols] fp32 row-major exactly as the checkpoint has it (llama2.ts:112-129);
+//   * RunState (llama2.ts:131-146): x, xb, xb2, hb, hb2, q, k, v, att, logits + KV caches [L][S][d];
+//   * {token,pos,step} live in device memory so a captured hipGraph can be replayed for every
+//     position without touching kernel arguments.
+// One forward = 5 fused kernels per layer + the classifier, replayed as ONE hipGraph launch.
+#include "../../include/llama2_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.hip.h"
+
+using namespace l2k;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(L2_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- RCCL, bound lazily so the library has no link-time dependency on it ------------------------
+typedef struct { char internal[128]; } nccl_uid;
+typedef void* nccl_comm;
+struct Rccl {
+  void* so = nullptr;
+  int (*GetUniqueId)(nccl_uid*) = nullptr;
+  int (*CommInitRank)(nccl_comm*, int, nccl_uid, int) = nullptr;
+  int (*CommDestroy)(nccl_comm) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, nccl_comm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+enum { NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
+
+static int rccl_bind() {
+  if (g_rccl.so) return L2_OK;
+  const char* names[] = {getenv("L2_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* so = nullptr;
+  for (const char* n : names) {
+    if (!n) continue;
+    so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (so) break;
+  }
+  if (!so) return fail(L2_E_COMM, "cannot dlopen RCCL: %s", dlerror());
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(so, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(so, "ncclCommInitRank");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(so, "ncclCommDestroy");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(so, "ncclAllReduce");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(so, "ncclAllGather");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(so, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+    dlclose(so);
+    return fail(L2_E_COMM, "RCCL symbols missing");
+  }
+  g_rccl.so = so;
+  return L2_OK;
+}
+
+#define NCCLCHK(expr)                                                                             \
+  do {                                                                                            \
+    int r_ = (expr);                                                                              \
+    if (r_ != 0) return fail(L2_E_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+struct l2_ctx {
+  int32_t hdr[7];
+  int d, h, L, H, V, S, hs;
+  bool shared;
+  int device;
+  hipStream_t stream = nullptr;
+  // tensor parallel shard (G == 1: everything local)
+  int G = 1, rank = 0;
+  int d_loc, h_loc, H_loc, V_loc;
+  nccl_comm comm = nullptr;
+
+  float* w[L2_T_COUNT] = {};
+  size_t layer_elems[L2_T_COUNT] = {};  // LOCAL floats per layer (or whole tensor when unlayered)
+  int layers_of[L2_T_COUNT] = {};
+  std::vector<uint8_t> uploaded[L2_T_COUNT];
+
+  float *x = nullptr, *xb = nullptr, *xb2 = nullptr, *hb = nullptr, *hb2 = nullptr, *q = nullptr, *k = nullptr,
+        *v = nullptr, *att = nullptr, *logits = nullptr, *logits_loc = nullptr, *kc = nullptr, *vc = nullptr, *xn = nullptr;
+  double* partial = nullptr;
+  int* tokpos = nullptr;    // device {token,pos,step,0}
+  int* h_tokpos = nullptr;  // pinned
+  int* d_tokens = nullptr;  // device, S ints
+  float* h_logits = nullptr;
+
+  hipGraphExec_t g_step = nullptr, g_greedy = nullptr;
+  int opt_exact = 0, opt_graph = 1;
+  int next_pos = 0;
+  bool ran_forward = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // tuning overrides (env)
+  int tune_R = 0, tune_nwaves = 0, tune_gridcap = 0;
+};
+
+static bool is_layered(int kind) { return kind >= L2_T_RMS_ATT && kind <= L2_T_W3; }
+
+// Local (per-rank) shape of one layer of a tensor: rows x cols, plus where the slice sits in the
+// full tensor (row0/col0) so l2_upload can cut it out of the caller's full array.
+struct Slice { size_t rows, cols, full_rows, full_cols, row0, col0; };
+
+static Slice tensor_slice(const l2_ctx* c, int kind) {
+  const size_t d = c->d, h = c->h, V = c->V, S = c->S, hs2 = c->hs / 2;
+  const size_t dl = c->d_loc, hl = c->h_loc, Vl = c->V_loc, r = c->rank;
+  switch (kind) {
+    case L2_T_TOKEN_EMBEDDING: return {V, d, V, d, 0, 0};
+    case L2_T_RMS_ATT: case L2_T_RMS_FFN: case L2_T_RMS_FINAL: return {1, d, 1, d, 0, 0};
+    case L2_T_WQ: case L2_T_WK: case L2_T_WV: return {dl, d, d, d, r * dl, 0};  // whole heads
+    case L2_T_WO: return {d, dl, d, d, 0, r * dl};                                 // columns, repacked
+    case L2_T_W1: case L2_T_W3: return {hl, d, h, d, r * hl, 0};
+    case L2_T_W2: return {d, hl, d, h, 0, r * hl};
+    case L2_T_FREQ_REAL: case L2_T_FREQ_IMAG: return {S, hs2, S, hs2, 0, 0};
+    case L2_T_WCLS: return {Vl, d, V, d, r * Vl, 0};
+    default: return {0, 0, 0, 0, 0, 0};
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int l2_abi_version(void) { return L2_ABI_VERSION; }
+extern "C" const char* l2_last_error(void) { return g_err; }
+
+extern "C" int l2_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(L2_E_NOGPU, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+static void destroy_graphs(l2_ctx* c) {
+  if (c->g_step) { hipGraphExecDestroy(c->g_step); c->g_step = nullptr; }
+  if (c->g_greedy) { hipGraphExecDestroy(c->g_greedy); c->g_greedy = nullptr; }
+}
+
+extern "C" void l2_destroy(l2_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  destroy_graphs(c);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  for (int k = 0; k < L2_T_COUNT; ++k)
+    if (c->w[k] && !(k == L2_T_WCLS && c->shared)) hipFree(c->w[k]);  // shared wcls aliases the embedding table
+  float* bufs[] = {c->x, c->xb, c->xb2, c->hb, c->hb2, c->q, c->k, c->v, c->att, c->logits, c->kc, c->vc, c->xn};
+  for (float* b : bufs) if (b) hipFree(b);
+  if (c->logits_loc && c->logits_loc != c->logits) hipFree(c->logits_loc);
+  if (c->partial) hipFree(c->partial);
+  if (c->tokpos) hipFree(c->tokpos);
+  if (c->d_tokens) hipFree(c->d_tokens);
+  if (c->h_tokpos) hipHostFree(c->h_tokpos);
+  if (c->h_logits) hipHostFree(c->h_logits);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s && *s ? atoi(s) : dflt;
+}
+
+static int create_impl(const int32_t cfg[7], int device, int rank, int G, const void* nccl_id, l2_ctx** out) {
+  if (!cfg || !out) return fail(L2_E_ARG, "null argument");
+  *out = nullptr;
+  const int d = cfg[0], h = cfg[1], L = cfg[2], H = cfg[3], V = abs(cfg[5]), S = cfg[6];
+  if (d <= 0 || h <= 0 || L <= 0 || H <= 0 || V <= 0 || S <= 0) return fail(L2_E_CONFIG, "non-positive size in header");
+  if (d % H) return fail(L2_E_CONFIG, "dim %d not divisible by n_heads %d", d, H);
+  if ((d / H) % 2) return fail(L2_E_CONFIG, "odd head_size %d (RoPE rotates adjacent pairs, llama2.ts:224)", d / H);
+  if (G < 1 || rank < 0 || rank >= G) return fail(L2_E_ARG, "bad tensor-parallel rank %d of %d", rank, G);
+  if (G > 1 && (H % G || h % G || V % G || ((d / G) % 2) || ((h / G) % 1)))
+    return fail(L2_E_CONFIG, "shape does not shard over %d ranks (n_heads %d, hidden %d, vocab %d)", G, H, h, V);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(L2_E_NOGPU, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(L2_E_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("L2_ALLOW_ANY_ARCH"))
+    return fail(L2_E_NOGPU, "device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+
+  l2_ctx* c = new l2_ctx();
+  memcpy(c->hdr, cfg, sizeof(c->hdr));
+  c->d = d; c->h = h; c->L = L; c->H = H; c->V = V; c->S = S; c->hs = d / H;
+  c->shared = cfg[5] > 0;
+  c->device = device;
+  c->G = G; c->rank = rank;
+  c->d_loc = d / G; c->h_loc = h / G; c->H_loc = H / G; c->V_loc = V / G;
+  c->tune_R = env_int("L2_TUNE_R", 0);
+  c->tune_nwaves = env_int("L2_TUNE_NWAVES", 0);
+  c->tune_gridcap = env_int("L2_TUNE_GRIDCAP", 0);
+  c->opt_graph = env_int("L2_USE_GRAPH", G == 1 ? 1 : 0);
+
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
+  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CK(hipEventCreate(&c->ev0));
+  CK(hipEventCreate(&c->ev1));
+  for (int k = 0; k < L2_T_COUNT; ++k) {
+    const Slice s = tensor_slice(c, k);
+    c->layers_of[k] = is_layered(k) ? L : 1;
+    c->layer_elems[k] = s.rows * s.cols;
+    if (k == L2_T_WCLS && c->shared) {
+      if (G == 1) { c->w[k] = c->w[L2_T_TOKEN_EMBEDDING]; c->uploaded[k].assign(1, 0); continue; }
+      // sharded classifier over a shared table: the rank's row slice of the (full) embedding table
+      c->w[k] = c->w[L2_T_TOKEN_EMBEDDING] + (size_t)rank * c->V_loc * d;
+      c->uploaded[k].assign(1, 0);
+      continue;
+    }
+    CK(hipMalloc(&c->w[k], c->layer_elems[k] * c->layers_of[k] * sizeof(float)));
+    c->uploaded[k].assign(c->layers_of[k], 0);
+  }
+  const size_t dl = c->d_loc, kv = (size_t)L * S * dl;
+  CK(hipMalloc(&c->x, d * 4)); CK(hipMalloc(&c->xn, d * 4));
+  CK(hipMalloc(&c->xb, dl * 4)); CK(hipMalloc(&c->xb2, d * 4));
+  CK(hipMalloc(&c->hb, c->h_loc * 4)); CK(hipMalloc(&c->hb2, c->h_loc * 4));
+  CK(hipMalloc(&c->q, dl * 4)); CK(hipMalloc(&c->k, dl * 4)); CK(hipMalloc(&c->v, dl * 4));
+  CK(hipMalloc(&c->att, (size_t)c->H_loc * S * 4));
+  CK(hipMalloc(&c->logits, (size_t)V * 4));
+  if (G > 1) { CK(hipMalloc(&c->logits_loc, (size_t)c->V_loc * 4)); CK(hipMalloc(&c->partial, (size_t)d * 8)); }
+  else c->logits_loc = c->logits;
+  CK(hipMalloc(&c->kc, kv * 4)); CK(hipMalloc(&c->vc, kv * 4));
+  CK(hipMemsetAsync(c->kc, 0, kv * 4, c->stream)); CK(hipMemsetAsync(c->vc, 0, kv * 4, c->stream));
+  float* zero[] = {c->x, c->xn, c->xb, c->xb2, c->hb, c->hb2, c->q, c->k, c->v};
+  const size_t zn[] = {(size_t)d, (size_t)d, dl, (size_t)d, (size_t)c->h_loc, (size_t)c->h_loc, dl, dl, dl};
+  for (int i = 0; i < 9; ++i) CK(hipMemsetAsync(zero[i], 0, zn[i] * 4, c->stream));
+  CK(hipMemsetAsync(c->att, 0, (size_t)c->H_loc * S * 4, c->stream));
+  CK(hipMemsetAsync(c->logits, 0, (size_t)V * 4, c->stream));
+  CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
+  CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
+  CK(hipMalloc(&c->d_tokens, (size_t)S * sizeof(int)));
+  CK(hipHostMalloc(&c->h_tokpos, 4 * sizeof(int), hipHostMallocDefault));
+  CK(hipHostMalloc(&c->h_logits, (size_t)V * 4, hipHostMallocDefault));
+  memset(c->h_logits, 0, (size_t)V * 4);
+  CK(hipStreamSynchronize(c->stream));
+#undef CK
+  if (G > 1) {
+    int rc = rccl_bind();
+    if (rc) { l2_destroy(c); return rc; }
+    nccl_uid uid;
+    memcpy(&uid, nccl_id, sizeof(uid));
+    int r = g_rccl.CommInitRank(&c->comm, G, uid, rank);
+    if (r != 0) { l2_destroy(c); return fail(L2_E_COMM, "ncclCommInitRank failed: %d", r); }
+  }
+  *out = c;
+  return L2_OK;
+}
+
+extern "C" int l2_create(const int32_t cfg[7], int device, l2_ctx** out) { return create_impl(cfg, device, 0, 1, nullptr, out); }
+
+extern "C" int l2_tp_unique_id(void* id_out_128) {
+  if (!id_out_128) return fail(L2_E_ARG, "null argument");
+  int rc = rccl_bind();
+  if (rc) return rc;
+  nccl_uid uid;
+  NCCLCHK(g_rccl.GetUniqueId(&uid));
+  memcpy(id_out_128, &uid, sizeof(uid));
+  return L2_OK;
+}
+
+extern "C" int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out) {
+  if (tp_size > 1 && !nccl_id) return fail(L2_E_ARG, "nccl_id required for tp_size > 1");
+  return create_impl(cfg, device, tp_rank, tp_size, nccl_id, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+static int check_tensor(l2_ctx* c, int kind, int layer, int* layer_idx) {
+  if (!c) return fail(L2_E_ARG, "null context");
+  if (kind < 0 || kind >= L2_T_COUNT) return fail(L2_E_ARG, "tensor kind %d out of range", kind);
+  if (kind == L2_T_WCLS && c->shared) return fail(L2_E_ARG, "wcls aliases token_embedding_table for this checkpoint (vocab_size > 0, llama2.ts:127)");
+  if (is_layered(kind)) {
+    if (layer < 0 || layer >= c->L) return fail(L2_E_ARG, "layer %d out of range for tensor kind %d", layer, kind);
+    *layer_idx = layer;
+  } else {
+    if (layer != -1 && layer != 0) return fail(L2_E_ARG, "tensor kind %d is not per-layer", kind);
+    *layer_idx = 0;
+  }
+  return L2_OK;
+}
+
+extern "C" int l2_upload(l2_ctx* c, int kind, int layer, const float* host, size_t n_floats) {
+  int li = 0;
+  int rc = check_tensor(c, kind, layer, &li);
+  if (rc) return rc;
+  if (!host) return fail(L2_E_ARG, "null host pointer");
+  const Slice s = tensor_slice(c, kind);
+  if (n_floats != s.full_rows * s.full_cols)
+    return fail(L2_E_ARG, "tensor kind %d expects %zu floats, got %zu", kind, s.full_rows * s.full_cols, n_floats);
+  HIPCHK(hipSetDevice(c->device));
+  float* dst = c->w[kind] + c->layer_elems[kind] * (size_t)li;
+  const float* src = host + s.row0 * s.full_cols + s.col0;
+  if (s.cols == s.full_cols) {
+    HIPCHK(hipMemcpy(dst, src, s.rows * s.cols * sizeof(float), hipMemcpyHostToDevice));
+  } else {  // column slice, repacked contiguous (tensor-parallel wo / w2)
+    HIPCHK(hipMemcpy2D(dst, s.cols * sizeof(float), src, s.full_cols * sizeof(float), s.cols * sizeof(float), s.rows, hipMemcpyHostToDevice));
+  }
+  c->uploaded[kind][li] = 1;
+  return L2_OK;
+}
+
+// deterministic exp / sincos from IEEE basic operations (same recipe as the oracle's generator)
+static double det_exp(double x) {
+  const double y = x / 1024.0;
+  double t = 1.0, s = 1.0;
+  for (int k = 1; k <= 14; ++k) { t = (t * y) / (double)k; s = s + t; }
+  for (int i = 0; i < 10; ++i) s = s * s;
+  return s;
+}
+static void det_sincos(double x, double* sn, double* cs) {
+  const double x2 = x * x;
+  double ts = x, tc = 1.0, ss = x, cc = 1.0;
+  for (int k = 1; k <= 12; ++k) {
+    tc = ((-tc) * x2) / (double)((2 * k - 1) * (2 * k));
+    cc = cc + tc;
+    ts = ((-ts) * x2) / (double)((2 * k) * (2 * k + 1));
+    ss = ss + ts;
+  }
+  *sn = ss; *cs = cc;
+}
+
+static uint64_t full_count(const l2_ctx* c, int kind) {
+  if (kind == L2_T_WCLS && c->shared) return 0;
+  const size_t d = c->d, h = c->h, V = c->V, S = c->S, hs2 = c->hs / 2, L = c->L;
+  switch (kind) {
+    case L2_T_TOKEN_EMBEDDING: case L2_T_WCLS: return V * d;
+    case L2_T_RMS_ATT: case L2_T_RMS_FFN: return L * d;
+    case L2_T_WQ: case L2_T_WK: case L2_T_WV: case L2_T_WO: return L * d * d;
+    case L2_T_W1: case L2_T_W2: case L2_T_W3: return L * h * d;
+    case L2_T_RMS_FINAL: return d;
+    case L2_T_FREQ_REAL: case L2_T_FREQ_IMAG: return S * hs2;
+    default: return 0;
+  }
+}
+
+extern "C" int l2_synth_fill(l2_ctx* c, uint32_t seed) {
+  if (!c) return fail(L2_E_ARG, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  uint64_t off = 0;
+  for (int kind = 0; kind < L2_T_COUNT; ++kind) {
+    const uint64_t n = full_count(c, kind);
+    if (!n) continue;
+    if (kind == L2_T_FREQ_REAL || kind == L2_T_FREQ_IMAG) {
+      if (kind == L2_T_FREQ_REAL) {
+        const int hs2 = c->hs / 2;
+        std::vector<float> re((size_t)c->S * hs2), im((size_t)c->S * hs2);
+        for (int j = 0; j < hs2; ++j) {
+          const double theta = det_exp(-(((2.0 * (double)j) / (double)c->hs) * 9.210340371976184));
+          double st, ct;
+          det_sincos(theta, &st, &ct);
+          double cr = 1.0, ci = 0.0;
+          for (int t = 0; t < c->S; ++t) {
+            re[(size_t)t * hs2 + j] = (float)cr;
+            im[(size_t)t * hs2 + j] = (float)ci;
+            const double nr = cr * ct - ci * st, ni = cr * st + ci * ct;
+            cr = nr; ci = ni;
+          }
+        }
+        HIPCHK(hipMemcpy(c->w[L2_T_FREQ_REAL], re.data(), re.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->w[L2_T_FREQ_IMAG], im.data(), im.size() * 4, hipMemcpyHostToDevice));
+      }
+    } else {
+      double sigma = 0.0; float bias = 0.0f;
+      switch (kind) {
+        case L2_T_TOKEN_EMBEDDING: case L2_T_WCLS: sigma = 0.02; break;
+        case L2_T_RMS_ATT: case L2_T_RMS_FFN: case L2_T_RMS_FINAL: sigma = 0.1; bias = 1.0f; break;
+        case L2_T_W2: sigma = 1.0 / sqrt((double)c->h); break;
+        default: sigma = 1.0 / sqrt((double)c->d); break;
+      }
+      const float scale = (float)(sigma / 37837.22723720648);
+      // the rank's slice of every layer (whole tensor when not sharded); a shared classifier aliases the table
+      const Slice sl = tensor_slice(c, kind);
+      SynthSlice ss;
+      ss.g0 = off; ss.full_layer = sl.full_rows * sl.full_cols; ss.rows = sl.rows; ss.cols = sl.cols;
+      ss.full_cols = sl.full_cols; ss.row0 = sl.row0; ss.col0 = sl.col0;
+      ss.n = sl.rows * sl.cols * (uint64_t)c->layers_of[kind];
+      const uint64_t want = (ss.n + 256 * 8 - 1) / (256 * 8);
+      const int blocks = (int)(want > 65535 ? 65535 : (want < 1 ? 1 : want));
+      hipLaunchKernelGGL(synth_fill_kernel, dim3(blocks), dim3(256), 0, c->stream, c->w[kind], ss, seed, scale, bias);
+      HIPCHK(hipGetLastError());
+    }
+    for (auto& u : c->uploaded[kind]) u = 1;
+    off += n;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return L2_OK;
+}
+
+extern "C" int l2_read_tensor(l2_ctx* c, int kind, int layer, size_t offset, float* out, size_t n_floats) {
+  if (!c || !out) return fail(L2_E_ARG, "null argument");
+  if (kind < 0 || kind >= L2_T_COUNT) return fail(L2_E_ARG, "tensor kind %d out of range", kind);
+  int li = 0;
+  if (is_layered(kind)) { if (layer < 0 || layer >= c->L) return fail(L2_E_ARG, "layer out of range"); li = layer; }
+  const size_t n = c->layer_elems[kind] ? c->layer_elems[kind] : (size_t)c->V * c->d;
+  if (offset + n_floats > n) return fail(L2_E_ARG, "read of %zu floats at %zu exceeds tensor (%zu)", n_floats, offset, n);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy(out, c->w[kind] + n * (size_t)li + offset, n_floats * 4, hipMemcpyDeviceToHost));
+  return L2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launch geometry: a wave owns R rows at a time; enough waves to cover every CU several times over,
+// few enough workgroups that the per-workgroup prologue (input vector -> LDS) stays amortised.
+struct Geo { int R, nwaves, grid; bool vec; };
+
+static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
+  Geo g;
+  g.vec = (n % 4) == 0;
+  const int pair = (mode == MODE_W13) ? 2 : 1;  // W13: R covers R/2 rows of w1 + R/2 of w3
+  const int groups4 = (rows * pair + 3) / 4;
+  g.R = (groups4 >= 2048) ? 4 : 2;
+  if (c->tune_R == 2 || c->tune_R == 4) g.R = c->tune_R;
+  if (mode == MODE_QKV && (dim % g.R)) g.R = 2;  // a row group must not straddle wq/wk/wv (dim is even)
+  const int groups = (rows * pair + g.R - 1) / g.R;
+  g.nwaves = groups >= 2048 ? 4 : (groups >= 1024 ? 2 : 1);
+  if (c->tune_nwaves == 1 || c->tune_nwaves == 2 || c->tune_nwaves == 4) g.nwaves = c->tune_nwaves;
+  int grid = (groups + g.nwaves - 1) / g.nwaves;
+  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : 2048;
+  if (grid > cap) grid = cap;
+  g.grid = grid < 1 ? 1 : grid;
+  return g;
+}
+
+template <int MODE>
+static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
+  const Geo g = pick_geo(c, MODE, a.rows, a.n, a.dim);
+  const size_t lds = (((size_t)a.n * 4 + 15) & ~(size_t)15) + 64;
+  const dim3 grid(g.grid), block(64 * g.nwaves);
+  if (g.vec) {
+    if (g.R == 4) hipLaunchKernelGGL((phase_kernel<MODE, 4, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((phase_kernel<MODE, 2, true>), grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL((phase_kernel<MODE, 2, false>), grid, block, lds, st, a);
+  }
+  return hipGetLastError();
+}
+
+static int attn_lpr(int hs, bool vec) {
+  const int need = vec ? (hs + 3) / 4 : hs;
+  int l = 1;
+  while (l < need) l <<= 1;
+  return l;
+}
+
+static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
+  AttnArgs a;
+  const size_t loff = (size_t)l * c->S * c->d_loc;
+  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb; a.tokpos = c->tokpos;
+  a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.exact = c->opt_exact;
+  const bool vec = (c->hs % 4 == 0) && (c->d_loc % 4 == 0);
+  a.lpr = attn_lpr(c->hs, vec);
+  if (a.lpr > 64) return hipErrorInvalidValue;
+  const int G = 256 / a.lpr;
+  const size_t lds = (size_t)((c->S + 3) & ~3) * 4 + (size_t)((c->hs + 3) & ~3) * 4 + 64 + (size_t)G * c->hs * 8;
+  if (vec) hipLaunchKernelGGL((attn_kernel<true>), dim3(c->H_loc), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((attn_kernel<false>), dim3(c->H_loc), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+__global__ void tp_residual_kernel(float* x, const float* res_emb, const double* sum, float* mv_out, const int* tokpos, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  const float xr = res_emb ? res_emb[(size_t)tokpos[0] * d + i] : x[i];
+  const float mv = (float)sum[i];   // ONE rounding of the all-reduced fp64 sum (llama2.ts:201)
+  x[i] = xr + mv;                   // accum, llama2.ts:168-170
+  if (mv_out) mv_out[i] = mv;
+}
+
+#define LCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(L2_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
+static int enqueue_forward(l2_ctx* c, hipStream_t st) {
+  const float* emb = c->w[L2_T_TOKEN_EMBEDDING];
+  for (int l = 0; l < c->L; ++l) {
+    const size_t loff = (size_t)l * c->S * c->d_loc;
+    PhaseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tokpos = c->tokpos; a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG];
+    a.head_size = c->hs;
+    // 1. rmsnorm + q,k,v GEMVs + RoPE + KV-cache store (llama2.ts:216-240)
+    a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l;
+    a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
+    a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
+    a.in = c->x; a.emb = (l == 0) ? emb : nullptr;
+    a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * l;
+    a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff; a.aux = c->k; a.aux2 = c->v;
+    a.n = c->d; a.rows = 3 * c->d_loc; a.dim = c->d_loc;
+    LCHK(launch_phase<MODE_QKV>(c, a, st));
+    // 2. attention (llama2.ts:244-267)
+    LCHK(launch_attn(c, l, st));
+    // 3. wo GEMV + residual (llama2.ts:270-273)
+    memset(&a, 0, sizeof(a));
+    a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
+    a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l;
+    a.in = c->xb; a.emb = (l == 0) ? emb : nullptr; a.res = c->x; a.out = c->x; a.aux = c->xb2;
+    a.n = c->d_loc; a.rows = c->d;
+    if (c->G > 1) a.partial = c->partial;
+    LCHK(launch_phase<MODE_WO>(c, a, st));
+    if (c->G > 1) {
+      NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st));
+      hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? emb : nullptr, c->partial, c->xb2, c->tokpos, c->d);
+      LCHK(hipGetLastError());
+    }
+    // 4. rmsnorm + w1,w3 GEMVs + SwiGLU (llama2.ts:276-289)
+    memset(&a, 0, sizeof(a));
+    a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
+    a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l;
+    a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
+    a.in = c->x; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * l;
+    a.out = c->hb; a.aux = c->hb2;
+    a.n = c->d; a.rows = c->h_loc;
+    LCHK(launch_phase<MODE_W13>(c, a, st));
+    // 5. w2 GEMV + residual (llama2.ts:292-295)
+    memset(&a, 0, sizeof(a));
+    a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
+    a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l;
+    a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = (c->G == 1) ? c->xb : nullptr;
+    a.n = c->h_loc; a.rows = c->d;
+    if (c->G > 1) a.partial = c->partial;
+    LCHK(launch_phase<MODE_W2>(c, a, st));
+    if (c->G > 1) {
+      NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st));
+      hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, nullptr, c->partial, nullptr, c->tokpos, c->d);
+      LCHK(hipGetLastError());
+    }
+  }
+  // final rmsnorm + classifier (llama2.ts:299-302)
+  PhaseArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
+  a.w0 = c->w[L2_T_WCLS];
+  a.in = c->x; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xn;
+  a.n = c->d; a.rows = c->V_loc;
+  LCHK(launch_phase<MODE_CLS>(c, a, st));
+  if (c->G > 1) NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st));
+  return L2_OK;
+}
+
+static int ensure_ready(l2_ctx* c) {
+  for (int k = 0; k < L2_T_COUNT; ++k) {
+    if (k == L2_T_WCLS && c->shared) continue;
+    for (size_t l = 0; l < c->uploaded[k].size(); ++l)
+      if (!c->uploaded[k][l]) return fail(L2_E_STATE, "tensor kind %d layer %zu was never uploaded", k, l);
+  }
+  return L2_OK;
+}
+
+static int enqueue_step(l2_ctx* c, hipStream_t st) {  // drop-in step: H2D {token,pos}, forward, D2H logits
+  LCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, st));
+  int rc = enqueue_forward(c, st);
+  if (rc) return rc;
+  LCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, st));
+  return L2_OK;
+}
+
+static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step: forward, argmax, advance
+  int rc = enqueue_forward(c, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(argmax_advance_kernel, dim3(1), dim3(1024), 0, st, c->logits, c->V, c->tokpos, c->d_tokens);
+  LCHK(hipGetLastError());
+  return L2_OK;
+}
+
+static int capture(l2_ctx* c, int (*enq)(l2_ctx*, hipStream_t), hipGraphExec_t* out) {
+  hipGraph_t graph = nullptr;
+  LCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = enq(c, c->stream);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return fail(L2_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(L2_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  return L2_OK;
+}
+
+extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
+  if (!c) return fail(L2_E_ARG, "null context");
+  if (pos < 0 || pos >= c->S) return fail(L2_E_ARG, "pos %d outside [0, seq_len=%d)", pos, c->S);
+  if (token < 0 || token >= c->V) return fail(L2_E_ARG, "token %d outside [0, vocab_size=%d)", token, c->V);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  c->h_tokpos[0] = token; c->h_tokpos[1] = pos; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
+  if (c->opt_graph) {
+    if (!c->g_step) { rc = capture(c, enqueue_step, &c->g_step); if (rc) return rc; }
+    HIPCHK(hipGraphLaunch(c->g_step, c->stream));
+  } else {
+    rc = enqueue_step(c, c->stream);
+    if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->ran_forward = true;
+  if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
+  return L2_OK;
+}
+
+extern "C" float* l2_logits_host(l2_ctx* c) { return c ? c->h_logits : nullptr; }
+
+static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool timed, float* ms) {
+  if (!c) return fail(L2_E_ARG, "null context");
+  if (steps < 0 || pos0 < 0 || pos0 + steps > c->S) return fail(L2_E_ARG, "pos0 %d + steps %d exceeds seq_len %d", pos0, steps, c->S);
+  if (first_token < 0 || first_token >= c->V) return fail(L2_E_ARG, "token out of range");
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
+  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (c->opt_graph && !c->g_greedy) { rc = capture(c, enqueue_greedy, &c->g_greedy); if (rc) return rc; }
+  if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
+  for (int s = 0; s < steps; ++s) {
+    if (c->opt_graph) HIPCHK(hipGraphLaunch(c->g_greedy, c->stream));
+    else { rc = enqueue_greedy(c, c->stream); if (rc) return rc; }
+  }
+  if (timed) {
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->ran_forward = true;
+  return L2_OK;
+}
+
+extern "C" int l2_decode_greedy(l2_ctx* c, int first_token, int pos0, int steps, int32_t* tokens_out) {
+  if (!tokens_out && steps > 0) return fail(L2_E_ARG, "null tokens_out");
+  int rc = run_greedy(c, first_token, pos0, steps, false, nullptr);
+  if (rc) return rc;
+  if (steps > 0) HIPCHK(hipMemcpy(tokens_out, c->d_tokens, (size_t)steps * sizeof(int), hipMemcpyDeviceToHost));
+  return L2_OK;
+}
+
+extern "C" int l2_bench_decode(l2_ctx* c, int first_token, int pos0, int steps, float* total_ms) {
+  if (!total_ms) return fail(L2_E_ARG, "null total_ms");
+  return run_greedy(c, first_token, pos0, steps, true, total_ms);
+}
+
+extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t n_floats) {
+  if (!c || !out) return fail(L2_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  const float* src = nullptr;
+  size_t n = 0;
+  const size_t slab = (size_t)c->S * c->d_loc;
+  switch (which) {
+    case L2_S_X: src = c->ran_forward ? c->xn : c->x; n = c->d; break;
+    case L2_S_XB: src = c->xb; n = c->d_loc; break;
+    case L2_S_XB2: src = c->xb2; n = c->d; break;
+    case L2_S_HB: src = c->hb; n = c->h_loc; break;
+    case L2_S_HB2: src = c->hb2; n = c->h_loc; break;
+    case L2_S_Q: src = c->q; n = c->d_loc; break;
+    case L2_S_K: src = c->k; n = c->d_loc; break;
+    case L2_S_V: src = c->v; n = c->d_loc; break;
+    case L2_S_ATT: src = c->att; n = (size_t)c->H_loc * c->S; break;
+    case L2_S_LOGITS: src = c->logits; n = c->V; break;
+    case L2_S_KEY_CACHE: case L2_S_VALUE_CACHE: {
+      const float* base = which == L2_S_KEY_CACHE ? c->kc : c->vc;
+      if (layer < 0) { src = base; n = slab * c->L; }
+      else { if (layer >= c->L) return fail(L2_E_ARG, "layer out of range"); src = base + slab * layer; n = slab; }
+      break;
+    }
+    default: return fail(L2_E_ARG, "unknown state id %d", which);
+  }
+  if (n_floats != n) return fail(L2_E_ARG, "state %d has %zu floats, caller asked for %zu", which, n, n_floats);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+  return L2_OK;
+}
+
+extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
+  if (!c) return fail(L2_E_ARG, "null context");
+  switch (key) {
+    case L2_OPT_EXACT_ATTENTION: if (c->opt_exact != !!value) { c->opt_exact = !!value; destroy_graphs(c); } return L2_OK;
+    case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
+    case L2_OPT_MEGAKERNEL: return value ? fail(L2_E_ARG, "megakernel path not built in this version") : L2_OK;
+    default: return fail(L2_E_ARG, "unknown option %d", key);
+  }
+}
+
+extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
+  if (!c || !value) return fail(L2_E_ARG, "null argument");
+  switch (key) {
+    case L2_OPT_EXACT_ATTENTION: *value = c->opt_exact; return L2_OK;
+    case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
+    case L2_OPT_MEGAKERNEL: *value = 0; return L2_OK;
+    default: return fail(L2_E_ARG, "unknown option %d", key);
+  }
+}
+
+extern "C" int l2_timer_start(l2_ctx* c) {
+  if (!c) return fail(L2_E_ARG, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  return L2_OK;
+}
+
+extern "C" int l2_timer_stop(l2_ctx* c, float* ms) {
+  if (!c || !ms) return fail(L2_E_ARG, "null argument");
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  HIPCHK(hipEventSynchronize(c->ev1));
+  HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return L2_OK;
+}
+
+// The dominant kernel alone: one weight-streaming GEMV phase, launched `iters` times back to back.
+extern "C" int l2_bench_gemv(l2_ctx* c, int kind, int layer, int iters, float* avg_ms) {
+  if (!c || !avg_ms || iters <= 0) return fail(L2_E_ARG, "bad argument");
+  if (layer < 0 || layer >= c->L) layer = 0;
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  PhaseArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tokpos = c->tokpos; a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG]; a.head_size = c->hs; a.dim = c->d;
+  const size_t loff = (size_t)layer * c->S * c->d_loc;
+  int mode;
+  switch (kind) {
+    case L2_T_WQ: case L2_T_WK: case L2_T_WV:
+      mode = MODE_QKV;
+      a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * layer; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * layer;
+      a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * layer;
+      a.in = c->xn; a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * layer; a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff;
+      a.n = c->d; a.rows = 3 * c->d_loc; a.dim = c->d_loc; break;
+    case L2_T_WO:
+      mode = MODE_WO; a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * layer; a.in = c->xb; a.res = c->xn; a.out = c->xb2;
+      a.n = c->d_loc; a.rows = c->d; break;
+    case L2_T_W1: case L2_T_W3:
+      mode = MODE_W13; a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * layer; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * layer;
+      a.in = c->xn; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * layer; a.out = c->hb; a.n = c->d; a.rows = c->h_loc; break;
+    case L2_T_W2:
+      mode = MODE_W2; a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * layer; a.in = c->hb; a.res = c->xn; a.out = c->xb2;
+      a.n = c->h_loc; a.rows = c->d; break;
+    case L2_T_WCLS: case L2_T_TOKEN_EMBEDDING:
+      mode = MODE_CLS; a.w0 = c->w[L2_T_WCLS]; a.in = c->xn; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xb2;
+      a.n = c->d; a.rows = c->V_loc; break;
+    default: return fail(L2_E_ARG, "tensor kind %d is not a GEMV matrix", kind);
+  }
+  for (int it = -2; it < iters; ++it) {
+    if (it == 0) HIPCHK(hipEventRecord(c->ev0, c->stream));
+    hipError_t e;
+    switch (mode) {
+      case MODE_QKV: e = launch_phase<MODE_QKV>(c, a, c->stream); break;
+      case MODE_WO: e = launch_phase<MODE_WO>(c, a, c->stream); break;
+      case MODE_W13: e = launch_phase<MODE_W13>(c, a, c->stream); break;
+      case MODE_W2: e = launch_phase<MODE_W2>(c, a, c->stream); break;
+      default: e = launch_phase<MODE_CLS>(c, a, c->stream); break;
+    }
+    if (e != hipSuccess) return fail(L2_E_HIP, "gemv launch: %s", hipGetErrorString(e));
+  }
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  HIPCHK(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *avg_ms = ms / (float)iters;
+  return L2_OK;
+}

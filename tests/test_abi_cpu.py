@@ -1,0 +1,75 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, exports every symbol the header declares,
+and fails loudly (no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as graft
+from llama2_ts_amd import configs, runtime
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    graft.build()
+    return runtime.lib()
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "llama2_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(l2_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    assert sorted(runtime.ABI_SYMBOLS) == declared
+    raw = C.CDLL(runtime.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert built.l2_abi_version() == 1
+
+
+def test_header_cites_reference_lines():
+    hdr = open(os.path.join(ROOT, "include", "llama2_hip.h")).read()
+    for cite in ("llama2.ts:468", "llama2.ts:205-303", "llama2.ts:112-129", "llama2.ts:80-93", "llama2.ts:364-366"):
+        assert cite in hdr
+
+
+def test_no_cpu_fallback_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(runtime.L2Error) as e:
+        runtime.Context(configs.header("tiny"))
+    assert e.value.code == -5  # L2_E_NOGPU
+
+
+def test_bad_arguments_are_rejected_before_touching_the_gpu(built):
+    h = C.c_void_p()
+    assert built.l2_create(None, 0, C.byref(h)) == -1
+    bad = (C.c_int32 * 7)(64, 176, 2, 5, 5, 512, 64)   # dim % n_heads != 0
+    assert built.l2_create(bad, 0, C.byref(h)) == -2
+    assert b"n_heads" in built.l2_last_error()
+    odd = (C.c_int32 * 7)(66, 176, 2, 6, 6, 512, 64)    # head_size 11 is odd: RoPE pairs (llama2.ts:224)
+    assert built.l2_create(odd, 0, C.byref(h)) == -2
+    assert built.l2_forward(None, 1, 0, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "llama2.ts_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".mjs", ".js", ".ts")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle_lib" not in txt and "liboracle" not in txt and "llama2_oracle" not in txt.replace(
+                    "oracle/llama2_oracle.c", ""), (dp, f)
+
+
+def test_config_reader_and_shapes():
+    import struct
+    cfg = runtime.readConfig(struct.pack("<7i", *configs.header("llama2_7b")))
+    assert (cfg.dim, cfg.hidden_dim, cfg.n_layers, cfg.vocab_size, cfg.shared_weights, cfg.head_size) == (4096, 11008, 32, 32000, False, 128)
+    total = sum(max(l, 1) * n for _, l, n in runtime.tensor_shapes(cfg))
+    assert 28 + 4 * total == configs.checkpoint_bytes(cfg.header) == 26954711068
+    cfg = runtime.readConfig(struct.pack("<7i", *configs.header("stories15M")))
+    assert cfg.shared_weights and 28 + 4 * sum(max(l, 1) * n for _, l, n in runtime.tensor_shapes(cfg)) == 60816028
