@@ -398,8 +398,13 @@ __global__ void synth_fill_kernel(float* out, SynthSlice s, uint32_t seed, float
     const uint32_t h1 = hash32(lo ^ k);
     const uint32_t h2 = hash32(h1 + 0x9E3779B9U);
     const int c = (int)((h1 & 0xffffU) + (h1 >> 16) + (h2 & 0xffffU) + (h2 >> 16)) - 131070;
-    const float p = __fmul_rn((float)c, scale);
-    out[i] = __fadd_rn(bias, p);
+    float v;
+    {
+#pragma clang fp contract(off)   // two fp32 roundings like the host generator: never an FMA
+      const float p = (float)c * scale;
+      v = bias + p;
+    }
+    out[i] = v;
   }
 }
 
