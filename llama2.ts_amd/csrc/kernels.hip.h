@@ -33,7 +33,7 @@ struct PhaseArgs {
   float* out_k;       // QKV: key_cache   + l*S*d
   float* out_v;       // QKV: value_cache + l*S*d
   float* aux;         // CLS: final-normed x (llama2.ts:299)  QKV: k  W13: hb2  WO: xb2  W2: xb (parity reads; may be null)
-  float* aux2;        // QKV: v scratch (may be null)
+  float* aux2;        // QKV: v (parity reads; may be null)   CLS: host-mapped pinned logits (zero-copy hand-off) or null
   const float* res;   // WO/W2: residual source x
   const float* fr;    // freq_cis_real
   const float* fi;    // freq_cis_imag
@@ -197,7 +197,11 @@ __global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
     } else if (MODE == MODE_CLS) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        if (lane == r && row0 + r < a.rows) a.out[row0 + r] = (float)acc[r];  // llama2.ts:302
+        if (lane == r && row0 + r < a.rows) {
+          const float lg = (float)acc[r];                                     // llama2.ts:302
+          a.out[row0 + r] = lg;
+          if (a.aux2) a.aux2[row0 + r] = lg;   // straight into the host's RunState.logits (pinned, mapped)
+        }
     } else {  // WO / W2: matmul store then residual accum (llama2.ts:270-273, 292-295)
 #pragma unroll
       for (int r = 0; r < R; ++r) {

@@ -109,7 +109,10 @@ struct l2_ctx {
   int* tokpos = nullptr;    // device {token,pos,step,0}
   int* h_tokpos = nullptr;  // pinned
   int* d_tokens = nullptr;  // device, S ints
-  float* h_logits = nullptr;
+  float* h_logits = nullptr;      // pinned + mapped: the classifier kernel writes it directly
+  float* h_logits_dev = nullptr;  // device alias of h_logits
+  int opt_zero_copy = 1;
+  int profile_sync = 0;
 
   hipGraphExec_t g_step = nullptr, g_greedy = nullptr;
   int opt_exact = 0, opt_graph = 1;
@@ -215,6 +218,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->tune_nwaves = env_int("L2_TUNE_NWAVES", 0);
   c->tune_gridcap = env_int("L2_TUNE_GRIDCAP", 0);
   c->opt_graph = env_int("L2_USE_GRAPH", G == 1 ? 1 : 0);
+  c->profile_sync = env_int("L2_PROFILE_SYNC", 0);
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -254,8 +258,10 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
   CK(hipMalloc(&c->d_tokens, (size_t)S * sizeof(int)));
   CK(hipHostMalloc(&c->h_tokpos, 4 * sizeof(int), hipHostMallocDefault));
-  CK(hipHostMalloc(&c->h_logits, (size_t)V * 4, hipHostMallocDefault));
+  CK(hipHostMalloc(&c->h_logits, (size_t)V * 4, hipHostMallocMapped));
   memset(c->h_logits, 0, (size_t)V * 4);
+  CK(hipHostGetDevicePointer((void**)&c->h_logits_dev, c->h_logits, 0));
+  c->opt_zero_copy = env_int("L2_ZERO_COPY_LOGITS", G == 1 ? 1 : 0);
   CK(hipStreamSynchronize(c->stream));
 #undef CK
   if (G > 1) {
@@ -492,7 +498,7 @@ __global__ void tp_residual_kernel(float* x, const float* res_emb, const double*
 #define LCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(L2_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 // Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
-static int enqueue_forward(l2_ctx* c, hipStream_t st) {
+static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
   const float* emb = c->w[L2_T_TOKEN_EMBEDDING];
   for (int l = 0; l < c->L; ++l) {
     const size_t loff = (size_t)l * c->S * c->d_loc;
@@ -553,11 +559,15 @@ static int enqueue_forward(l2_ctx* c, hipStream_t st) {
   a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
   a.w0 = c->w[L2_T_WCLS];
   a.in = c->x; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xn;
+  a.aux2 = (to_host && c->opt_zero_copy && c->G == 1) ? c->h_logits_dev : nullptr;
   a.n = c->d; a.rows = c->V_loc;
   LCHK(launch_phase<MODE_CLS>(c, a, st));
   if (c->G > 1) NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st));
   return L2_OK;
 }
+
+static int enqueue_forward(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, false); }
+static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
 
 static int ensure_ready(l2_ctx* c) {
   for (int k = 0; k < L2_T_COUNT; ++k) {
@@ -565,14 +575,6 @@ static int ensure_ready(l2_ctx* c) {
     for (size_t l = 0; l < c->uploaded[k].size(); ++l)
       if (!c->uploaded[k][l]) return fail(L2_E_STATE, "tensor kind %d layer %zu was never uploaded", k, l);
   }
-  return L2_OK;
-}
-
-static int enqueue_step(l2_ctx* c, hipStream_t st) {  // drop-in step: H2D {token,pos}, forward, D2H logits
-  LCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, st));
-  int rc = enqueue_forward(c, st);
-  if (rc) return rc;
-  LCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, st));
   return L2_OK;
 }
 
@@ -605,13 +607,18 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
   if (rc) return rc;
   HIPCHK(hipSetDevice(c->device));
   c->h_tokpos[0] = token; c->h_tokpos[1] = pos; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
+  // {token,pos} in and logits out travel as plain stream copies around the replayed kernel graph
+  // (memcpy nodes inside a captured graph crash rocprofv3's kernel trace on ROCm 7.2)
+  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   if (c->opt_graph) {
-    if (!c->g_step) { rc = capture(c, enqueue_step, &c->g_step); if (rc) return rc; }
+    if (!c->g_step) { rc = capture(c, enqueue_forward_host, &c->g_step); if (rc) return rc; }
     HIPCHK(hipGraphLaunch(c->g_step, c->stream));
   } else {
-    rc = enqueue_step(c, c->stream);
+    rc = enqueue_forward_host(c, c->stream);
     if (rc) return rc;
   }
+  if (!(c->opt_zero_copy && c->G == 1))
+    HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
   if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
@@ -634,6 +641,9 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   for (int s = 0; s < steps; ++s) {
     if (c->opt_graph) HIPCHK(hipGraphLaunch(c->g_greedy, c->stream));
     else { rc = enqueue_greedy(c, c->stream); if (rc) return rc; }
+    // rocprofv3 (ROCm 7.2) segfaults with thousands of un-synchronised dispatches queued behind it:
+    // L2_PROFILE_SYNC=1 drains the stream after every token (kernel durations are unaffected)
+    if (c->profile_sync) HIPCHK(hipStreamSynchronize(c->stream));
   }
   if (timed) {
     HIPCHK(hipEventRecord(c->ev1, c->stream));
