@@ -22,6 +22,22 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_QKV = 0, MODE_WO = 1, MODE_W13 = 2, MODE_W2 = 3, MODE_CLS = 4 };
 
+// Diagnostic build only (-DL2_STAMPS, tools/stamps.py): shader-clock stamps of wave 0 of a few workgroups go
+// to a buffer nothing else reads.  In the product build STAMP() is empty.
+#ifdef L2_STAMPS
+#define L2_NSTAMP 12
+#define STAMP(k)                                                                                        \
+  do {                                                                                                  \
+    if (a.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) { \
+      unsigned long long t_;                                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+      a.dbg[((blockIdx.x == 0) ? 0 : (blockIdx.x == gridDim.x - 1) ? 2 : 1) * L2_NSTAMP + (k)] = t_;  \
+    }                                                                                                   \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 struct PhaseArgs {
   const float* w0;    // QKV: wq[l]   W13: w1[l]   else: the matrix
   const float* w1;    // QKV: wk[l]   W13: w3[l]
@@ -44,13 +60,45 @@ struct PhaseArgs {
   int head_size;
   // tensor parallel: column-sharded WO/W2 write fp64 partials instead of x
   double* partial;    // non-null (WO/W2 of a tensor-parallel rank): out[i] is not written, partial[i] = fp64 sum
+  unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
 };
 
 // ------------------------------------------------------------------------------------------------
+// Cross-lane reductions on the DPP path (register-to-register, ~10 cycles a step) instead of
+// ds_bpermute shuffles (an LDS round trip per step, twice for a 64-bit value): quad swaps, half-row and
+// row mirrors leave every lane with its 16-lane row total, row_bcast15 / row_bcast31 fold the four rows
+// into lane 63, which is then broadcast through a scalar register.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {   // lanes outside ROW_MASK receive 0
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int nlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  const int nhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(nhi, nlo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_f64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_f64<0x140, 0xf>(v);   // row_mirror
+  v += dpp_f64<0x142, 0xa>(v);   // row_bcast15 -> rows 1, 3
+  v += dpp_f64<0x143, 0xc>(v);   // row_bcast31 -> rows 2, 3; lane 63 = total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#define L2_DPP_MAX(CTRL, RM)                                                                              \
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RM, 0xf, false)))
+  L2_DPP_MAX(0xB1, 0xf);
+  L2_DPP_MAX(0x4E, 0xf);
+  L2_DPP_MAX(0x141, 0xf);
+  L2_DPP_MAX(0x140, 0xf);
+  L2_DPP_MAX(0x142, 0xa);   // rows not written keep their own value (old = v)
+  L2_DPP_MAX(0x143, 0xc);
+#undef L2_DPP_MAX
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red, int tid, int nthreads) {
@@ -70,22 +118,283 @@ __device__ __forceinline__ f4 ldg_nt(const float* p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// One dependency phase of a layer = prologue (stage input, optional rmsnorm) + GEMV rows + epilogue.
-// A wave owns R consecutive output rows at a time and strides over the columns 16 B per lane.
-template <int MODE, int R, bool VEC>
+// One dependency phase of a layer = prologue (stage the input vector in LDS, optional rmsnorm) +
+// GEMV over this phase's matrix rows + fused epilogue.
+//
+// Work split: a wave owns R consecutive output rows ("row group") at a time and walks the columns in
+// batches of U x 64 float4 per row, so one batch = R*U independent 16-byte non-temporal loads per lane
+// (R*U KiB per wave).  Two register sets (A/B) are filled alternately: batch b+1 is always issued
+// BEFORE batch b is consumed, across row-group boundaries too, and the first batch is issued before the
+// prologue -- the weight stream never depends on the activations, only the FMAs do.  hipcc turns the
+// in-order load queue into counted `s_waitcnt vmcnt(R*U)` waits, so ~2*R*U KiB per wave stay in flight.
+struct RowGeom { int rows_per_group, groups; };
+
+template <int MODE, int R>
+__device__ __forceinline__ void row_ptrs(const PhaseArgs& a, int g, int n, const float* (&rp)[R]) {
+  if (MODE == MODE_QKV) {
+    const int row0 = g * R;
+    const int m = row0 / a.dim, i0 = row0 - m * a.dim;
+    const float* base = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2;
+#pragma unroll
+    for (int r = 0; r < R; ++r) rp[r] = base + (size_t)min(i0 + r, a.dim - 1) * n;
+  } else if (MODE == MODE_W13) {
+    const int row0 = g * (R / 2);
+#pragma unroll
+    for (int r = 0; r < R / 2; ++r) {
+      const size_t ro = (size_t)min(row0 + r, a.rows - 1) * n;
+      rp[r] = a.w0 + ro;
+      rp[R / 2 + r] = a.w1 + ro;
+    }
+  } else {
+    const int row0 = g * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) rp[r] = a.w0 + (size_t)min(row0 + r, a.rows - 1) * n;
+  }
+}
+
+// Epilogue of one row group; every lane holds every reduced sum, lane p finishes output / pair p.
+template <int MODE, int R>
+__device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const double (&acc)[R], int lane, int token, int pos) {
+  if (MODE == MODE_QKV) {
+    const int row0 = g * R;
+    const int m = row0 / a.dim, i0 = row0 - m * a.dim;
+#pragma unroll
+    for (int p = 0; p < R / 2; ++p) {
+      if (lane == p && i0 + 2 * p < a.dim) {
+        const int i = i0 + 2 * p;
+        const float s0 = (float)acc[2 * p], s1 = (float)acc[2 * p + 1];  // matmul store, llama2.ts:201
+        if (m == 2) {  // v: straight into the cache row (llama2.ts:240)
+          float* vc = a.out_v + (size_t)pos * a.dim;
+          vc[i] = s0; vc[i + 1] = s1;
+          if (a.aux2) { a.aux2[i] = s0; a.aux2[i + 1] = s1; }
+        } else {       // RoPE on the adjacent pair (llama2.ts:224-235)
+          const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
+          const double fcr = a.fr[idx], fci = a.fi[idx];
+          const float o0 = (float)((double)s0 * fcr - (double)s1 * fci);
+          const float o1 = (float)((double)s0 * fci + (double)s1 * fcr);
+          if (m == 0) { a.out[i] = o0; a.out[i + 1] = o1; }
+          else {        // k: cache row (llama2.ts:239)
+            float* kc = a.out_k + (size_t)pos * a.dim;
+            kc[i] = o0; kc[i + 1] = o1;
+            if (a.aux) { a.aux[i] = o0; a.aux[i + 1] = o1; }
+          }
+        }
+      }
+    }
+  } else if (MODE == MODE_W13) {
+    const int row0 = g * (R / 2);
+#pragma unroll
+    for (int p = 0; p < R / 2; ++p) {
+      if (lane == p && row0 + p < a.rows) {
+        const float h1 = (float)acc[p], h3 = (float)acc[R / 2 + p];       // llama2.ts:280-281
+        const double v = h1;
+        const float sl = (float)(v * (1.0 / (1.0 + exp(-v))));            // llama2.ts:285 (store #1)
+        a.out[row0 + p] = (float)((double)sl * (double)h3);                // llama2.ts:289 (store #2)
+        if (a.aux) a.aux[row0 + p] = h3;
+      }
+    }
+  } else if (MODE == MODE_CLS) {
+    const int row0 = g * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (lane == r && row0 + r < a.rows) {
+        const float lg = (float)acc[r];                                     // llama2.ts:302
+        a.out[row0 + r] = lg;
+        if (a.aux2) a.aux2[row0 + r] = lg;   // straight into the host's RunState.logits (pinned, mapped)
+      }
+    }
+  } else {  // WO / W2: matmul store then residual accum (llama2.ts:270-273, 292-295)
+    const int row0 = g * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (lane == r && row0 + r < a.rows) {
+        const int i = row0 + r;
+        if (a.partial) {
+          a.partial[i] = acc[r];
+        } else {
+          const float xr = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : a.res[i];
+          const float mv = (float)acc[r];   // xb2 (WO) / xb (W2) as the reference stores it
+          a.out[i] = xr + mv;
+          if (a.aux) a.aux[i] = mv;
+        }
+      }
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ constexpr bool mode_has_norm() { return MODE == MODE_QKV || MODE == MODE_W13 || MODE == MODE_CLS; }
+
+// Vector path: n % 4 == 0 (every real checkpoint).  LDS: xs[npad4] float4 (zero padded to whole batches),
+// ws[n4] float4 (norm weight, norm modes only), 8 doubles of reduction scratch.
+template <int MODE, int R, int U, int PRE>
 __global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CPI = 64 * U;                       // float4 per row per batch
+  const int n = a.n, n4 = n >> 2;
+  const int nchunks = (n4 + CPI - 1) / CPI;
+  const int npad4 = nchunks * CPI;
+  // PRE = float4 per thread per staging round, picked by the host so one round covers the vector
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  const int nstage4 = ((npad4 + PRE * nthreads - 1) / (PRE * nthreads)) * (PRE * nthreads);  // whole staging rounds
+  f4* xs4 = reinterpret_cast<f4*>(smem);
+  f4* ws4 = xs4 + nstage4;
+  double* red = reinterpret_cast<double*>(smem + (size_t)(nstage4 * (mode_has_norm<MODE>() ? 2 : 1)) * 16);
+
+  const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
+  const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
+  const int wstride = gridDim.x * nwaves;
+  int g = blockIdx.x * nwaves + wave;
+  int ch = 0;
+  bool have = g < groups;
+
+  STAMP(0);
+  f4 bufA[R][U], bufB[R][U];
+  auto issue = [&](f4 (&buf)[R][U], int gi, int ci) {
+    const float* rp[R];
+    row_ptrs<MODE, R>(a, gi, n, rp);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = min(ci * CPI + u * 64 + lane, n4 - 1);   // tail lanes re-read the last float4 (x there is 0)
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[r][u] = ldg_nt(rp[r] + 4 * c);
+    }
+  };
+  double acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.0;
+  auto consume = [&](const f4 (&buf)[R][U], int ci) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f4 xv = xs4[ci * CPI + u * 64 + lane];
+      const double x0 = xv.x, x1 = xv.y, x2 = xv.z, x3 = xv.w;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        acc[r] += (double)buf[r][u].x * x0;
+        acc[r] += (double)buf[r][u].y * x1;
+        acc[r] += (double)buf[r][u].z * x2;
+        acc[r] += (double)buf[r][u].w * x3;
+      }
+    }
+  };
+
+  // ---- prologue: input vector -> LDS (rmsnorm fused, llama2.ts:172-179).
+  // Vector-memory results return in issue order, so the activations are requested FIRST and the first
+  // batch of weights right behind them: waiting for x then costs one L2 round trip while the weight
+  // batch (which depends on nothing) is already in flight.
+  // {token,pos}: requested first, needed late (pos: RoPE / cache row in the epilogue) -- except in layer 0,
+  // where the input IS the embedding row of `token` (llama2.ts:211) and the address waits for it
+  int token = 0, pos = 0;
+  if (MODE == MODE_QKV || MODE == MODE_WO) { token = a.tokpos[0]; pos = a.tokpos[1]; }
+  const float* src = a.in;
+  if (MODE == MODE_QKV) { if (a.emb) src = a.emb + (size_t)token * n; }
+  const f4* src4 = reinterpret_cast<const f4*>(src);
+  const f4* rw4 = reinterpret_cast<const f4*>(a.rmsw);
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  double ss = 0.0, ss1 = 0.0, ss2 = 0.0, ss3 = 0.0;   // four chains: fp64 FMA latency is not on the path
+  auto stage_load = [&](f4 (&xr)[PRE], f4 (&wr)[PRE], int base) {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int cc = min(base + tid + k * nthreads, n4 - 1);
+      xr[k] = src4[cc];
+      if (mode_has_norm<MODE>()) wr[k] = rw4[cc];
+    }
+  };
+  auto stage_store = [&](const f4 (&xr)[PRE], const f4 (&wr)[PRE], int base) {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int c = base + tid + k * nthreads;   // < nstage4: the LDS arrays hold whole staging rounds, so no
+      const f4 xv = (c < n4) ? xr[k] : zero4;    // branch here (a branch lets hipcc sink the load behind the weights)
+      xs4[c] = xv;
+      if (mode_has_norm<MODE>()) {
+        ws4[c] = wr[k];
+        ss += (double)xv.x * (double)xv.x;
+        ss1 += (double)xv.y * (double)xv.y;
+        ss2 += (double)xv.z * (double)xv.z;
+        ss3 += (double)xv.w * (double)xv.w;
+      }
+    }
+  };
+  {
+    f4 xr[PRE], wr[PRE];
+    stage_load(xr, wr, 0);
+    issue(bufA, have ? g : groups - 1, 0);   // queued right behind the activations; unconditional so the
+                                             // compiler's wait for x stays a counted vmcnt(R*U)
+    STAMP(1);
+    stage_store(xr, wr, 0);
+    STAMP(2);
+  }
+  for (int base = PRE * nthreads; base < npad4; base += PRE * nthreads) {
+    f4 xr[PRE], wr[PRE];
+    stage_load(xr, wr, base);
+    stage_store(xr, wr, base);
+  }
+  if (mode_has_norm<MODE>()) {
+    ss = block_sum((ss + ss1) + (ss2 + ss3), red, tid, nthreads);
+    STAMP(3);
+    ss /= (double)n;
+    ss = 1.0 / sqrt(1e-5 + ss);
+    for (int c = tid; c < n4; c += nthreads) {   // same thread, same elements as above: no barrier needed in between
+      const f4 xv = xs4[c], wv = ws4[c];
+      f4 o;
+      o.x = (float)((double)wv.x * (ss * (double)xv.x));
+      o.y = (float)((double)wv.y * (ss * (double)xv.y));
+      o.z = (float)((double)wv.z * (ss * (double)xv.z));
+      o.w = (float)((double)wv.w * (ss * (double)xv.w));
+      xs4[c] = o;
+      if (MODE == MODE_CLS && blockIdx.x == 0) reinterpret_cast<f4*>(a.aux)[c] = o;  // rmsnorm(x, x, ...) in place, llama2.ts:299
+    }
+  }
+  __syncthreads();
+  STAMP(4);
+
+  // ---- GEMV, double buffered over the flattened (row group, column batch) sequence of this wave
+  while (have) {
+    int g2 = g, ch2 = ch + 1;
+    if (ch2 == nchunks) { ch2 = 0; g2 = g + wstride; }
+    const bool have2 = g2 < groups;
+    issue(bufB, have2 ? g2 : g, have2 ? ch2 : ch);   // unconditional: keeps the wait counts uniform
+    consume(bufA, ch);
+    STAMP(5);
+    if (ch == nchunks - 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+      STAMP(6);
+      finish_group<MODE, R>(a, g, acc, lane, token, pos);
+      STAMP(7);
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    }
+    if (!have2) break;
+    int g3 = g2, ch3 = ch2 + 1;
+    if (ch3 == nchunks) { ch3 = 0; g3 = g2 + wstride; }
+    const bool have3 = g3 < groups;
+    issue(bufA, have3 ? g3 : g2, have3 ? ch3 : ch2);
+    consume(bufB, ch2);
+    if (ch2 == nchunks - 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+      finish_group<MODE, R>(a, g2, acc, lane, token, pos);
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    }
+    g = g3; ch = ch3; have = have3;
+  }
+}
+
+// Scalar path for shapes with n % 4 != 0 (rows are not 16-byte aligned): correctness only.
+template <int MODE>
+__global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
+  constexpr int R = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xs = reinterpret_cast<float*>(smem);
   double* red = reinterpret_cast<double*>(smem + (((size_t)a.n * 4 + 15) & ~(size_t)15));
-
   const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   const int n = a.n;
   const int token = a.tokpos[0], pos = a.tokpos[1];
-
-  // ---- prologue: input vector -> LDS (rmsnorm fused, llama2.ts:172-179)
   const float* src = a.in;
-  if ((MODE == MODE_QKV) && a.emb) src = a.emb + (size_t)token * n;  // x.set(embedding row), llama2.ts:211
-  if (MODE == MODE_QKV || MODE == MODE_W13 || MODE == MODE_CLS) {
+  if ((MODE == MODE_QKV) && a.emb) src = a.emb + (size_t)token * n;
+  if (mode_has_norm<MODE>()) {
     double ss = 0.0;
     for (int j = tid; j < n; j += nthreads) { const double v = src[j]; ss += v * v; }
     ss = block_sum(ss, red, tid, nthreads);
@@ -94,130 +403,29 @@ __global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
     for (int j = tid; j < n; j += nthreads) {
       const float o = (float)((double)a.rmsw[j] * (ss * (double)src[j]));
       xs[j] = o;
-      if (MODE == MODE_CLS && blockIdx.x == 0) a.aux[j] = o;  // rmsnorm(x, x, ...) in place, llama2.ts:299
+      if (MODE == MODE_CLS && blockIdx.x == 0) a.aux[j] = o;
     }
   } else {
     for (int j = tid; j < n; j += nthreads) xs[j] = src[j];
   }
   __syncthreads();
-
-  // ---- GEMV: groups of R rows per wave
-  // QKV: rows [0,3*dim) = q rows, k rows, v rows.  W13: group g = rows [g*R/2, ...) of BOTH w1 and w3.
   const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
   const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
   for (int g = blockIdx.x * nwaves + wave; g < groups; g += gridDim.x * nwaves) {
     const float* rp[R];
-    int row0 = g * rows_per_group;
-    if (MODE == MODE_QKV) {
-      const int m = row0 / a.dim, i0 = row0 - m * a.dim;
-      const float* base = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2;
-#pragma unroll
-      for (int r = 0; r < R; ++r) rp[r] = base + (size_t)min(i0 + r, a.dim - 1) * n;
-    } else if (MODE == MODE_W13) {
-#pragma unroll
-      for (int r = 0; r < R / 2; ++r) {
-        const size_t ro = (size_t)min(row0 + r, a.rows - 1) * n;
-        rp[r] = a.w0 + ro;
-        rp[R / 2 + r] = a.w1 + ro;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < R; ++r) rp[r] = a.w0 + (size_t)min(row0 + r, a.rows - 1) * n;
-    }
-
+    row_ptrs<MODE, R>(a, g, n, rp);
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
-
-    if (VEC) {
-      const int n4 = n >> 2;
 #pragma unroll 4
-      for (int c = lane; c < n4; c += 64) {
-        const f4 xv = reinterpret_cast<const f4*>(xs)[c];
-        f4 wv[R];
+    for (int c = lane; c < n; c += 64) {
+      const double xv = xs[c];
 #pragma unroll
-        for (int r = 0; r < R; ++r) wv[r] = ldg_nt(rp[r] + 4 * c);
-        const double x0 = xv.x, x1 = xv.y, x2 = xv.z, x3 = xv.w;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          acc[r] += (double)wv[r].x * x0;
-          acc[r] += (double)wv[r].y * x1;
-          acc[r] += (double)wv[r].z * x2;
-          acc[r] += (double)wv[r].w * x3;
-        }
-      }
-    } else {
-#pragma unroll 4
-      for (int c = lane; c < n; c += 64) {
-        const double xv = xs[c];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] += (double)__builtin_nontemporal_load(rp[r] + c) * xv;
-      }
+      for (int r = 0; r < R; ++r) acc[r] += (double)__builtin_nontemporal_load(rp[r] + c) * xv;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-
-    // ---- epilogue (every lane holds every sum; lane p finishes output / pair p)
-    if (MODE == MODE_QKV) {
-      const int m = row0 / a.dim, i0 = row0 - m * a.dim;
-#pragma unroll
-      for (int p = 0; p < R / 2; ++p) {
-        if (lane == p && i0 + 2 * p < a.dim) {
-          const int i = i0 + 2 * p;
-          const float s0 = (float)acc[2 * p], s1 = (float)acc[2 * p + 1];  // matmul store, llama2.ts:201
-          if (m == 2) {  // v: straight into the cache row (llama2.ts:240)
-            float* vc = a.out_v + (size_t)pos * a.dim;
-            vc[i] = s0; vc[i + 1] = s1;
-            if (a.aux2) { a.aux2[i] = s0; a.aux2[i + 1] = s1; }
-          } else {       // RoPE on the adjacent pair (llama2.ts:224-235)
-            const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
-            const double fcr = a.fr[idx], fci = a.fi[idx];
-            const float o0 = (float)((double)s0 * fcr - (double)s1 * fci);
-            const float o1 = (float)((double)s0 * fci + (double)s1 * fcr);
-            if (m == 0) { a.out[i] = o0; a.out[i + 1] = o1; }
-            else {        // k: cache row (llama2.ts:239)
-              float* kc = a.out_k + (size_t)pos * a.dim;
-              kc[i] = o0; kc[i + 1] = o1;
-              if (a.aux) { a.aux[i] = o0; a.aux[i + 1] = o1; }
-            }
-          }
-        }
-      }
-    } else if (MODE == MODE_W13) {
-#pragma unroll
-      for (int p = 0; p < R / 2; ++p) {
-        if (lane == p && row0 + p < a.rows) {
-          const float h1 = (float)acc[p], h3 = (float)acc[R / 2 + p];       // llama2.ts:280-281
-          const double v = h1;
-          const float s = (float)(v * (1.0 / (1.0 + exp(-v))));              // llama2.ts:285 (store #1)
-          a.out[row0 + p] = (float)((double)s * (double)h3);                  // llama2.ts:289 (store #2)
-          if (a.aux) a.aux[row0 + p] = h3;
-        }
-      }
-    } else if (MODE == MODE_CLS) {
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (lane == r && row0 + r < a.rows) {
-          const float lg = (float)acc[r];                                     // llama2.ts:302
-          a.out[row0 + r] = lg;
-          if (a.aux2) a.aux2[row0 + r] = lg;   // straight into the host's RunState.logits (pinned, mapped)
-        }
-    } else {  // WO / W2: matmul store then residual accum (llama2.ts:270-273, 292-295)
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (lane == r && row0 + r < a.rows) {
-          const int i = row0 + r;
-          if (a.partial) {
-            a.partial[i] = acc[r];
-          } else {
-            const float xr = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : a.res[i];
-            const float mv = (float)acc[r];   // xb2 (WO) / xb (W2) as the reference stores it
-            a.out[i] = xr + mv;
-            if (a.aux) a.aux[i] = mv;
-          }
-        }
-      }
-    }
+    finish_group<MODE, R>(a, g, acc, lane, token, pos);
   }
 }
 
@@ -254,37 +462,33 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   for (int i = tid; i < hs; i += 256) qs[i] = a.q[(size_t)h * hs + i];
   __syncthreads();
 
-  // ---- scores (llama2.ts:249-254)
-  double qv[W];
-#pragma unroll
-  for (int j = 0; j < W; ++j) qv[j] = live ? (double)qs[e0 + j] : 0.0;
+  // ---- scores (llama2.ts:249-254): one thread per timestep, i ascending in fp64 -- the reference's own order
   const double rsq = sqrt((double)hs);
-  const float* kbase = a.kc + (size_t)h * hs + e0;
-  for (int t0 = 0; t0 <= pos; t0 += G) {
-    const int t = t0 + grp;
-    double p = 0.0;
-    if (live && t <= pos) {
-      const float* kp = kbase + (size_t)t * dim;
-      if (VEC) {
-        const f4 kv = *reinterpret_cast<const f4*>(kp);
-        p = qv[0] * (double)kv.x;
-        p += qv[1] * (double)kv.y;
-        p += qv[2] * (double)kv.z;
-        p += qv[3] * (double)kv.w;
-      } else {
-        p = qv[0] * (double)kp[0];
+  for (int t = tid; t <= pos; t += 256) {
+    const float* kp = a.kc + (size_t)t * dim + (size_t)h * hs;
+    double sc = 0.0;
+    if (VEC) {
+      const f4* kp4 = reinterpret_cast<const f4*>(kp);
+      const f4* q4 = reinterpret_cast<const f4*>(qs);
+#pragma unroll 8
+      for (int i = 0; i < hs / 4; ++i) {
+        const f4 kv = kp4[i], qv = q4[i];
+        sc += (double)qv.x * (double)kv.x;
+        sc += (double)qv.y * (double)kv.y;
+        sc += (double)qv.z * (double)kv.z;
+        sc += (double)qv.w * (double)kv.w;
       }
+    } else {
+      for (int i = 0; i < hs; ++i) sc += (double)qs[i] * (double)kp[i];
     }
-    for (int off = lpr >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
-    if (sub == 0 && t <= pos) att[t] = (float)(p / rsq);
+    att[t] = (float)(sc / rsq);
   }
   __syncthreads();
 
   // ---- softmax (llama2.ts:181-194)
   float mx = -INFINITY;
   for (int t = tid; t <= pos; t += 256) mx = fmaxf(mx, att[t]);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  mx = wave_max(mx);
   float* redf = reinterpret_cast<float*>(red);
   if ((tid & 63) == 0) redf[tid >> 6] = mx;
   __syncthreads();
@@ -332,6 +536,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int j = 0; j < W; ++j) o[j] = 0.0;
     if (live) {
+#pragma unroll 4
       for (int t = grp; t <= pos; t += G) {
         const double at = att[t];
         const float* vp = vbase + (size_t)t * dim;
@@ -362,7 +567,19 @@ __global__ void __launch_bounds__(1024) argmax_advance_kernel(const float* logit
   __shared__ int si[16];
   const int tid = threadIdx.x;
   float bv = -INFINITY; int bi = 0x7fffffff;
-  for (int i = tid; i < V; i += 1024) { const float v = logits[i]; if (v > bv) { bv = v; bi = i; } }
+  if ((V & 3) == 0) {   // 16-byte loads, all issued before the first compare
+    const f4* l4 = reinterpret_cast<const f4*>(logits);
+#pragma unroll 8
+    for (int c = tid; c < V / 4; c += 1024) {
+      const f4 v = l4[c];
+      if (v.x > bv) { bv = v.x; bi = 4 * c; }
+      if (v.y > bv) { bv = v.y; bi = 4 * c + 1; }
+      if (v.z > bv) { bv = v.z; bi = 4 * c + 2; }
+      if (v.w > bv) { bv = v.w; bi = 4 * c + 3; }
+    }
+  } else {
+    for (int i = tid; i < V; i += 1024) { const float v = logits[i]; if (v > bv) { bv = v; bi = i; } }
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const float ov = __shfl_xor(bv, off, 64); const int oi = __shfl_xor(bi, off, 64);

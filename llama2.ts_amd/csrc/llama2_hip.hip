@@ -113,6 +113,7 @@ struct l2_ctx {
   float* h_logits_dev = nullptr;  // device alias of h_logits
   int opt_zero_copy = 1;
   int profile_sync = 0;
+  unsigned long long* dbg = nullptr;  // L2_STAMPS builds
 
   hipGraphExec_t g_step = nullptr, g_greedy = nullptr;
   int opt_exact = 0, opt_graph = 1;
@@ -120,7 +121,7 @@ struct l2_ctx {
   bool ran_forward = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // tuning overrides (env)
-  int tune_R = 0, tune_nwaves = 0, tune_gridcap = 0;
+  int tune_R = 0, tune_U = 0, tune_nwaves = 0, tune_gridcap = 0;
 };
 
 static bool is_layered(int kind) { return kind >= L2_T_RMS_ATT && kind <= L2_T_W3; }
@@ -215,6 +216,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->G = G; c->rank = rank;
   c->d_loc = d / G; c->h_loc = h / G; c->H_loc = H / G; c->V_loc = V / G;
   c->tune_R = env_int("L2_TUNE_R", 0);
+  c->tune_U = env_int("L2_TUNE_U", 0);
   c->tune_nwaves = env_int("L2_TUNE_NWAVES", 0);
   c->tune_gridcap = env_int("L2_TUNE_GRIDCAP", 0);
   c->opt_graph = env_int("L2_USE_GRAPH", G == 1 ? 1 : 0);
@@ -262,6 +264,10 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   memset(c->h_logits, 0, (size_t)V * 4);
   CK(hipHostGetDevicePointer((void**)&c->h_logits_dev, c->h_logits, 0));
   c->opt_zero_copy = env_int("L2_ZERO_COPY_LOGITS", G == 1 ? 1 : 0);
+#ifdef L2_STAMPS
+  CK(hipMalloc(&c->dbg, 8 * 64 * 64));
+  CK(hipMemset(c->dbg, 0, 8 * 64 * 64));
+#endif
   CK(hipStreamSynchronize(c->stream));
 #undef CK
   if (G > 1) {
@@ -428,39 +434,71 @@ extern "C" int l2_read_tensor(l2_ctx* c, int kind, int layer, size_t offset, flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// Launch geometry: a wave owns R rows at a time; enough waves to cover every CU several times over,
-// few enough workgroups that the per-workgroup prologue (input vector -> LDS) stays amortised.
-struct Geo { int R, nwaves, grid; bool vec; };
+// Launch geometry.  A wave owns R rows at a time and loads U x 64 float4 per row per batch; see
+// phase_kernel.  (R, U) is picked so one batch is ~16 loads per lane and a short row is one batch; the
+// grid is capped at what is co-resident so every wave loops over several row groups with its two
+// register sets always full (the per-workgroup prologue is then amortised as well).
+struct Geo { int R, U, pre, nwaves, grid; bool vec; };
 
 static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
   Geo g;
   g.vec = (n % 4) == 0;
+  const int n4 = n / 4;
   const int pair = (mode == MODE_W13) ? 2 : 1;  // W13: R covers R/2 rows of w1 + R/2 of w3
-  const int groups4 = (rows * pair + 3) / 4;
-  g.R = (groups4 >= 2048) ? 4 : 2;
-  if (c->tune_R == 2 || c->tune_R == 4) g.R = c->tune_R;
-  if (mode == MODE_QKV && (dim % g.R)) g.R = 2;  // a row group must not straddle wq/wk/wv (dim is even)
+  // Measured on MI355X (tools/sweep_gemv.py, 7B shapes): small batches at high occupancy win -- R = 2 rows,
+  // U = 2..4 (8..16 KiB in flight per wave, <= 64 VGPRs => 8 waves per SIMD) reach 6.0-6.4 TB/s, R = 4 / U = 8
+  // variants (more bytes per wave, fewer waves) stay below 5.5.
+  g.R = 2;
+  (void)dim;
+  int U = (n4 <= 64) ? 1 : 2;                    // a short row is a single batch
+  if (n4 > 128 && n4 <= 256) U = 4;
+  if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4) U = c->tune_U;
+  g.U = U;
   const int groups = (rows * pair + g.R - 1) / g.R;
-  g.nwaves = groups >= 2048 ? 4 : (groups >= 1024 ? 2 : 1);
+  g.nwaves = groups >= 1024 ? 4 : (groups >= 512 ? 2 : 1);
   if (c->tune_nwaves == 1 || c->tune_nwaves == 2 || c->tune_nwaves == 4) g.nwaves = c->tune_nwaves;
+  // staging: PRE float4 per thread per round, one round if it can cover the (padded) vector
+  const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 64 * g.nwaves;
+  g.pre = (npad4 <= nth) ? 1 : (npad4 <= 2 * nth ? 2 : 4);
   int grid = (groups + g.nwaves - 1) / g.nwaves;
-  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : 2048;
+  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : 256 * 6;
   if (grid > cap) grid = cap;
   g.grid = grid < 1 ? 1 : grid;
   return g;
 }
 
+#ifdef L2_STAMPS
+static int g_stamp_slot = 0;   // each launch of the enqueue gets its own 36-stamp slot
+extern "C" int l2_debug_stamps(l2_ctx* c, unsigned long long* out, size_t n) {
+  hipStreamSynchronize(c->stream);
+  return hipMemcpy(out, c->dbg, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
+
 template <int MODE>
-static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
+static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream_t st) {
+  PhaseArgs a = a_in;
+#ifdef L2_STAMPS
+  a.dbg = c->dbg + (size_t)(g_stamp_slot++ % 64) * 36;
+#endif
   const Geo g = pick_geo(c, MODE, a.rows, a.n, a.dim);
-  const size_t lds = (((size_t)a.n * 4 + 15) & ~(size_t)15) + 64;
   const dim3 grid(g.grid), block(64 * g.nwaves);
-  if (g.vec) {
-    if (g.R == 4) hipLaunchKernelGGL((phase_kernel<MODE, 4, true>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((phase_kernel<MODE, 2, true>), grid, block, lds, st, a);
-  } else {
-    hipLaunchKernelGGL((phase_kernel<MODE, 2, false>), grid, block, lds, st, a);
+  if (!g.vec) {
+    const size_t lds = (((size_t)a.n * 4 + 15) & ~(size_t)15) + 64;
+    hipLaunchKernelGGL((phase_kernel_scalar<MODE>), grid, block, lds, st, a);
+    return hipGetLastError();
   }
+  const int n4 = a.n / 4, cpi = 64 * g.U;
+  const int npad4 = ((n4 + cpi - 1) / cpi) * cpi;
+  const bool norm = (MODE == MODE_QKV || MODE == MODE_W13 || MODE == MODE_CLS);
+  const int round4 = g.pre * 64 * g.nwaves;                   // PRE * nthreads (kernels.hip.h)
+  const int nstage4 = ((npad4 + round4 - 1) / round4) * round4;
+  const size_t lds = (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
+#define L2_LAUNCH(UU, PP) hipLaunchKernelGGL((phase_kernel<MODE, 2, UU, PP>), grid, block, lds, st, a)
+#define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else L2_LAUNCH(UU, 4); } while (0)
+  if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
+#undef L2_LAUNCH_U
+#undef L2_LAUNCH
   return hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ import struct
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libllama2hip.so")
+LIB_PATH = os.environ.get("L2_LIB_PATH") or os.path.join(_HERE, "lib", "libllama2hip.so")
 
 T_TOKEN_EMBEDDING, T_RMS_ATT, T_WQ, T_WK, T_WV, T_WO, T_RMS_FFN, T_W1, T_W2, T_W3, T_RMS_FINAL, \
     T_FREQ_REAL, T_FREQ_IMAG, T_WCLS = range(14)
