@@ -35,7 +35,7 @@ WORK = "/tmp/l2_goldens"
 GOLD = os.path.join(ROOT, "tests", "golden")
 CLI = os.path.join(ROOT, "oracle", "build", "oracle_cli")
 
-# name -> (steps, positions whose full logits are kept, keep RunState dumps?, prompt)
+# name -> (steps, positions whose full logits are kept, keep RunState dumps?, prompt[, extra argv, synthetic tokenizer?])
 PLAN = {
     "tiny": (64, "all", True, None),
     "ragged": (33, "all", True, None),
@@ -43,6 +43,11 @@ PLAN = {
     "stories15M_prompt": (24, [3, 4, 23], False, "Once upon a time"),
     "stories110M": (40, [0, 39], False, None),
     "llama2_7b_L2": (6, [0, 5], False, None),
+    # whole-CLI goldens (stdout text): the reference runs with the repo's SYNTHETIC tokenizer.bin in its cwd
+    "cli_greedy": (48, [], False, None, ["-t", "0", "-s", "1"], True),
+    "cli_prompt": (40, [], False, "wetds oyn fra uynia", ["-t", "0", "-s", "1"], True),
+    "cli_temp": (40, [], False, None, ["-t", "0.9", "-s", "42"], True),
+    "cli_topp": (24, [], False, "once", ["-t", "1.0", "-p", "0.9", "-s", "7"], True),
 }
 
 DUMP_STMT = (
@@ -87,8 +92,11 @@ def sha(a):
 
 
 def run_one(inst, name):
-    steps, keep, keep_state, prompt = PLAN[name]
-    shape = name.replace("_prompt", "")
+    plan = PLAN[name]
+    steps, keep, keep_state, prompt = plan[:4]
+    extra = plan[4] if len(plan) > 4 else ["-t", "0", "-s", "1"]
+    synth_tok = plan[5] if len(plan) > 5 else False
+    shape = "stories15M" if name.startswith("cli_") else name.replace("_prompt", "")
     hdr = configs.header(shape)
     seed = configs.DEFAULT_SEED
     ckpt = os.path.join(WORK, shape + ".bin")
@@ -102,10 +110,17 @@ def run_one(inst, name):
     env = dict(os.environ, L2_DUMP=dump)
     if keep_state:
         env["L2_DUMP_STATE"] = "1"
-    cmd = ["node", inst, ckpt, "-t", "0", "-s", "1", "-n", str(steps)]
+    cwd = WORK
+    if synth_tok:   # llama2.ts:444 reads "tokenizer.bin" from the working directory
+        cwd = os.path.join(WORK, "synthtok")
+        os.makedirs(cwd, exist_ok=True)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import synth_tokenizer
+        synth_tokenizer.write(os.path.join(cwd, "tokenizer.bin"))
+    cmd = ["node", inst, ckpt, *extra, "-n", str(steps)]
     if prompt is not None:
         cmd += ["-i", prompt]
-    r = subprocess.run(cmd, cwd=WORK, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    r = subprocess.run(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
     V = abs(hdr[5])
     logits = np.fromfile(dump + ".logits", dtype="<f4").reshape(-1, V)
     tokens = np.fromfile(dump + ".tokens", dtype="<i4")
@@ -120,7 +135,10 @@ def run_one(inst, name):
         "tokens_fed": tokens.tolist(),
         "argmax": [int(np.argmax(logits[i])) for i in range(n)],
         "stdout_tail": r.stdout.decode("utf8", "replace")[-80:],
+        "tokenizer": "synthetic (tests/synth_tokenizer.py)" if synth_tok else "reference tokenizer.bin",
     }
+    if synth_tok:
+        meta["stdout"] = r.stdout.decode("utf8")
     arrays = {}
     if keep == "all":
         arrays["logits"] = logits

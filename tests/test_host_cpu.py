@@ -1,0 +1,60 @@
+"""CPU-side checks of the JS host + N-API addon: builds, loads under the box's node, keeps the reference's
+CLI grammar, and fails loudly (exit 1, no fallback) when no GPU is present."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "llama2.ts_amd", "host", "llama2.mjs")
+
+pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="no node")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as graft
+    graft.build()
+    assert os.path.exists(os.path.join(ROOT, "llama2.ts_amd", "host", "l2_napi.node"))
+
+
+def test_usage_text_matches_reference_contract(built):
+    r = subprocess.run(["node", HOST], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = r.stderr.decode().splitlines()
+    assert r.returncode == 1 and r.stdout == b""
+    assert lines[0] == "Usage: ... llama2.ts <checkpoint> [options]"      # llama2.ts:515
+    assert lines[-1] == "  -i <string> input prompt"                       # llama2.ts:522
+    assert len(lines) == 8
+
+
+def test_flag_grammar(built, tmp_path):
+    for argv in (["m.bin", "-t"], ["m.bin", "t", "1"], ["m.bin", "-tt", "1"], ["m.bin", "-z", "1"]):
+        r = subprocess.run(["node", HOST, *argv], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(tmp_path))
+        assert r.returncode == 1 and b"Usage:" in r.stderr, argv
+
+
+def test_addon_exports_and_fails_without_gpu(built, tmp_path):
+    js = ("const a=require(%r); console.log(Object.keys(a).sort().join(','));"
+          "a.open(%r); try{a.create(new Int32Array([64,176,2,4,4,512,64]),0); console.log('created')}"
+          "catch(e){console.log('ERR '+e.message)}") % (
+        os.path.join(ROOT, "llama2.ts_amd", "host", "l2_napi.node"),
+        os.path.join(ROOT, "llama2.ts_amd", "lib", "libllama2hip.so"))
+    r = subprocess.run(["node", "-e", js], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    out = r.stdout.decode().splitlines()
+    assert out[0] == "create,decodeGreedy,destroy,deviceCount,forward,logitsBuffer,open,readState,setOption,synthFill,upload"
+    import torch
+    if not torch.cuda.is_available():
+        assert out[1].startswith("ERR libllama2hip: no HIP device visible")
+
+
+def test_synthetic_tokenizer_is_deterministic(tmp_path):
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth_tokenizer
+    v, s = synth_tokenizer.write(str(tmp_path / "t.bin"))
+    assert len(v) == 32000 and v[1] == "\n<s>\n" and v[3 + ord("a")] == "a" and len(set(v)) == 32000
+    h = hashlib.sha256(open(tmp_path / "t.bin", "rb").read()).hexdigest()
+    v2, _ = synth_tokenizer.write(str(tmp_path / "t2.bin"))
+    assert v2 == v and hashlib.sha256(open(tmp_path / "t2.bin", "rb").read()).hexdigest() == h
