@@ -97,6 +97,7 @@ struct l2_ctx {
   int G = 1, rank = 0;
   int d_loc, h_loc, H_loc, V_loc;
   nccl_comm comm = nullptr;
+  bool tp_path = false;   // WO/W2 write fp64 partials + all-reduce; logits all-gathered (G > 1, or forced for tests)
 
   float* w[L2_T_COUNT] = {};
   size_t layer_elems[L2_T_COUNT] = {};  // LOCAL floats per layer (or whole tensor when unlayered)
@@ -219,7 +220,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->tune_U = env_int("L2_TUNE_U", 0);
   c->tune_nwaves = env_int("L2_TUNE_NWAVES", 0);
   c->tune_gridcap = env_int("L2_TUNE_GRIDCAP", 0);
-  c->opt_graph = env_int("L2_USE_GRAPH", G == 1 ? 1 : 0);
+  c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !env_int("L2_TP_FORCE_COMM", 0)) ? 1 : 0);
   c->profile_sync = env_int("L2_PROFILE_SYNC", 0);
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
@@ -247,7 +248,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMalloc(&c->q, dl * 4)); CK(hipMalloc(&c->k, dl * 4)); CK(hipMalloc(&c->v, dl * 4));
   CK(hipMalloc(&c->att, (size_t)c->H_loc * S * 4));
   CK(hipMalloc(&c->logits, (size_t)V * 4));
-  if (G > 1) { CK(hipMalloc(&c->logits_loc, (size_t)c->V_loc * 4)); CK(hipMalloc(&c->partial, (size_t)d * 8)); }
+  c->tp_path = G > 1 || env_int("L2_TP_FORCE_COMM", 0);   // the latter: 1-rank communicator, exercises the RCCL path on one GPU
+  if (c->tp_path) { CK(hipMalloc(&c->logits_loc, (size_t)c->V_loc * 4)); CK(hipMalloc(&c->partial, (size_t)d * 8)); }
   else c->logits_loc = c->logits;
   CK(hipMalloc(&c->kc, kv * 4)); CK(hipMalloc(&c->vc, kv * 4));
   CK(hipMemsetAsync(c->kc, 0, kv * 4, c->stream)); CK(hipMemsetAsync(c->vc, 0, kv * 4, c->stream));
@@ -270,11 +272,15 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
 #endif
   CK(hipStreamSynchronize(c->stream));
 #undef CK
-  if (G > 1) {
+  if (G > 1 && env_int("L2_TP_NO_COMM", 0)) {
+    // shard-layout tests on a single GPU: the slices are real, the communicator is absent and every
+    // forward on this context fails with L2_E_COMM
+  } else if (c->tp_path) {
     int rc = rccl_bind();
     if (rc) { l2_destroy(c); return rc; }
     nccl_uid uid;
-    memcpy(&uid, nccl_id, sizeof(uid));
+    if (nccl_id) memcpy(&uid, nccl_id, sizeof(uid));
+    else if (g_rccl.GetUniqueId(&uid) != 0) { l2_destroy(c); return fail(L2_E_COMM, "ncclGetUniqueId failed"); }
     int r = g_rccl.CommInitRank(&c->comm, G, uid, rank);
     if (r != 0) { l2_destroy(c); return fail(L2_E_COMM, "ncclCommInitRank failed: %d", r); }
   }
@@ -561,9 +567,9 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
     a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l;
     a.in = c->xb; a.emb = (l == 0) ? emb : nullptr; a.res = c->x; a.out = c->x; a.aux = c->xb2;
     a.n = c->d_loc; a.rows = c->d;
-    if (c->G > 1) a.partial = c->partial;
+    if (c->tp_path) a.partial = c->partial;
     LCHK(launch_phase<MODE_WO>(c, a, st));
-    if (c->G > 1) {
+    if (c->tp_path) {
       NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st));
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? emb : nullptr, c->partial, c->xb2, c->tokpos, c->d);
       LCHK(hipGetLastError());
@@ -581,11 +587,11 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
     memset(&a, 0, sizeof(a));
     a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
     a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l;
-    a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = (c->G == 1) ? c->xb : nullptr;
+    a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = c->tp_path ? nullptr : c->xb;
     a.n = c->h_loc; a.rows = c->d;
-    if (c->G > 1) a.partial = c->partial;
+    if (c->tp_path) a.partial = c->partial;
     LCHK(launch_phase<MODE_W2>(c, a, st));
-    if (c->G > 1) {
+    if (c->tp_path) {
       NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st));
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, nullptr, c->partial, nullptr, c->tokpos, c->d);
       LCHK(hipGetLastError());
@@ -597,10 +603,10 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
   a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
   a.w0 = c->w[L2_T_WCLS];
   a.in = c->x; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xn;
-  a.aux2 = (to_host && c->opt_zero_copy && c->G == 1) ? c->h_logits_dev : nullptr;
+  a.aux2 = (to_host && c->opt_zero_copy && !c->tp_path) ? c->h_logits_dev : nullptr;
   a.n = c->d; a.rows = c->V_loc;
   LCHK(launch_phase<MODE_CLS>(c, a, st));
-  if (c->G > 1) NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st));
+  if (c->tp_path) NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st));
   return L2_OK;
 }
 
@@ -608,6 +614,7 @@ static int enqueue_forward(l2_ctx* c, hipStream_t st) { return enqueue_forward_i
 static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
 
 static int ensure_ready(l2_ctx* c) {
+  if (c->tp_path && !c->comm) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
   for (int k = 0; k < L2_T_COUNT; ++k) {
     if (k == L2_T_WCLS && c->shared) continue;
     for (size_t l = 0; l < c->uploaded[k].size(); ++l)
@@ -655,7 +662,7 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
     rc = enqueue_forward_host(c, c->stream);
     if (rc) return rc;
   }
-  if (!(c->opt_zero_copy && c->G == 1))
+  if (!(c->opt_zero_copy && !c->tp_path))
     HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
