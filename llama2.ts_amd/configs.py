@@ -10,6 +10,7 @@ CONFIGS = {
     # name: (dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, seq_len)
     "tiny": (64, 176, 2, 4, 4, 512, 64),
     "ragged": (66, 170, 2, 3, 3, -259, 33),          # n % 4 != 0 everywhere, unshared classifier
+    "tinylong": (64, 176, 2, 4, 4, 512, 1280),       # long context at tiny width: crosses every attention split level
     "stories15M": (288, 768, 6, 6, 6, 32000, 256),
     "stories110M": (768, 2048, 12, 12, 12, 32000, 1024),
     "llama2_7b_L2": (4096, 11008, 2, 32, 32, -32000, 2048),   # 7B width, 2 layers (golden-sized)

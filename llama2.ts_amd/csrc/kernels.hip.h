@@ -560,6 +560,153 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Attention split over the timesteps (flash-decode form): grid (head, split).  Split s scores its slice of
+// 0..pos, keeps a local softmax (max m_s, e_t = exp(score - m_s), l_s = sum e_t) and the fp64 value partial
+// acc_s = sum e_t * v_t, publishes {acc_s, l_s, m_s} write-through and takes a ticket; the workgroup that
+// draws the last ticket of its head merges: out = sum_s w_s acc_s / sum_s w_s l_s, w_s = exp(m_s - max m).
+// Hand-off per /opt/skills/guides (one lane's agent-scope atomic add after every storing wave drained its
+// sc1 stores and the workgroup barrier; the last arriver reads with sc1 loads after a barrier).
+// Differs from the reference's roundings (probabilities are not rounded to fp32 before the weighted sum) by
+// ~1e-7 relative -- the default, non-bit-faithful mode only.
+struct AttnSplitArgs {
+  const float* q; const float* kc; const float* vc;
+  float* att; float* xb;
+  const int* tokpos;
+  double* part;            // [H][NS][rec] doubles, rec = round_up(hs + 2, 16)
+  unsigned* counter;       // [H], zero between launches
+  int dim, head_size, seq_len, nsplit, lpr;
+};
+
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) attn_split_kernel(const AttnSplitArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = a.seq_len, hs = a.head_size, dim = a.dim, NS = a.nsplit;
+  const int cmax = (S + NS - 1) / NS;
+  float* es = reinterpret_cast<float*>(smem);                                     // cmax floats
+  float* qs = es + ((cmax + 3) & ~3);                                             // hs floats
+  double* red = reinterpret_cast<double*>(qs + ((hs + 3) & ~3));                  // 16 doubles
+  double* pacc = red + 16;                                                        // G * hs doubles
+  unsigned* ticket = reinterpret_cast<unsigned*>(red + 15);   // all LDS in the one dynamic array (16-byte aligned base)
+
+  const int tid = threadIdx.x, h = blockIdx.x, sp = blockIdx.y;
+  const int T = a.tokpos[1] + 1;
+  const int chunk = (T + NS - 1) / NS;
+  const int t0 = sp * chunk, t1 = min(T, t0 + chunk);
+  constexpr int W = VEC ? 4 : 1;
+  const int lpr = a.lpr, sub = tid & (lpr - 1), grp = tid / lpr, G = 256 / lpr;
+  const int e0 = sub * W;
+  const bool live = e0 < hs;
+  const int rec = (hs + 2 + 15) & ~15;
+  double* mypart = a.part + ((size_t)h * NS + sp) * rec;
+
+  for (int i = tid; i < hs; i += 256) qs[i] = a.q[(size_t)h * hs + i];
+  __syncthreads();
+
+  // scores of this slice (llama2.ts:249-254), one thread per timestep
+  const double rsq = sqrt((double)hs);
+  float mx = -INFINITY;
+  for (int t = t0 + tid; t < t1; t += 256) {
+    const float* kp = a.kc + (size_t)t * dim + (size_t)h * hs;
+    double sc = 0.0;
+    if (VEC) {
+      const f4* kp4 = reinterpret_cast<const f4*>(kp);
+      const f4* q4 = reinterpret_cast<const f4*>(qs);
+#pragma unroll 8
+      for (int i = 0; i < hs / 4; ++i) {
+        const f4 kv = kp4[i], qv = q4[i];
+        sc += (double)qv.x * (double)kv.x;
+        sc += (double)qv.y * (double)kv.y;
+        sc += (double)qv.z * (double)kv.z;
+        sc += (double)qv.w * (double)kv.w;
+      }
+    } else {
+      for (int i = 0; i < hs; ++i) sc += (double)qs[i] * (double)kp[i];
+    }
+    const float sf = (float)(sc / rsq);
+    es[t - t0] = sf;
+    mx = fmaxf(mx, sf);
+  }
+  mx = wave_max(mx);
+  float* redf = reinterpret_cast<float*>(red);
+  if ((tid & 63) == 0) redf[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+  double lsum = 0.0;
+  for (int t = t0 + tid; t < t1; t += 256) {
+    const float e = (float)exp((double)es[t - t0] - (double)mx);
+    es[t - t0] = e;
+    st_sc1(a.att + (size_t)h * S + t, e);      // rescaled to probabilities by the merging workgroup
+    lsum += (double)e;
+  }
+  const double l = block_sum(lsum, red + 8, tid, 256);   // (has the barriers that publish es[])
+
+  // value partial of this slice (llama2.ts:257-265)
+  const float* vbase = a.vc + (size_t)h * hs + e0;
+  double o[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) o[j] = 0.0;
+  if (live) {
+#pragma unroll 4
+    for (int t = t0 + grp; t < t1; t += G) {
+      const double at = es[t - t0];
+      const float* vp = vbase + (size_t)t * dim;
+      if (VEC) {
+        const f4 vv = *reinterpret_cast<const f4*>(vp);
+        o[0] += at * (double)vv.x; o[1] += at * (double)vv.y; o[2] += at * (double)vv.z; o[3] += at * (double)vv.w;
+      } else {
+        o[0] += at * (double)vp[0];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) pacc[(size_t)grp * hs + e0 + j] = o[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < hs; i += 256) {
+    double sacc = 0.0;
+    for (int g2 = 0; g2 < G; ++g2) sacc += pacc[(size_t)g2 * hs + i];
+    st_sc1(mypart + i, sacc);
+  }
+  if (tid == 0) { st_sc1(mypart + hs, l); st_sc1(mypart + hs + 1, (double)mx); }
+
+  // publish: every storing wave drains its write-through stores, barrier, ONE ticket per workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) *ticket = __hip_atomic_fetch_add(a.counter + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*ticket != (unsigned)(NS - 1)) return;
+
+  // ---- last arriver of this head: merge the NS partials (sc1 loads: they bypass this CU's L1)
+  const double* hp = a.part + (size_t)h * NS * rec;
+  double M = -INFINITY;
+  for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, ld_sc1(hp + (size_t)s2 * rec + hs + 1));
+  double Lsum = 0.0;
+  for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + hs);
+  for (int i = tid; i < hs; i += 256) {
+    double num = 0.0;
+    for (int s2 = 0; s2 < NS; ++s2) num += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + i);
+    a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
+  }
+  for (int t = tid; t < T; t += 256) {          // probabilities for parity reads of RunState.att
+    const double ws = exp(ld_sc1(hp + (size_t)(t / chunk) * rec + hs + 1) - M);
+    a.att[(size_t)h * S + t] = (float)((double)ld_sc1(a.att + (size_t)h * S + t) * ws / Lsum);
+  }
+  if (tid == 0) __hip_atomic_store(a.counter + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
 // argmax (llama2.ts:364-366: first maximum, strict '>') + advance {token,pos,step}: keeps the greedy
 // loop (llama2.ts:465-508 at -t 0) on the device.
 __global__ void __launch_bounds__(1024) argmax_advance_kernel(const float* logits, int V, int* tokpos, int* tokens_out) {

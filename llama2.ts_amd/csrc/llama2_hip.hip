@@ -107,6 +107,10 @@ struct l2_ctx {
   float *x = nullptr, *xb = nullptr, *xb2 = nullptr, *hb = nullptr, *hb2 = nullptr, *q = nullptr, *k = nullptr,
         *v = nullptr, *att = nullptr, *logits = nullptr, *logits_loc = nullptr, *kc = nullptr, *vc = nullptr, *xn = nullptr;
   double* partial = nullptr;
+  double* attn_part = nullptr;      // split attention partials [H][NS][rec]
+  unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
+  int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
+  int cur_splits = 1;               // split count of the step being enqueued / captured
   int* tokpos = nullptr;    // device {token,pos,step,0}
   int* h_tokpos = nullptr;  // pinned
   int* d_tokens = nullptr;  // device, S ints
@@ -116,7 +120,7 @@ struct l2_ctx {
   int profile_sync = 0;
   unsigned long long* dbg = nullptr;  // L2_STAMPS builds
 
-  hipGraphExec_t g_step = nullptr, g_greedy = nullptr;
+  hipGraphExec_t g_step[3] = {}, g_greedy[3] = {};   // one captured graph per attention split level
   int opt_exact = 0, opt_graph = 1;
   int next_pos = 0;
   bool ran_forward = false;
@@ -159,9 +163,20 @@ extern "C" int l2_device_count(void) {
 }
 
 static void destroy_graphs(l2_ctx* c) {
-  if (c->g_step) { hipGraphExecDestroy(c->g_step); c->g_step = nullptr; }
-  if (c->g_greedy) { hipGraphExecDestroy(c->g_greedy); c->g_greedy = nullptr; }
+  for (int i = 0; i < 3; ++i) {
+    if (c->g_step[i]) { hipGraphExecDestroy(c->g_step[i]); c->g_step[i] = nullptr; }
+    if (c->g_greedy[i]) { hipGraphExecDestroy(c->g_greedy[i]); c->g_greedy[i] = nullptr; }
+  }
 }
+
+// Attention split level by context length (measured on 7B, tools/longctx.py): one workgroup per head is
+// fastest below ~256 cached timesteps, 4 splits up to ~1024, 8 beyond (pos 1900: 7.4 -> 5.6 ms per token).
+static const int kSplitLevels[3] = {1, 4, 8};
+static int split_level(const l2_ctx* c, int pos) {
+  if (c->attn_splits_forced > 0) return 0;
+  return pos < 256 ? 0 : (pos < 1024 ? 1 : 2);
+}
+static int splits_of(const l2_ctx* c, int level) { return c->attn_splits_forced > 0 ? c->attn_splits_forced : kSplitLevels[level]; }
 
 extern "C" void l2_destroy(l2_ctx* c) {
   if (!c) return;
@@ -175,6 +190,8 @@ extern "C" void l2_destroy(l2_ctx* c) {
   for (float* b : bufs) if (b) hipFree(b);
   if (c->logits_loc && c->logits_loc != c->logits) hipFree(c->logits_loc);
   if (c->partial) hipFree(c->partial);
+  if (c->attn_part) hipFree(c->attn_part);
+  if (c->attn_counter) hipFree(c->attn_counter);
   if (c->tokpos) hipFree(c->tokpos);
   if (c->d_tokens) hipFree(c->d_tokens);
   if (c->h_tokpos) hipHostFree(c->h_tokpos);
@@ -258,6 +275,16 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   for (int i = 0; i < 9; ++i) CK(hipMemsetAsync(zero[i], 0, zn[i] * 4, c->stream));
   CK(hipMemsetAsync(c->att, 0, (size_t)c->H_loc * S * 4, c->stream));
   CK(hipMemsetAsync(c->logits, 0, (size_t)V * 4, c->stream));
+  // split attention scratch (sized for the largest split count)
+  c->attn_splits_forced = env_int("L2_ATTN_SPLITS", 0);
+  if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;
+  {
+    const size_t rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;
+    const int maxs = c->attn_splits_forced > 8 ? c->attn_splits_forced : 8;
+    CK(hipMalloc(&c->attn_part, (size_t)c->H_loc * maxs * rec * 8));
+    CK(hipMalloc(&c->attn_counter, (size_t)c->H_loc * 4));
+    CK(hipMemsetAsync(c->attn_counter, 0, (size_t)c->H_loc * 4, c->stream));
+  }
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
   CK(hipMalloc(&c->d_tokens, (size_t)S * sizeof(int)));
@@ -516,14 +543,26 @@ static int attn_lpr(int hs, bool vec) {
 }
 
 static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
-  AttnArgs a;
   const size_t loff = (size_t)l * c->S * c->d_loc;
+  const bool vec = (c->hs % 4 == 0) && (c->d_loc % 4 == 0);
+  const int lpr = attn_lpr(c->hs, vec);
+  if (lpr > 64) return hipErrorInvalidValue;
+  const int G = 256 / lpr;
+  if (c->cur_splits > 1 && !c->opt_exact) {
+    AttnSplitArgs a;
+    a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb; a.tokpos = c->tokpos;
+    a.part = c->attn_part; a.counter = c->attn_counter;
+    a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.nsplit = c->cur_splits; a.lpr = lpr;
+    const int cmax = (c->S + a.nsplit - 1) / a.nsplit;
+    const size_t lds = (size_t)((cmax + 3) & ~3) * 4 + (size_t)((c->hs + 3) & ~3) * 4 + 128 + (size_t)G * c->hs * 8;
+    if (vec) hipLaunchKernelGGL((attn_split_kernel<true>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((attn_split_kernel<false>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
+    return hipGetLastError();
+  }
+  AttnArgs a;
   a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb; a.tokpos = c->tokpos;
   a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.exact = c->opt_exact;
-  const bool vec = (c->hs % 4 == 0) && (c->d_loc % 4 == 0);
-  a.lpr = attn_lpr(c->hs, vec);
-  if (a.lpr > 64) return hipErrorInvalidValue;
-  const int G = 256 / a.lpr;
+  a.lpr = lpr;
   const size_t lds = (size_t)((c->S + 3) & ~3) * 4 + (size_t)((c->hs + 3) & ~3) * 4 + 64 + (size_t)G * c->hs * 8;
   if (vec) hipLaunchKernelGGL((attn_kernel<true>), dim3(c->H_loc), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((attn_kernel<false>), dim3(c->H_loc), dim3(256), lds, st, a);
@@ -655,9 +694,11 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
   // {token,pos} in and logits out travel as plain stream copies around the replayed kernel graph
   // (memcpy nodes inside a captured graph crash rocprofv3's kernel trace on ROCm 7.2)
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  const int lvl = split_level(c, pos);
+  c->cur_splits = splits_of(c, lvl);
   if (c->opt_graph) {
-    if (!c->g_step) { rc = capture(c, enqueue_forward_host, &c->g_step); if (rc) return rc; }
-    HIPCHK(hipGraphLaunch(c->g_step, c->stream));
+    if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc) return rc; }
+    HIPCHK(hipGraphLaunch(c->g_step[lvl], c->stream));
   } else {
     rc = enqueue_forward_host(c, c->stream);
     if (rc) return rc;
@@ -681,10 +722,17 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   HIPCHK(hipSetDevice(c->device));
   c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  if (c->opt_graph && !c->g_greedy) { rc = capture(c, enqueue_greedy, &c->g_greedy); if (rc) return rc; }
+  if (c->opt_graph) {   // capture what this run needs before the timed region
+    for (int s = 0; s < steps; ++s) {
+      const int lvl = split_level(c, pos0 + s);
+      if (!c->g_greedy[lvl]) { c->cur_splits = splits_of(c, lvl); rc = capture(c, enqueue_greedy, &c->g_greedy[lvl]); if (rc) return rc; }
+    }
+  }
   if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
   for (int s = 0; s < steps; ++s) {
-    if (c->opt_graph) HIPCHK(hipGraphLaunch(c->g_greedy, c->stream));
+    const int lvl = split_level(c, pos0 + s);
+    c->cur_splits = splits_of(c, lvl);
+    if (c->opt_graph) HIPCHK(hipGraphLaunch(c->g_greedy[lvl], c->stream));
     else { rc = enqueue_greedy(c, c->stream); if (rc) return rc; }
     // rocprofv3 (ROCm 7.2) segfaults with thousands of un-synchronised dispatches queued behind it:
     // L2_PROFILE_SYNC=1 drains the stream after every token (kernel durations are unaffected)

@@ -39,6 +39,7 @@ CLI = os.path.join(ROOT, "oracle", "build", "oracle_cli")
 PLAN = {
     "tiny": (64, "all", True, None),
     "ragged": (33, "all", True, None),
+    "tinylong": (1280, [0, 255, 256, 257, 1023, 1024, 1279], False, None),
     "stories15M": (256, [0, 1, 2, 127, 255], False, None),
     "stories15M_prompt": (24, [3, 4, 23], False, "Once upon a time"),
     "stories110M": (40, [0, 39], False, None),

@@ -178,3 +178,46 @@ def test_long_context_full_sequence(built):
         tok = O.argmax(want)
         assert tok == toks[pos]
     ctx.close()
+
+
+@pytest.mark.parametrize("name,splits", [("tiny", 4), ("ragged", 3), ("stories15M", 8)])
+def test_split_attention_matches_reference(built, name, splits):
+    """Flash-decode split of the timesteps over several workgroups per head (default for long contexts)."""
+    meta, g = load_gold(name)
+    os.environ["L2_ATTN_SPLITS"] = str(splits)
+    try:
+        ctx = runtime.Context(meta["header"])
+    finally:
+        del os.environ["L2_ATTN_SPLITS"]
+    ctx.synth_fill(meta["seed"])
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    for pos, tok in enumerate(meta["tokens_fed"]):
+        got = np.array(ctx.forward(tok, pos), copy=True)
+        assert runtime.argmax(got) == meta["argmax"][pos], (name, pos)
+        if pos in keep:
+            assert np.abs(got - g["logits"][keep[pos]]).max() <= TOL
+            if "att" in g.files:
+                H, S = ctx.cfg.n_heads, ctx.cfg.seq_len
+                att = ctx.read_state("att").reshape(H, S)[:, :pos + 1]
+                assert np.abs(att - g["att"][pos].reshape(H, S)[:, :pos + 1]).max() <= 1e-6
+                assert np.abs(ctx.read_state("xb2") - g["xb2"][pos]).max() <= TOL
+    ctx.close()
+
+
+def test_long_context_crosses_every_split_level_token_exact(built):
+    """1280 greedy steps at tiny width: attention runs unsplit (pos < 256), 4-way (< 1024) and 8-way split;
+    the token stream and the logits at the level boundaries must still equal the TRUE reference's."""
+    meta, g = load_gold("tinylong")
+    ctx = runtime.Context(meta["header"])
+    ctx.synth_fill(meta["seed"])
+    toks = ctx.decode_greedy(1, 0, meta["steps_run"])
+    assert toks.tolist() == meta["argmax"]
+    ctx.close()
+    ctx = runtime.Context(meta["header"])
+    ctx.synth_fill(meta["seed"])
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    for pos, tok in enumerate(meta["tokens_fed"]):
+        got = ctx.forward(tok, pos)
+        if pos in keep:
+            assert np.abs(got - g["logits"][keep[pos]]).max() <= TOL, pos
+    ctx.close()

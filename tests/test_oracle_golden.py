@@ -26,7 +26,7 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("name", ["tiny", "ragged", "stories15M", "stories15M_prompt", "stories110M", "llama2_7b_L2"])
+@pytest.mark.parametrize("name", ["tiny", "ragged", "tinylong", "stories15M", "stories15M_prompt", "stories110M", "llama2_7b_L2"])
 def test_oracle_matches_reference_bit_for_bit(name):
     meta, g = load(name)
     o = O.Oracle(meta["header"], meta["seed"])
