@@ -22,6 +22,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_QKV = 0, MODE_WO = 1, MODE_W13 = 2, MODE_W2 = 3, MODE_CLS = 4 };
 
+// Hand-off counters sit one per 128-byte line: atomics on one line serialise at ~12 ns each at the memory side
+// (6144 adds on one line cost a 7B layer 74 us; spread over 32 lines they overlap).
+enum { CTR_STRIDE = 32 };
+
 // Diagnostic build only (-DL2_STAMPS, tools/stamps.py): shader-clock stamps of wave 0 of a few workgroups go
 // to a buffer nothing else reads.  In the product build STAMP() is empty.
 #ifdef L2_STAMPS
@@ -61,6 +65,7 @@ struct PhaseArgs {
   // tensor parallel: column-sharded WO/W2 write fp64 partials instead of x
   double* partial;    // non-null (WO/W2 of a tensor-parallel rank): out[i] is not written, partial[i] = fp64 sum
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
+  unsigned* head_done;      // QKV fused with attention: per-head count of finished row groups (else null)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -127,13 +132,35 @@ __device__ __forceinline__ f4 ldg_nt(const float* p) {
 // BEFORE batch b is consumed, across row-group boundaries too, and the first batch is issued before the
 // prologue -- the weight stream never depends on the activations, only the FMAs do.  hipcc turns the
 // in-order load queue into counted `s_waitcnt vmcnt(R*U)` waits, so ~2*R*U KiB per wave stay in flight.
-struct RowGeom { int rows_per_group, groups; };
+// write-through (sc1) stores / L1-bypassing loads: relaxed agent-scope atomics (hand-offs inside a launch)
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+
+// QKV row groups are ordered head-major: all q, k and v rows of head 0, then head 1, ... so a head's three
+// projections finish together and attention on it can start while later heads are still streaming.
+__device__ __forceinline__ void qkv_group(const PhaseArgs& a, int g, int R, int& m, int& i0) {
+  const int per_mat = a.head_size / R, per_head = 3 * per_mat;
+  const int head = g / per_head, rem = g - head * per_head;
+  m = rem / per_mat;
+  i0 = head * a.head_size + (rem - m * per_mat) * R;
+}
 
 template <int MODE, int R>
 __device__ __forceinline__ void row_ptrs(const PhaseArgs& a, int g, int n, const float* (&rp)[R]) {
   if (MODE == MODE_QKV) {
-    const int row0 = g * R;
-    const int m = row0 / a.dim, i0 = row0 - m * a.dim;
+    int m, i0;
+    qkv_group(a, g, R, m, i0);
     const float* base = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2;
 #pragma unroll
     for (int r = 0; r < R; ++r) rp[r] = base + (size_t)min(i0 + r, a.dim - 1) * n;
@@ -156,8 +183,9 @@ __device__ __forceinline__ void row_ptrs(const PhaseArgs& a, int g, int n, const
 template <int MODE, int R>
 __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const double (&acc)[R], int lane, int token, int pos) {
   if (MODE == MODE_QKV) {
-    const int row0 = g * R;
-    const int m = row0 / a.dim, i0 = row0 - m * a.dim;
+    int m, i0;
+    qkv_group(a, g, R, m, i0);
+    const bool hand = a.head_done != nullptr;   // attention waits inside this launch: publish write-through
 #pragma unroll
     for (int p = 0; p < R / 2; ++p) {
       if (lane == p && i0 + 2 * p < a.dim) {
@@ -166,20 +194,28 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         if (m == 2) {  // v: straight into the cache row (llama2.ts:240)
           float* vc = a.out_v + (size_t)pos * a.dim;
           vc[i] = s0; vc[i + 1] = s1;
-          if (a.aux2) { a.aux2[i] = s0; a.aux2[i + 1] = s1; }
+          if (hand) { st_sc1(a.aux2 + i, s0); st_sc1(a.aux2 + i + 1, s1); }
+          else if (a.aux2) { a.aux2[i] = s0; a.aux2[i + 1] = s1; }
         } else {       // RoPE on the adjacent pair (llama2.ts:224-235)
           const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
           const double fcr = a.fr[idx], fci = a.fi[idx];
           const float o0 = (float)((double)s0 * fcr - (double)s1 * fci);
           const float o1 = (float)((double)s0 * fci + (double)s1 * fcr);
-          if (m == 0) { a.out[i] = o0; a.out[i + 1] = o1; }
-          else {        // k: cache row (llama2.ts:239)
+          if (m == 0) {
+            if (hand) { st_sc1(a.out + i, o0); st_sc1(a.out + i + 1, o1); }
+            else { a.out[i] = o0; a.out[i + 1] = o1; }
+          } else {        // k: cache row (llama2.ts:239)
             float* kc = a.out_k + (size_t)pos * a.dim;
             kc[i] = o0; kc[i + 1] = o1;
-            if (a.aux) { a.aux[i] = o0; a.aux[i + 1] = o1; }
+            if (hand) { st_sc1(a.aux + i, o0); st_sc1(a.aux + i + 1, o1); }
+            else if (a.aux) { a.aux[i] = o0; a.aux[i + 1] = o1; }
           }
         }
       }
+    }
+    if (hand) {   // this wave's stores are out (write-through) before its ticket counts for the head
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(a.head_done + (size_t)(i0 / a.head_size) * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else if (MODE == MODE_W13) {
     const int row0 = g * (R / 2);
@@ -228,8 +264,7 @@ __device__ __forceinline__ constexpr bool mode_has_norm() { return MODE == MODE_
 // Vector path: n % 4 == 0 (every real checkpoint).  LDS: xs[npad4] float4 (zero padded to whole batches),
 // ws[n4] float4 (norm weight, norm modes only), 8 doubles of reduction scratch.
 template <int MODE, int R, int U, int PRE>
-__global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const int vblock, const int vgrid) {
   constexpr int CPI = 64 * U;                       // float4 per row per batch
   const int n = a.n, n4 = n >> 2;
   const int nchunks = (n4 + CPI - 1) / CPI;
@@ -243,8 +278,8 @@ __global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
 
   const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
   const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
-  const int wstride = gridDim.x * nwaves;
-  int g = blockIdx.x * nwaves + wave;
+  const int wstride = vgrid * nwaves;
+  int g = vblock * nwaves + wave;
   int ch = 0;
   bool have = g < groups;
 
@@ -342,7 +377,7 @@ __global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
       o.z = (float)((double)wv.z * (ss * (double)xv.z));
       o.w = (float)((double)wv.w * (ss * (double)xv.w));
       xs4[c] = o;
-      if (MODE == MODE_CLS && blockIdx.x == 0) reinterpret_cast<f4*>(a.aux)[c] = o;  // rmsnorm(x, x, ...) in place, llama2.ts:299
+      if (MODE == MODE_CLS && vblock == 0) reinterpret_cast<f4*>(a.aux)[c] = o;  // rmsnorm(x, x, ...) in place, llama2.ts:299
     }
   }
   __syncthreads();
@@ -380,6 +415,12 @@ __global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
     }
     g = g3; ch = ch3; have = have3;
   }
+}
+
+template <int MODE, int R, int U, int PRE>
+__global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  phase_body<MODE, R, U, PRE>(a, smem, blockIdx.x, gridDim.x);
 }
 
 // Scalar path for shapes with n % 4 != 0 (rows are not 16-byte aligned): correctness only.
@@ -430,59 +471,112 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Multi-head attention for one layer (llama2.ts:244-267): one workgroup per head.
+// Multi-head attention for one layer (llama2.ts:244-267).
+//
+// Two forms share AttnArgs: attn_body (one workgroup per head; keeps every rounding of the reference, and the
+// bit-faithful value accumulate when `exact`) and attn_split_body (timesteps split over `nsplit` workgroups
+// per head, flash-decode merge by the last arriver -- long contexts).  Either runs as its own kernel or as the
+// leading workgroups of qkv_attn_kernel, where it waits on `head_done[h]` for the head's q / k / v rows of
+// THIS position to be produced by the GEMV waves of the same launch (`fused`); those rows (q, and the new k and
+// v from the k / v scratch vectors, written write-through) are read with L1-bypassing loads into LDS, every
+// older cache row was written by earlier launches and is read normally.
 struct AttnArgs {
   const float* q;        // (dim) rotated q
+  const float* knew;     // (dim) this position's k (RunState.k)   -- same values as cache row `pos`
+  const float* vnew;     // (dim) this position's v (RunState.v)
   const float* kc;       // key_cache   + l*S*d
   const float* vc;       // value_cache + l*S*d
   float* att;            // (H, S) scores / probabilities (kept for parity reads)
   float* xb;             // (dim) out
   const int* tokpos;
-  int dim, head_size, seq_len;
+  double* part;          // split form: [H][nsplit][rec] doubles, rec = round_up(hs + 2, 16)
+  unsigned* counter;     // split form: [H] merge tickets, zero between launches
+  unsigned* head_done;   // fused form: [H] finished q/k/v row groups of the head, zero between launches
+  int* err;              // set to 1 if a bounded wait gives up
+  unsigned expect;       // fused form: row groups per head (3 * head_size / R)
+  int fused;
+  int dim, head_size, seq_len, n_heads, nsplit;
   int exact;             // 1: fp32-rounded t-sequential value accumulate (llama2.ts:263)
   int lpr;               // lanes per timestep row (power of two >= ceil(head_size / vecw))
 };
 
+__device__ __forceinline__ unsigned ld_sc1(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// q.k over one head, i ascending in fp64 -- the reference's own summation order (llama2.ts:252)
+template <bool VEC, class KP>
+__device__ __forceinline__ double head_dot(const float* qs, KP kp, int hs) {
+  double sc = 0.0;
+  if (VEC) {
+    const f4* q4 = reinterpret_cast<const f4*>(qs);
+#pragma unroll 8
+    for (int i = 0; i < hs / 4; ++i) {
+      const f4 kv = reinterpret_cast<const f4*>(kp)[i], qv = q4[i];
+      sc += (double)qv.x * (double)kv.x;
+      sc += (double)qv.y * (double)kv.y;
+      sc += (double)qv.z * (double)kv.z;
+      sc += (double)qv.w * (double)kv.w;
+    }
+  } else {
+    for (int i = 0; i < hs; ++i) sc += (double)qs[i] * (double)kp[i];
+  }
+  return sc;
+}
+
+// Wait (bounded) until the GEMV waves of this launch have finished every q/k/v row group of head h, then
+// stage q and the new k / v rows in LDS.  Not fused: plain copies, no wait.
+__device__ __forceinline__ void attn_stage(const AttnArgs& a, int h, int tid, float* qs, float* kn, float* vn) {
+  const int hs = a.head_size;
+  if (a.fused) {
+    if (tid == 0) {
+      unsigned spins = 0;
+      while (ld_sc1(a.head_done + (size_t)h * CTR_STRIDE) < a.expect) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) { *a.err = 1; break; }   // never hang the GPU: give up, the host reports it
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < hs; i += 256) {
+      qs[i] = ld_sc1(a.q + (size_t)h * hs + i);
+      kn[i] = ld_sc1(a.knew + (size_t)h * hs + i);
+      vn[i] = ld_sc1(a.vnew + (size_t)h * hs + i);
+    }
+  } else {
+    for (int i = tid; i < hs; i += 256) {
+      qs[i] = a.q[(size_t)h * hs + i];
+      kn[i] = a.knew[(size_t)h * hs + i];
+      vn[i] = a.vnew[(size_t)h * hs + i];
+    }
+  }
+  __syncthreads();
+}
+
 template <bool VEC>
-__global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int S = a.seq_len, hs = a.head_size, dim = a.dim;
+__device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const int h) {
+  const int S = a.seq_len, hs = a.head_size, dim = a.dim, hs4 = (hs + 3) & ~3;
   float* att = reinterpret_cast<float*>(smem);                                   // S floats
   float* qs = att + ((S + 3) & ~3);                                               // hs floats
-  double* red = reinterpret_cast<double*>(qs + ((hs + 3) & ~3));                  // 8 doubles
+  float* kn = qs + hs4;
+  float* vn = kn + hs4;
+  double* red = reinterpret_cast<double*>(vn + hs4);                              // 8 doubles
   double* pacc = red + 8;                                                         // G * hs doubles
 
-  const int tid = threadIdx.x, h = blockIdx.x;
+  const int tid = threadIdx.x;
   const int pos = a.tokpos[1];
   constexpr int W = VEC ? 4 : 1;
   const int lpr = a.lpr, sub = tid & (lpr - 1), grp = tid / lpr, G = 256 / lpr;
   const int e0 = sub * W;                       // first element of this lane inside the head
   const bool live = e0 < hs;
 
-  for (int i = tid; i < hs; i += 256) qs[i] = a.q[(size_t)h * hs + i];
-  __syncthreads();
+  attn_stage(a, h, tid, qs, kn, vn);
+  if (a.fused && tid == 0) __hip_atomic_store(a.head_done + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-  // ---- scores (llama2.ts:249-254): one thread per timestep, i ascending in fp64 -- the reference's own order
+  // ---- scores (llama2.ts:249-254): one thread per timestep
   const double rsq = sqrt((double)hs);
-  for (int t = tid; t <= pos; t += 256) {
-    const float* kp = a.kc + (size_t)t * dim + (size_t)h * hs;
-    double sc = 0.0;
-    if (VEC) {
-      const f4* kp4 = reinterpret_cast<const f4*>(kp);
-      const f4* q4 = reinterpret_cast<const f4*>(qs);
-#pragma unroll 8
-      for (int i = 0; i < hs / 4; ++i) {
-        const f4 kv = kp4[i], qv = q4[i];
-        sc += (double)qv.x * (double)kv.x;
-        sc += (double)qv.y * (double)kv.y;
-        sc += (double)qv.z * (double)kv.z;
-        sc += (double)qv.w * (double)kv.w;
-      }
-    } else {
-      for (int i = 0; i < hs; ++i) sc += (double)qs[i] * (double)kp[i];
-    }
-    att[t] = (float)(sc / rsq);
-  }
+  for (int t = tid; t < pos; t += 256)
+    att[t] = (float)(head_dot<VEC>(qs, a.kc + (size_t)t * dim + (size_t)h * hs, hs) / rsq);
+  if (tid == (pos & 255)) att[pos] = (float)(head_dot<VEC>(qs, kn, hs) / rsq);
   __syncthreads();
 
   // ---- softmax (llama2.ts:181-194)
@@ -515,18 +609,16 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
       float o[W];
 #pragma unroll
       for (int j = 0; j < W; ++j) o[j] = 0.0f;
-      for (int t = 0; t <= pos; ++t) {
+      for (int t = 0; t < pos; ++t) {
         const double at = att[t];
         const float* vp = vbase + (size_t)t * dim;
-        if (VEC) {
-          const f4 vv = *reinterpret_cast<const f4*>(vp);
-          o[0] = (float)((double)o[0] + at * (double)vv.x);
-          o[1] = (float)((double)o[1] + at * (double)vv.y);
-          o[2] = (float)((double)o[2] + at * (double)vv.z);
-          o[3] = (float)((double)o[3] + at * (double)vv.w);
-        } else {
-          o[0] = (float)((double)o[0] + at * (double)vp[0]);
-        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) o[j] = (float)((double)o[j] + at * (double)vp[j]);
+      }
+      {
+        const double at = att[pos];
+#pragma unroll
+        for (int j = 0; j < W; ++j) o[j] = (float)((double)o[j] + at * (double)vn[e0 + j]);
       }
 #pragma unroll
       for (int j = 0; j < W; ++j) a.xb[(size_t)h * hs + e0 + j] = o[j];
@@ -537,7 +629,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     for (int j = 0; j < W; ++j) o[j] = 0.0;
     if (live) {
 #pragma unroll 4
-      for (int t = grp; t <= pos; t += G) {
+      for (int t = grp; t < pos; t += G) {
         const double at = att[t];
         const float* vp = vbase + (size_t)t * dim;
         if (VEC) {
@@ -547,64 +639,55 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
           o[0] += at * (double)vp[0];
         }
       }
+      if (grp == (pos % G)) {
+        const double at = att[pos];
+#pragma unroll
+        for (int j = 0; j < W; ++j) o[j] += at * (double)vn[e0 + j];
+      }
 #pragma unroll
       for (int j = 0; j < W; ++j) pacc[(size_t)grp * hs + e0 + j] = o[j];
     }
     __syncthreads();
     for (int i = tid; i < hs; i += 256) {
-      double s = 0.0;
-      for (int g2 = 0; g2 < G; ++g2) s += pacc[(size_t)g2 * hs + i];
-      a.xb[(size_t)h * hs + i] = (float)s;
+      double sacc = 0.0;
+      for (int g2 = 0; g2 < G; ++g2) sacc += pacc[(size_t)g2 * hs + i];
+      a.xb[(size_t)h * hs + i] = (float)sacc;
     }
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Attention split over the timesteps (flash-decode form): grid (head, split).  Split s scores its slice of
-// 0..pos, keeps a local softmax (max m_s, e_t = exp(score - m_s), l_s = sum e_t) and the fp64 value partial
-// acc_s = sum e_t * v_t, publishes {acc_s, l_s, m_s} write-through and takes a ticket; the workgroup that
-// draws the last ticket of its head merges: out = sum_s w_s acc_s / sum_s w_s l_s, w_s = exp(m_s - max m).
-// Hand-off per /opt/skills/guides (one lane's agent-scope atomic add after every storing wave drained its
-// sc1 stores and the workgroup barrier; the last arriver reads with sc1 loads after a barrier).
-// Differs from the reference's roundings (probabilities are not rounded to fp32 before the weighted sum) by
-// ~1e-7 relative -- the default, non-bit-faithful mode only.
-struct AttnSplitArgs {
-  const float* q; const float* kc; const float* vc;
-  float* att; float* xb;
-  const int* tokpos;
-  double* part;            // [H][NS][rec] doubles, rec = round_up(hs + 2, 16)
-  unsigned* counter;       // [H], zero between launches
-  int dim, head_size, seq_len, nsplit, lpr;
-};
-
-__device__ __forceinline__ void st_sc1(double* p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_sc1(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_sc1(float* p, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_sc1(const float* p) {
-  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
 template <bool VEC>
-__global__ void __launch_bounds__(256) attn_split_kernel(const AttnSplitArgs a) {
+__global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int S = a.seq_len, hs = a.head_size, dim = a.dim, NS = a.nsplit;
+  attn_body<VEC>(a, smem, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split form (flash-decode): split s scores its slice of 0..pos, keeps a local softmax (max m_s,
+// e_t = exp(score - m_s), l_s = sum e_t) and the fp64 value partial acc_s = sum e_t * v_t, publishes
+// {acc_s, l_s, m_s} write-through and takes a ticket; the workgroup that draws the last ticket of its head
+// merges: out = sum_s w_s acc_s / sum_s w_s l_s, w_s = exp(m_s - max m).  Hand-off per the MI355X guide: one
+// lane's agent-scope atomic add after every storing wave drained its sc1 stores and the workgroup barrier; the
+// last arriver reads with sc1 loads after a barrier.  Probabilities are not rounded to fp32 before the weighted
+// sum here (~1e-7 relative vs the reference): default mode only, never with `exact`.
+template <bool VEC>
+__device__ __forceinline__ void attn_split_body(const AttnArgs& a, char* smem, const int h, const int sp) {
+  const int S = a.seq_len, hs = a.head_size, dim = a.dim, NS = a.nsplit, hs4 = (hs + 3) & ~3;
   const int cmax = (S + NS - 1) / NS;
   float* es = reinterpret_cast<float*>(smem);                                     // cmax floats
   float* qs = es + ((cmax + 3) & ~3);                                             // hs floats
-  double* red = reinterpret_cast<double*>(qs + ((hs + 3) & ~3));                  // 16 doubles
+  float* kn = qs + hs4;
+  float* vn = kn + hs4;
+  double* red = reinterpret_cast<double*>(vn + hs4);                              // 16 doubles
   double* pacc = red + 16;                                                        // G * hs doubles
   unsigned* ticket = reinterpret_cast<unsigned*>(red + 15);   // all LDS in the one dynamic array (16-byte aligned base)
 
-  const int tid = threadIdx.x, h = blockIdx.x, sp = blockIdx.y;
-  const int T = a.tokpos[1] + 1;
+  const int tid = threadIdx.x;
+  const int pos = a.tokpos[1], T = pos + 1;
   const int chunk = (T + NS - 1) / NS;
   const int t0 = sp * chunk, t1 = min(T, t0 + chunk);
+  const int tg = min(t1, pos);                  // [t0, tg) comes from the cache, t == pos from LDS
+  const bool has_new = (t1 == T) && (t0 <= pos);
   constexpr int W = VEC ? 4 : 1;
   const int lpr = a.lpr, sub = tid & (lpr - 1), grp = tid / lpr, G = 256 / lpr;
   const int e0 = sub * W;
@@ -612,31 +695,19 @@ __global__ void __launch_bounds__(256) attn_split_kernel(const AttnSplitArgs a) 
   const int rec = (hs + 2 + 15) & ~15;
   double* mypart = a.part + ((size_t)h * NS + sp) * rec;
 
-  for (int i = tid; i < hs; i += 256) qs[i] = a.q[(size_t)h * hs + i];
-  __syncthreads();
+  attn_stage(a, h, tid, qs, kn, vn);
 
   // scores of this slice (llama2.ts:249-254), one thread per timestep
   const double rsq = sqrt((double)hs);
   float mx = -INFINITY;
-  for (int t = t0 + tid; t < t1; t += 256) {
-    const float* kp = a.kc + (size_t)t * dim + (size_t)h * hs;
-    double sc = 0.0;
-    if (VEC) {
-      const f4* kp4 = reinterpret_cast<const f4*>(kp);
-      const f4* q4 = reinterpret_cast<const f4*>(qs);
-#pragma unroll 8
-      for (int i = 0; i < hs / 4; ++i) {
-        const f4 kv = kp4[i], qv = q4[i];
-        sc += (double)qv.x * (double)kv.x;
-        sc += (double)qv.y * (double)kv.y;
-        sc += (double)qv.z * (double)kv.z;
-        sc += (double)qv.w * (double)kv.w;
-      }
-    } else {
-      for (int i = 0; i < hs; ++i) sc += (double)qs[i] * (double)kp[i];
-    }
-    const float sf = (float)(sc / rsq);
+  for (int t = t0 + tid; t < tg; t += 256) {
+    const float sf = (float)(head_dot<VEC>(qs, a.kc + (size_t)t * dim + (size_t)h * hs, hs) / rsq);
     es[t - t0] = sf;
+    mx = fmaxf(mx, sf);
+  }
+  if (has_new && tid == ((pos - t0) & 255)) {
+    const float sf = (float)(head_dot<VEC>(qs, kn, hs) / rsq);
+    es[pos - t0] = sf;
     mx = fmaxf(mx, sf);
   }
   mx = wave_max(mx);
@@ -660,7 +731,7 @@ __global__ void __launch_bounds__(256) attn_split_kernel(const AttnSplitArgs a) 
   for (int j = 0; j < W; ++j) o[j] = 0.0;
   if (live) {
 #pragma unroll 4
-    for (int t = t0 + grp; t < t1; t += G) {
+    for (int t = t0 + grp; t < tg; t += G) {
       const double at = es[t - t0];
       const float* vp = vbase + (size_t)t * dim;
       if (VEC) {
@@ -669,6 +740,11 @@ __global__ void __launch_bounds__(256) attn_split_kernel(const AttnSplitArgs a) 
       } else {
         o[0] += at * (double)vp[0];
       }
+    }
+    if (has_new && grp == ((pos - t0) % G)) {
+      const double at = es[pos - t0];
+#pragma unroll
+      for (int j = 0; j < W; ++j) o[j] += at * (double)vn[e0 + j];
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) pacc[(size_t)grp * hs + e0 + j] = o[j];
@@ -684,7 +760,7 @@ __global__ void __launch_bounds__(256) attn_split_kernel(const AttnSplitArgs a) 
   // publish: every storing wave drains its write-through stores, barrier, ONE ticket per workgroup
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) *ticket = __hip_atomic_fetch_add(a.counter + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) *ticket = __hip_atomic_fetch_add(a.counter + (size_t)h * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (*ticket != (unsigned)(NS - 1)) return;
 
@@ -703,7 +779,34 @@ __global__ void __launch_bounds__(256) attn_split_kernel(const AttnSplitArgs a) 
     const double ws = exp(ld_sc1(hp + (size_t)(t / chunk) * rec + hs + 1) - M);
     a.att[(size_t)h * S + t] = (float)((double)ld_sc1(a.att + (size_t)h * S + t) * ws / Lsum);
   }
-  if (tid == 0) __hip_atomic_store(a.counter + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {   // every split of this head has passed its wait and taken its ticket: re-arm both counters
+    __hip_atomic_store(a.counter + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.fused) __hip_atomic_store(a.head_done + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) attn_split_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_split_body<VEC>(a, smem, blockIdx.x, blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rmsnorm + q,k,v GEMVs + RoPE + KV store AND the attention of the same layer in ONE launch: workgroups
+// [0, nattn) are attention workgroups (head = id % H, split = id / H) that wait per head, the rest stream
+// the wq/wk/wv rows head-major and tick head_done[] as each head's rows land.  Attention of head h overlaps
+// the weight stream of heads h+1.. and one kernel boundary per layer disappears.  Progress does not depend
+// on co-residency: the GEMV workgroups never wait, so queued ones always get the slots they free.
+template <int U, int PRE, bool SPLIT>
+__global__ void __launch_bounds__(256) qkv_attn_kernel(const PhaseArgs pa, const AttnArgs aa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nattn = aa.n_heads * (SPLIT ? aa.nsplit : 1);
+  if ((int)blockIdx.x < nattn) {
+    if (SPLIT) attn_split_body<true>(aa, smem, blockIdx.x % aa.n_heads, blockIdx.x / aa.n_heads);
+    else attn_body<true>(aa, smem, blockIdx.x);
+  } else {
+    phase_body<MODE_QKV, 2, U, PRE>(pa, smem, blockIdx.x - nattn, gridDim.x - nattn);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

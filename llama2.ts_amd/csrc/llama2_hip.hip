@@ -111,6 +111,10 @@ struct l2_ctx {
   unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int cur_splits = 1;               // split count of the step being enqueued / captured
+  unsigned* head_done = nullptr;    // [H] fused QKV+attention hand-off counters, zero between launches
+  int* h_err = nullptr;             // pinned + mapped: set by a kernel whose bounded wait gave up
+  int* h_err_dev = nullptr;
+  int opt_fuse = 0;                 // L2_FUSE_ATTN: attention inside the QKV launch (experimental)
   int* tokpos = nullptr;    // device {token,pos,step,0}
   int* h_tokpos = nullptr;  // pinned
   int* d_tokens = nullptr;  // device, S ints
@@ -192,6 +196,8 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->partial) hipFree(c->partial);
   if (c->attn_part) hipFree(c->attn_part);
   if (c->attn_counter) hipFree(c->attn_counter);
+  if (c->head_done) hipFree(c->head_done);
+  if (c->h_err) hipHostFree(c->h_err);
   if (c->tokpos) hipFree(c->tokpos);
   if (c->d_tokens) hipFree(c->d_tokens);
   if (c->h_tokpos) hipHostFree(c->h_tokpos);
@@ -282,8 +288,14 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     const size_t rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;
     const int maxs = c->attn_splits_forced > 8 ? c->attn_splits_forced : 8;
     CK(hipMalloc(&c->attn_part, (size_t)c->H_loc * maxs * rec * 8));
-    CK(hipMalloc(&c->attn_counter, (size_t)c->H_loc * 4));
-    CK(hipMemsetAsync(c->attn_counter, 0, (size_t)c->H_loc * 4, c->stream));
+    CK(hipMalloc(&c->attn_counter, (size_t)c->H_loc * CTR_STRIDE * 4));
+    CK(hipMemsetAsync(c->attn_counter, 0, (size_t)c->H_loc * CTR_STRIDE * 4, c->stream));
+    CK(hipMalloc(&c->head_done, (size_t)c->H_loc * CTR_STRIDE * 4));
+    CK(hipMemsetAsync(c->head_done, 0, (size_t)c->H_loc * CTR_STRIDE * 4, c->stream));
+    CK(hipHostMalloc(&c->h_err, sizeof(int), hipHostMallocMapped));
+    *c->h_err = 0;
+    CK(hipHostGetDevicePointer((void**)&c->h_err_dev, c->h_err, 0));
+    c->opt_fuse = env_int("L2_FUSE_ATTN", 0);   // measured: no gain (the last head's attention latency stays exposed), off by default
   }
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
@@ -542,30 +554,82 @@ static int attn_lpr(int hs, bool vec) {
   return l;
 }
 
-static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
+static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4 == 0); }
+
+static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a, int* G_out) {
   const size_t loff = (size_t)l * c->S * c->d_loc;
-  const bool vec = (c->hs % 4 == 0) && (c->d_loc % 4 == 0);
-  const int lpr = attn_lpr(c->hs, vec);
-  if (lpr > 64) return hipErrorInvalidValue;
-  const int G = 256 / lpr;
-  if (c->cur_splits > 1 && !c->opt_exact) {
-    AttnSplitArgs a;
-    a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb; a.tokpos = c->tokpos;
-    a.part = c->attn_part; a.counter = c->attn_counter;
-    a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.nsplit = c->cur_splits; a.lpr = lpr;
+  memset(&a, 0, sizeof(a));
+  a.q = c->q; a.knew = c->k; a.vnew = c->v; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb;
+  a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter; a.head_done = c->head_done; a.err = c->h_err_dev;
+  a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
+  a.exact = c->opt_exact;
+  a.lpr = attn_lpr(c->hs, attn_vec(c));
+  *G_out = 256 / a.lpr;
+}
+
+static size_t attn_lds(const l2_ctx* c, const AttnArgs& a, int G, bool split) {
+  const size_t hs4 = (size_t)((c->hs + 3) & ~3);
+  if (split) {
     const int cmax = (c->S + a.nsplit - 1) / a.nsplit;
-    const size_t lds = (size_t)((cmax + 3) & ~3) * 4 + (size_t)((c->hs + 3) & ~3) * 4 + 128 + (size_t)G * c->hs * 8;
+    return (size_t)((cmax + 3) & ~3) * 4 + 3 * hs4 * 4 + 128 + (size_t)G * c->hs * 8;
+  }
+  return (size_t)((c->S + 3) & ~3) * 4 + 3 * hs4 * 4 + 64 + (size_t)G * c->hs * 8;
+}
+
+static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
+  AttnArgs a;
+  int G;
+  fill_attn_args(c, l, a, &G);
+  if (a.lpr > 64) return hipErrorInvalidValue;
+  const bool vec = attn_vec(c);
+  const bool split = c->cur_splits > 1 && !c->opt_exact;
+  const size_t lds = attn_lds(c, a, G, split);
+  if (split) {
     if (vec) hipLaunchKernelGGL((attn_split_kernel<true>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((attn_split_kernel<false>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
-    return hipGetLastError();
+  } else {
+    if (vec) hipLaunchKernelGGL((attn_kernel<true>), dim3(c->H_loc), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((attn_kernel<false>), dim3(c->H_loc), dim3(256), lds, st, a);
   }
+  return hipGetLastError();
+}
+
+// rmsnorm + QKV + RoPE + KV store + attention of layer l in one launch (qkv_attn_kernel).
+static bool can_fuse_attn(const l2_ctx* c) { return c->opt_fuse && attn_vec(c) && (c->d % 4 == 0); }
+
+static hipError_t launch_qkv_attn(const l2_ctx* c, int l, const PhaseArgs& pa_in, hipStream_t st) {
+  PhaseArgs pa = pa_in;
+  pa.head_done = c->head_done;
   AttnArgs a;
-  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb; a.tokpos = c->tokpos;
-  a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.exact = c->opt_exact;
-  a.lpr = lpr;
-  const size_t lds = (size_t)((c->S + 3) & ~3) * 4 + (size_t)((c->hs + 3) & ~3) * 4 + 64 + (size_t)G * c->hs * 8;
-  if (vec) hipLaunchKernelGGL((attn_kernel<true>), dim3(c->H_loc), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((attn_kernel<false>), dim3(c->H_loc), dim3(256), lds, st, a);
+  int G;
+  fill_attn_args(c, l, a, &G);
+  if (a.lpr > 64) return hipErrorInvalidValue;
+  a.fused = 1;
+  a.expect = (unsigned)(3 * c->hs / 2);                      // row groups per head at R = 2
+  const bool split = c->cur_splits > 1 && !c->opt_exact;
+  const int nattn = c->H_loc * (split ? a.nsplit : 1);
+  // GEMV geometry at 4 waves per workgroup (one block size for the whole launch)
+  const int n4 = pa.n / 4;
+  int U = (n4 <= 64) ? 1 : 2;
+  if (n4 > 128 && n4 <= 256) U = 4;
+  if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4) U = c->tune_U;
+  const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 256;
+  const int pre = (npad4 <= nth) ? 1 : (npad4 <= 2 * nth ? 2 : 4);
+  const int groups = (pa.rows + 1) / 2;
+  int ggrid = (groups + 3) / 4;
+  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : 256 * 6;
+  if (ggrid > cap) ggrid = cap;
+  const int round4 = pre * nth, nstage4 = ((npad4 + round4 - 1) / round4) * round4;
+  size_t lds = (size_t)nstage4 * 2 * 16 + 64;
+  const size_t alds = attn_lds(c, a, G, split);
+  if (alds > lds) lds = alds;
+  const dim3 grid(nattn + ggrid), block(256);
+#define L2_QA(UU, PP) do { if (split) hipLaunchKernelGGL((qkv_attn_kernel<UU, PP, true>), grid, block, lds, st, pa, a); \
+                           else hipLaunchKernelGGL((qkv_attn_kernel<UU, PP, false>), grid, block, lds, st, pa, a); } while (0)
+#define L2_QA_U(UU) do { if (pre == 1) L2_QA(UU, 1); else if (pre == 2) L2_QA(UU, 2); else L2_QA(UU, 4); } while (0)
+  if (U == 1) L2_QA_U(1); else if (U == 2) L2_QA_U(2); else L2_QA_U(4);
+#undef L2_QA_U
+#undef L2_QA
   return hipGetLastError();
 }
 
@@ -597,9 +661,13 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
     a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * l;
     a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff; a.aux = c->k; a.aux2 = c->v;
     a.n = c->d; a.rows = 3 * c->d_loc; a.dim = c->d_loc;
-    LCHK(launch_phase<MODE_QKV>(c, a, st));
-    // 2. attention (llama2.ts:244-267)
-    LCHK(launch_attn(c, l, st));
+    if (can_fuse_attn(c)) {   // 1+2 in one launch: attention waits per head on the q/k/v rows of this position
+      LCHK(launch_qkv_attn(c, l, a, st));
+    } else {
+      LCHK(launch_phase<MODE_QKV>(c, a, st));
+      // 2. attention (llama2.ts:244-267)
+      LCHK(launch_attn(c, l, st));
+    }
     // 3. wo GEMV + residual (llama2.ts:270-273)
     memset(&a, 0, sizeof(a));
     a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
@@ -707,6 +775,7 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
     HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
+  if (*c->h_err) { *c->h_err = 0; return fail(L2_E_HIP, "in-kernel hand-off wait timed out (attention never saw its head's q/k/v rows)"); }
   if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
   return L2_OK;
 }
@@ -745,6 +814,7 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
+  if (*c->h_err) { *c->h_err = 0; return fail(L2_E_HIP, "in-kernel hand-off wait timed out (attention never saw its head's q/k/v rows)"); }
   return L2_OK;
 }
 
