@@ -122,6 +122,17 @@ __device__ __forceinline__ f4 ldg_nt(const float* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
 }
 
+// Sum over aligned groups of `lpr` lanes (power of two); the total is valid in the LAST lane of each group.
+__device__ __forceinline__ double seg_sum(double v, int lpr) {
+  if (lpr >= 2) v += dpp_f64<0xB1, 0xf>(v);
+  if (lpr >= 4) v += dpp_f64<0x4E, 0xf>(v);
+  if (lpr >= 8) v += dpp_f64<0x141, 0xf>(v);
+  if (lpr >= 16) v += dpp_f64<0x140, 0xf>(v);
+  if (lpr >= 32) v += dpp_f64<0x142, 0xa>(v);
+  if (lpr >= 64) v += dpp_f64<0x143, 0xc>(v);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // One dependency phase of a layer = prologue (stage the input vector in LDS, optional rmsnorm) +
 // GEMV over this phase's matrix rows + fused epilogue.
@@ -493,6 +504,7 @@ struct AttnArgs {
   unsigned* counter;     // split form: [H] merge tickets, zero between launches
   unsigned* head_done;   // fused form: [H] finished q/k/v row groups of the head, zero between launches
   int* err;              // set to 1 if a bounded wait gives up
+  unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
   unsigned expect;       // fused form: row groups per head (3 * head_size / R)
   int fused;
   int dim, head_size, seq_len, n_heads, nsplit;
@@ -504,29 +516,36 @@ __device__ __forceinline__ unsigned ld_sc1(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// q.k over one head, i ascending in fp64 -- the reference's own summation order (llama2.ts:252)
+// q.k over one head in fp64.  Four independent chains (one per float4 component): a single accumulator makes
+// the sweep a 128-long dependent v_fma_f64 chain (~64 cycles an element measured), which -- not memory -- was
+// 60 % of the attention kernel.  Order of fp64 additions differs from the reference's (llama2.ts:252) as in
+// every other reduction here; the fp32 score it rounds to does not.
+typedef double d2 __attribute__((ext_vector_type(2)));
+
 template <bool VEC, class KP>
-__device__ __forceinline__ double head_dot(const float* qs, KP kp, int hs) {
-  double sc = 0.0;
+__device__ __forceinline__ double head_dot(const double* qd, KP kp, int hs) {   // q is staged widened to fp64
   if (VEC) {
-    const f4* q4 = reinterpret_cast<const f4*>(qs);
-#pragma unroll 8
+    const d2* q2 = reinterpret_cast<const d2*>(qd);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 16
     for (int i = 0; i < hs / 4; ++i) {
-      const f4 kv = reinterpret_cast<const f4*>(kp)[i], qv = q4[i];
-      sc += (double)qv.x * (double)kv.x;
-      sc += (double)qv.y * (double)kv.y;
-      sc += (double)qv.z * (double)kv.z;
-      sc += (double)qv.w * (double)kv.w;
+      const f4 kv = reinterpret_cast<const f4*>(kp)[i];
+      const d2 qa = q2[2 * i], qb = q2[2 * i + 1];
+      s0 += qa.x * (double)kv.x;
+      s1 += qa.y * (double)kv.y;
+      s2 += qb.x * (double)kv.z;
+      s3 += qb.y * (double)kv.w;
     }
-  } else {
-    for (int i = 0; i < hs; ++i) sc += (double)qs[i] * (double)kp[i];
+    return (s0 + s1) + (s2 + s3);
   }
+  double sc = 0.0;
+  for (int i = 0; i < hs; ++i) sc += qd[i] * (double)kp[i];
   return sc;
 }
 
 // Wait (bounded) until the GEMV waves of this launch have finished every q/k/v row group of head h, then
 // stage q and the new k / v rows in LDS.  Not fused: plain copies, no wait.
-__device__ __forceinline__ void attn_stage(const AttnArgs& a, int h, int tid, float* qs, float* kn, float* vn) {
+__device__ __forceinline__ void attn_stage(const AttnArgs& a, int h, int tid, double* qs, float* kn, float* vn) {
   const int hs = a.head_size;
   if (a.fused) {
     if (tid == 0) {
@@ -538,13 +557,13 @@ __device__ __forceinline__ void attn_stage(const AttnArgs& a, int h, int tid, fl
     }
     __syncthreads();
     for (int i = tid; i < hs; i += 256) {
-      qs[i] = ld_sc1(a.q + (size_t)h * hs + i);
+      qs[i] = (double)ld_sc1(a.q + (size_t)h * hs + i);
       kn[i] = ld_sc1(a.knew + (size_t)h * hs + i);
       vn[i] = ld_sc1(a.vnew + (size_t)h * hs + i);
     }
   } else {
     for (int i = tid; i < hs; i += 256) {
-      qs[i] = a.q[(size_t)h * hs + i];
+      qs[i] = (double)a.q[(size_t)h * hs + i];
       kn[i] = a.knew[(size_t)h * hs + i];
       vn[i] = a.vnew[(size_t)h * hs + i];
     }
@@ -552,14 +571,51 @@ __device__ __forceinline__ void attn_stage(const AttnArgs& a, int h, int tid, fl
   __syncthreads();
 }
 
+// One batch of NB passes of the score / value sweeps: all NB row loads are issued before the first use (addresses
+// clamped, never predicated: a predicated load makes hipcc serialise the batch behind vmcnt(0) waits).
+template <int NB>
+__device__ __forceinline__ void score_batch(const float* kbase, int dim, int tb, int G, int grp, int pos, int lpr, int sub,
+                                            const double (&qv)[4], double rsq, float* att) {
+  f4 kr[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) kr[b] = *reinterpret_cast<const f4*>(kbase + (size_t)min(tb + b * G + grp, pos - 1) * dim);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int t = tb + b * G + grp;
+    double p = qv[0] * (double)kr[b].x;
+    p += qv[1] * (double)kr[b].y;
+    p += qv[2] * (double)kr[b].z;
+    p += qv[3] * (double)kr[b].w;
+    p = seg_sum(p, lpr);
+    if (sub == lpr - 1 && t < pos) att[t] = (float)(p / rsq);
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void value_batch(const float* vbase, int dim, int tb, int G, int grp, int pos, const float* att, double (&o)[4]) {
+  f4 vr[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) vr[b] = *reinterpret_cast<const f4*>(vbase + (size_t)min(tb + b * G + grp, pos - 1) * dim);
+  double e[4] = {0.0, 0.0, 0.0, 0.0};   // second set of chains for the odd passes
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int t = tb + b * G + grp;
+    const double at = (t < pos) ? (double)att[t] : 0.0;
+    if (b & 1) { e[0] += at * (double)vr[b].x; e[1] += at * (double)vr[b].y; e[2] += at * (double)vr[b].z; e[3] += at * (double)vr[b].w; }
+    else { o[0] += at * (double)vr[b].x; o[1] += at * (double)vr[b].y; o[2] += at * (double)vr[b].z; o[3] += at * (double)vr[b].w; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] += e[j];
+}
+
 template <bool VEC>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const int h) {
   const int S = a.seq_len, hs = a.head_size, dim = a.dim, hs4 = (hs + 3) & ~3;
   float* att = reinterpret_cast<float*>(smem);                                   // S floats
-  float* qs = att + ((S + 3) & ~3);                                               // hs floats
-  float* kn = qs + hs4;
+  float* kn = att + ((S + 3) & ~3);                                               // hs floats
   float* vn = kn + hs4;
-  double* red = reinterpret_cast<double*>(vn + hs4);                              // 8 doubles
+  double* qs = reinterpret_cast<double*>(vn + hs4);                               // hs doubles (q widened once)
+  double* red = qs + hs4;                                                         // 8 doubles
   double* pacc = red + 8;                                                         // G * hs doubles
 
   const int tid = threadIdx.x;
@@ -569,15 +625,19 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
   const int e0 = sub * W;                       // first element of this lane inside the head
   const bool live = e0 < hs;
 
+  STAMP(0);
   attn_stage(a, h, tid, qs, kn, vn);
+  STAMP(1);
   if (a.fused && tid == 0) __hip_atomic_store(a.head_done + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-  // ---- scores (llama2.ts:249-254): one thread per timestep
+  // ---- scores (llama2.ts:249-254): one thread per timestep, i ascending in fp64 -- the reference's own
+  // summation order, no cross-lane reduction (a lanes-per-row layout with DPP reductions measured slower)
   const double rsq = sqrt((double)hs);
   for (int t = tid; t < pos; t += 256)
     att[t] = (float)(head_dot<VEC>(qs, a.kc + (size_t)t * dim + (size_t)h * hs, hs) / rsq);
   if (tid == (pos & 255)) att[pos] = (float)(head_dot<VEC>(qs, kn, hs) / rsq);
   __syncthreads();
+  STAMP(2);
 
   // ---- softmax (llama2.ts:181-194)
   float mx = -INFINITY;
@@ -600,6 +660,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
     a.att[(size_t)h * S + t] = pr;
   }
   __syncthreads();
+  STAMP(3);
 
   // ---- weighted sum of values (llama2.ts:257-265)
   const float* vbase = a.vc + (size_t)h * hs + e0;
@@ -628,16 +689,19 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
 #pragma unroll
     for (int j = 0; j < W; ++j) o[j] = 0.0;
     if (live) {
-#pragma unroll 4
-      for (int t = grp; t < pos; t += G) {
-        const double at = att[t];
-        const float* vp = vbase + (size_t)t * dim;
-        if (VEC) {
-          const f4 vv = *reinterpret_cast<const f4*>(vp);
-          o[0] += at * (double)vv.x; o[1] += at * (double)vv.y; o[2] += at * (double)vv.z; o[3] += at * (double)vv.w;
-        } else {
-          o[0] += at * (double)vp[0];
+      if (VEC) {
+        double o4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int tb = 0; tb < pos;) {
+          const int left = (pos - tb + G - 1) / G;
+          if (left > 8) { value_batch<16>(vbase, dim, tb, G, grp, pos, att, o4); tb += 16 * G; }
+          else if (left > 4) { value_batch<8>(vbase, dim, tb, G, grp, pos, att, o4); tb += 8 * G; }
+          else if (left > 2) { value_batch<4>(vbase, dim, tb, G, grp, pos, att, o4); tb += 4 * G; }
+          else { value_batch<2>(vbase, dim, tb, G, grp, pos, att, o4); tb += 2 * G; }
         }
+#pragma unroll
+        for (int j = 0; j < W; ++j) o[j] = o4[j];
+      } else {
+        for (int t = grp; t < pos; t += G) o[0] += (double)att[t] * (double)vbase[(size_t)t * dim];
       }
       if (grp == (pos % G)) {
         const double at = att[pos];
@@ -647,12 +711,14 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
 #pragma unroll
       for (int j = 0; j < W; ++j) pacc[(size_t)grp * hs + e0 + j] = o[j];
     }
+    STAMP(4);
     __syncthreads();
     for (int i = tid; i < hs; i += 256) {
       double sacc = 0.0;
       for (int g2 = 0; g2 < G; ++g2) sacc += pacc[(size_t)g2 * hs + i];
       a.xb[(size_t)h * hs + i] = (float)sacc;
     }
+    STAMP(5);
   }
 }
 
@@ -675,10 +741,10 @@ __device__ __forceinline__ void attn_split_body(const AttnArgs& a, char* smem, c
   const int S = a.seq_len, hs = a.head_size, dim = a.dim, NS = a.nsplit, hs4 = (hs + 3) & ~3;
   const int cmax = (S + NS - 1) / NS;
   float* es = reinterpret_cast<float*>(smem);                                     // cmax floats
-  float* qs = es + ((cmax + 3) & ~3);                                             // hs floats
-  float* kn = qs + hs4;
+  float* kn = es + ((cmax + 3) & ~3);                                             // hs floats
   float* vn = kn + hs4;
-  double* red = reinterpret_cast<double*>(vn + hs4);                              // 16 doubles
+  double* qs = reinterpret_cast<double*>(vn + hs4);                               // hs doubles
+  double* red = qs + hs4;                                                         // 16 doubles
   double* pacc = red + 16;                                                        // G * hs doubles
   unsigned* ticket = reinterpret_cast<unsigned*>(red + 15);   // all LDS in the one dynamic array (16-byte aligned base)
 

@@ -565,15 +565,18 @@ static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a, int* G_out) {
   a.exact = c->opt_exact;
   a.lpr = attn_lpr(c->hs, attn_vec(c));
   *G_out = 256 / a.lpr;
+#ifdef L2_STAMPS
+  a.dbg = c->dbg + 64 * 36;   // attention stamps live behind the phase-kernel slots (last launch wins)
+#endif
 }
 
 static size_t attn_lds(const l2_ctx* c, const AttnArgs& a, int G, bool split) {
   const size_t hs4 = (size_t)((c->hs + 3) & ~3);
   if (split) {
     const int cmax = (c->S + a.nsplit - 1) / a.nsplit;
-    return (size_t)((cmax + 3) & ~3) * 4 + 3 * hs4 * 4 + 128 + (size_t)G * c->hs * 8;
+    return (size_t)((cmax + 3) & ~3) * 4 + 4 * hs4 * 4 + 128 + (size_t)G * c->hs * 8;
   }
-  return (size_t)((c->S + 3) & ~3) * 4 + 3 * hs4 * 4 + 64 + (size_t)G * c->hs * 8;
+  return (size_t)((c->S + 3) & ~3) * 4 + 4 * hs4 * 4 + 64 + (size_t)G * c->hs * 8;
 }
 
 static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
