@@ -66,6 +66,12 @@ struct PhaseArgs {
   double* partial;    // non-null (WO/W2 of a tensor-parallel rank): out[i] is not written, partial[i] = fp64 sum
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
   unsigned* head_done;      // QKV fused with attention: per-head count of finished row groups (else null)
+  // chain launch (one kernel per token, phases ordered by block id): dependency + completion counters
+  const unsigned* wait_flag; // 8 replicas (CTR_STRIDE apart) set when the previous phase has completed; null: no wait
+  unsigned* done_shard;      // 16 shard counters (CTR_STRIDE apart) of THIS phase
+  unsigned* done_top;        // shards completed
+  unsigned* done_flag;       // 8 replicas set by the last arriver
+  int* err;                  // set to 1 when a bounded wait gives up
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -158,13 +164,59 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
 }
 
 
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+// 16-byte L1-bypassing load (buffer_load_dwordx4 ... sc1) of element idx4 of a float4 array of `n4` elements
+__device__ __forceinline__ f4 ld16_sc1(const float* base, int idx4, int n4) {
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n4 * 16, 0x00020000);
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, idx4 * 16, 0, 16));
+}
+
+// Chain launch: wait (bounded) until the previous phase has published its outputs.
+__device__ __forceinline__ void chain_wait(const unsigned* flag, int* err, int tid) {
+  if (flag) {
+    if (tid == 0) {
+      const unsigned* f = flag + (size_t)(blockIdx.x & 7) * CTR_STRIDE;
+      unsigned spins = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 21)) { *err = 1; break; }   // never hang: the host falls back to separate launches
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Chain launch: this workgroup's write-through stores are out; count it.  Shards keep the arrival burst off a
+// single line (an atomic per ~12 ns per line); the last shard to fill raises the 8 flag replicas.
+__device__ __forceinline__ void chain_signal(unsigned* shard, unsigned* top, unsigned* flag, int vblock, int vgrid, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int sidx = vblock & 15;
+    const unsigned in_shard = (unsigned)((vgrid - sidx + 15) / 16);
+    const unsigned old = __hip_atomic_fetch_add(shard + (size_t)sidx * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == in_shard) {
+      const unsigned nsh = (unsigned)min(16, vgrid);
+      const unsigned o2 = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (o2 + 1 == nsh)
+        for (int r = 0; r < 8; ++r) __hip_atomic_store(flag + (size_t)r * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // QKV row groups are ordered head-major: all q, k and v rows of head 0, then head 1, ... so a head's three
 // projections finish together and attention on it can start while later heads are still streaming.
 __device__ __forceinline__ void qkv_group(const PhaseArgs& a, int g, int R, int& m, int& i0) {
-  const int per_mat = a.head_size / R, per_head = 3 * per_mat;
-  const int head = g / per_head, rem = g - head * per_head;
-  m = rem / per_mat;
-  i0 = head * a.head_size + (rem - m * per_mat) * R;
+  if (a.head_done) {   // fused with attention only: head-major (two integer divisions per batch are not free)
+    const int per_mat = a.head_size / R, per_head = 3 * per_mat;
+    const int head = g / per_head, rem = g - head * per_head;
+    m = rem / per_mat;
+    i0 = head * a.head_size + (rem - m * per_mat) * R;
+  } else {             // all q rows, then k, then v
+    const int row0 = g * R;
+    m = (row0 >= a.dim) + (row0 >= 2 * a.dim);   // compares, not a division: this runs once per batch
+    i0 = row0 - m * a.dim;
+  }
 }
 
 template <int MODE, int R>
@@ -191,12 +243,12 @@ __device__ __forceinline__ void row_ptrs(const PhaseArgs& a, int g, int n, const
 }
 
 // Epilogue of one row group; every lane holds every reduced sum, lane p finishes output / pair p.
-template <int MODE, int R>
+template <int MODE, int R, bool CHAIN>
 __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const double (&acc)[R], int lane, int token, int pos) {
   if (MODE == MODE_QKV) {
     int m, i0;
     qkv_group(a, g, R, m, i0);
-    const bool hand = a.head_done != nullptr;   // attention waits inside this launch: publish write-through
+    const bool hand = CHAIN || a.head_done != nullptr;   // consumed inside this launch: publish write-through
 #pragma unroll
     for (int p = 0; p < R / 2; ++p) {
       if (lane == p && i0 + 2 * p < a.dim) {
@@ -224,7 +276,7 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         }
       }
     }
-    if (hand) {   // this wave's stores are out (write-through) before its ticket counts for the head
+    if (a.head_done != nullptr) {   // this wave's stores are out (write-through) before its ticket counts for the head
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(a.head_done + (size_t)(i0 / a.head_size) * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -236,7 +288,8 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         const float h1 = (float)acc[p], h3 = (float)acc[R / 2 + p];       // llama2.ts:280-281
         const double v = h1;
         const float sl = (float)(v * (1.0 / (1.0 + exp(-v))));            // llama2.ts:285 (store #1)
-        a.out[row0 + p] = (float)((double)sl * (double)h3);                // llama2.ts:289 (store #2)
+        const float hv = (float)((double)sl * (double)h3);                  // llama2.ts:289 (store #2)
+        if (CHAIN) st_sc1(a.out + row0 + p, hv); else a.out[row0 + p] = hv;
         if (a.aux) a.aux[row0 + p] = h3;
       }
     }
@@ -246,7 +299,7 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
     for (int r = 0; r < R; ++r) {
       if (lane == r && row0 + r < a.rows) {
         const float lg = (float)acc[r];                                     // llama2.ts:302
-        a.out[row0 + r] = lg;
+        if (CHAIN) st_sc1(a.out + row0 + r, lg); else a.out[row0 + r] = lg;
         if (a.aux2) a.aux2[row0 + r] = lg;   // straight into the host's RunState.logits (pinned, mapped)
       }
     }
@@ -259,9 +312,9 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         if (a.partial) {
           a.partial[i] = acc[r];
         } else {
-          const float xr = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : a.res[i];
+          const float xr = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : (CHAIN ? ld_sc1(a.res + i) : a.res[i]);
           const float mv = (float)acc[r];   // xb2 (WO) / xb (W2) as the reference stores it
-          a.out[i] = xr + mv;
+          if (CHAIN) st_sc1(a.out + i, xr + mv); else a.out[i] = xr + mv;
           if (a.aux) a.aux[i] = mv;
         }
       }
@@ -274,7 +327,7 @@ __device__ __forceinline__ constexpr bool mode_has_norm() { return MODE == MODE_
 
 // Vector path: n % 4 == 0 (every real checkpoint).  LDS: xs[npad4] float4 (zero padded to whole batches),
 // ws[n4] float4 (norm weight, norm modes only), 8 doubles of reduction scratch.
-template <int MODE, int R, int U, int PRE>
+template <int MODE, int R, int U, int PRE, bool CHAIN>
 __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const int vblock, const int vgrid) {
   constexpr int CPI = 64 * U;                       // float4 per row per batch
   const int n = a.n, n4 = n >> 2;
@@ -290,9 +343,6 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
   const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
   const int wstride = vgrid * nwaves;
-  int g = vblock * nwaves + wave;
-  int ch = 0;
-  bool have = g < groups;
 
   STAMP(0);
   f4 bufA[R][U], bufB[R][U];
@@ -323,13 +373,24 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
       }
     }
   };
+  // the flattened (row group, column batch) sequence of this wave: batch k -> (gk, ck); prefetches past the
+  // end are clamped to the last valid batch (unconditional loads keep hipcc's waits counted, never vmcnt(0))
+  auto next = [&](int& gi, int& ci, bool& hv) {
+    if (++ci == nchunks) { ci = 0; gi += wstride; }
+    hv = gi < groups;
+  };
+  int g0 = vblock * nwaves + wave, c0 = 0;
+  bool h0 = g0 < groups;
+  int g1 = g0, c1 = c0;
+  bool h1 = h0;
+  if (h0) next(g1, c1, h1);
 
   // ---- prologue: input vector -> LDS (rmsnorm fused, llama2.ts:172-179).
-  // Vector-memory results return in issue order, so the activations are requested FIRST and the first
-  // batch of weights right behind them: waiting for x then costs one L2 round trip while the weight
-  // batch (which depends on nothing) is already in flight.
-  // {token,pos}: requested first, needed late (pos: RoPE / cache row in the epilogue) -- except in layer 0,
-  // where the input IS the embedding row of `token` (llama2.ts:211) and the address waits for it
+  // Vector-memory results return in issue order.  Separate launches: the activations are requested FIRST and
+  // two weight batches right behind them, so waiting for x costs one L2 round trip while the weight stream
+  // (which depends on nothing) is already in flight.  Chain launch: the two weight batches go out before the
+  // wait on the previous phase -- the HBM pipe stays busy across the dependency -- and x is read (L1-bypassing)
+  // once the flag is up.
   int token = 0, pos = 0;
   if (MODE == MODE_QKV || MODE == MODE_WO) { token = a.tokpos[0]; pos = a.tokpos[1]; }
   const float* src = a.in;
@@ -342,7 +403,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const int cc = min(base + tid + k * nthreads, n4 - 1);
-      xr[k] = src4[cc];
+      xr[k] = CHAIN ? ld16_sc1(src, cc, n4) : src4[cc];
       if (mode_has_norm<MODE>()) wr[k] = rw4[cc];
     }
   };
@@ -361,11 +422,17 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
       }
     }
   };
-  {
+  if (CHAIN) {
+    issue(bufA, h0 ? g0 : groups - 1, h0 ? c0 : 0);
+    issue(bufB, h1 ? g1 : (h0 ? g0 : groups - 1), h1 ? c1 : (h0 ? c0 : 0));
+    chain_wait(a.wait_flag, a.err, tid);
     f4 xr[PRE], wr[PRE];
     stage_load(xr, wr, 0);
-    issue(bufA, have ? g : groups - 1, 0);   // queued right behind the activations; unconditional so the
-                                             // compiler's wait for x stays a counted vmcnt(R*U)
+    stage_store(xr, wr, 0);
+  } else {
+    f4 xr[PRE], wr[PRE];
+    stage_load(xr, wr, 0);
+    issue(bufA, h0 ? g0 : groups - 1, h0 ? c0 : 0);
     STAMP(1);
     stage_store(xr, wr, 0);
     STAMP(2);
@@ -394,44 +461,65 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   __syncthreads();
   STAMP(4);
 
-  // ---- GEMV, double buffered over the flattened (row group, column batch) sequence of this wave
-  while (have) {
-    int g2 = g, ch2 = ch + 1;
-    if (ch2 == nchunks) { ch2 = 0; g2 = g + wstride; }
-    const bool have2 = g2 < groups;
-    issue(bufB, have2 ? g2 : g, have2 ? ch2 : ch);   // unconditional: keeps the wait counts uniform
-    consume(bufA, ch);
-    STAMP(5);
-    if (ch == nchunks - 1) {
+  auto finish = [&](int gi) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-      STAMP(6);
-      finish_group<MODE, R>(a, g, acc, lane, token, pos);
-      STAMP(7);
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    STAMP(6);
+    finish_group<MODE, R, CHAIN>(a, gi, acc, lane, token, pos);
+    STAMP(7);
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+  };
+  if (!CHAIN) {
+    // ---- GEMV, double buffered: batch k+1 is issued, then batch k consumed (A holds batch 0 on entry).
+    // (Pre-issuing two batches costs ~20 VGPRs and one wave per SIMD of occupancy: measured slower.)
+    int g = g0, ch = c0;
+    bool have = h0;
+    while (have) {
+      int g2 = g, ch2 = ch;
+      bool have2 = true;
+      next(g2, ch2, have2);
+      issue(bufB, have2 ? g2 : g, have2 ? ch2 : ch);   // unconditional: keeps the wait counts uniform
+      consume(bufA, ch);
+      STAMP(5);
+      if (ch == nchunks - 1) finish(g);
+      if (!have2) break;
+      int g3 = g2, ch3 = ch2;
+      bool have3 = true;
+      next(g3, ch3, have3);
+      issue(bufA, have3 ? g3 : g2, have3 ? ch3 : ch2);
+      consume(bufB, ch2);
+      if (ch2 == nchunks - 1) finish(g2);
+      g = g3; ch = ch3; have = have3;
     }
-    if (!have2) break;
-    int g3 = g2, ch3 = ch2 + 1;
-    if (ch3 == nchunks) { ch3 = 0; g3 = g2 + wstride; }
-    const bool have3 = g3 < groups;
-    issue(bufA, have3 ? g3 : g2, have3 ? ch3 : ch2);
-    consume(bufB, ch2);
-    if (ch2 == nchunks - 1) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-      finish_group<MODE, R>(a, g2, acc, lane, token, pos);
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = 0.0;
+  } else {
+    // ---- chain launch: A = batch k, B = batch k+1 are in flight on entry (issued before the dependency wait)
+    while (h0) {
+      int g2 = g1, c2 = c1;
+      bool h2 = h1;
+      if (h1) next(g2, c2, h2);
+      consume(bufA, c0);
+      if (c0 == nchunks - 1) finish(g0);
+      if (!h1) break;
+      issue(bufA, h2 ? g2 : g1, h2 ? c2 : c1);           // refill A with batch k+2
+      int g3 = g2, c3 = c2;
+      bool h3 = h2;
+      if (h2) next(g3, c3, h3);
+      consume(bufB, c1);
+      if (c1 == nchunks - 1) finish(g1);
+      if (!h2) break;
+      issue(bufB, h3 ? g3 : g2, h3 ? c3 : c2);           // refill B with batch k+3
+      g0 = g2; c0 = c2; h0 = true;
+      g1 = g3; c1 = c3; h1 = h3;
     }
-    g = g3; ch = ch3; have = have3;
   }
+  if (CHAIN) chain_signal(a.done_shard, a.done_top, a.done_flag, vblock, vgrid, tid);
 }
 
 template <int MODE, int R, int U, int PRE>
 __global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  phase_body<MODE, R, U, PRE>(a, smem, blockIdx.x, gridDim.x);
+  phase_body<MODE, R, U, PRE, false>(a, smem, blockIdx.x, gridDim.x);
 }
 
 // Scalar path for shapes with n % 4 != 0 (rows are not 16-byte aligned): correctness only.
@@ -477,7 +565,7 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-    finish_group<MODE, R>(a, g, acc, lane, token, pos);
+    finish_group<MODE, R, false>(a, g, acc, lane, token, pos);
   }
 }
 
@@ -871,7 +959,7 @@ __global__ void __launch_bounds__(256) qkv_attn_kernel(const PhaseArgs pa, const
     if (SPLIT) attn_split_body<true>(aa, smem, blockIdx.x % aa.n_heads, blockIdx.x / aa.n_heads);
     else attn_body<true>(aa, smem, blockIdx.x);
   } else {
-    phase_body<MODE_QKV, 2, U, PRE>(pa, smem, blockIdx.x - nattn, gridDim.x - nattn);
+    phase_body<MODE_QKV, 2, U, PRE, false>(pa, smem, blockIdx.x - nattn, gridDim.x - nattn);
   }
 }
 
