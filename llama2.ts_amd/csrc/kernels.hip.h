@@ -67,10 +67,9 @@ struct PhaseArgs {
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
   unsigned* head_done;      // QKV fused with attention: per-head count of finished row groups (else null)
   // chain launch (one kernel per token, phases ordered by block id): dependency + completion counters
-  const unsigned* wait_flag; // 8 replicas (CTR_STRIDE apart) set when the previous phase has completed; null: no wait
-  unsigned* done_shard;      // 16 shard counters (CTR_STRIDE apart) of THIS phase
-  unsigned* done_top;        // shards completed
-  unsigned* done_flag;       // 8 replicas set by the last arriver
+  const unsigned* wait_shard; // the previous phase's 16 shard counters (CTR_STRIDE apart); null: no wait
+  int wait_blocks;            // workgroups of the previous phase
+  unsigned* done_shard;       // 16 shard counters of THIS phase
   int* err;                  // set to 1 when a bounded wait gives up
 };
 
@@ -171,37 +170,32 @@ __device__ __forceinline__ f4 ld16_sc1(const float* base, int idx4, int n4) {
   return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, idx4 * 16, 0, 16));
 }
 
-// Chain launch: wait (bounded) until the previous phase has published its outputs.
-__device__ __forceinline__ void chain_wait(const unsigned* flag, int* err, int tid) {
-  if (flag) {
-    if (tid == 0) {
-      const unsigned* f = flag + (size_t)(blockIdx.x & 7) * CTR_STRIDE;
+// Chain launch hand-off.  A finished workgroup adds 1 (fire-and-forget, no returned value: nothing waits on
+// the atomic's round trip) to one of 16 shard counters on separate lines, after its write-through stores have
+// drained.  A waiting workgroup polls all 16 shards with one wave instruction (lane s reads shard s) until
+// every shard holds its share of the previous phase's workgroups.  Bounded: gives up after ~0.5 s and sets err.
+__device__ __forceinline__ void chain_wait(const unsigned* shards, int prev_blocks, int* err, int tid) {
+  if (shards) {
+    if (tid < 64) {
+      const int s16 = tid & 15;
+      const unsigned want = (unsigned)((prev_blocks - s16 + 15) / 16);   // workgroups of the previous phase in shard s16
+      const unsigned* f = shards + (size_t)s16 * CTR_STRIDE;
       unsigned spins = 0;
-      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 21)) { *err = 1; break; }   // never hang: the host falls back to separate launches
+      for (;;) {
+        const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= want)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) { if (tid == 0) *err = 1; break; }   // never hang: the host falls back to separate launches
       }
     }
     __syncthreads();
   }
 }
 
-// Chain launch: this workgroup's write-through stores are out; count it.  Shards keep the arrival burst off a
-// single line (an atomic per ~12 ns per line); the last shard to fill raises the 8 flag replicas.
-__device__ __forceinline__ void chain_signal(unsigned* shard, unsigned* top, unsigned* flag, int vblock, int vgrid, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+__device__ __forceinline__ void chain_signal(unsigned* shard, int vblock, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have reached memory
   __syncthreads();
-  if (tid == 0) {
-    const int sidx = vblock & 15;
-    const unsigned in_shard = (unsigned)((vgrid - sidx + 15) / 16);
-    const unsigned old = __hip_atomic_fetch_add(shard + (size_t)sidx * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == in_shard) {
-      const unsigned nsh = (unsigned)min(16, vgrid);
-      const unsigned o2 = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (o2 + 1 == nsh)
-        for (int r = 0; r < 8; ++r) __hip_atomic_store(flag + (size_t)r * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  if (tid == 0) __hip_atomic_fetch_add(shard + (size_t)(vblock & 15) * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // QKV row groups are ordered head-major: all q, k and v rows of head 0, then head 1, ... so a head's three
@@ -425,7 +419,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   if (CHAIN) {
     issue(bufA, h0 ? g0 : groups - 1, h0 ? c0 : 0);
     issue(bufB, h1 ? g1 : (h0 ? g0 : groups - 1), h1 ? c1 : (h0 ? c0 : 0));
-    chain_wait(a.wait_flag, a.err, tid);
+    chain_wait(a.wait_shard, a.wait_blocks, a.err, tid);
     f4 xr[PRE], wr[PRE];
     stage_load(xr, wr, 0);
     stage_store(xr, wr, 0);
@@ -513,7 +507,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
       g1 = g3; c1 = c3; h1 = h3;
     }
   }
-  if (CHAIN) chain_signal(a.done_shard, a.done_top, a.done_flag, vblock, vgrid, tid);
+  if (CHAIN) chain_signal(a.done_shard, vblock, tid);
 }
 
 template <int MODE, int R, int U, int PRE>
@@ -592,6 +586,8 @@ struct AttnArgs {
   unsigned* counter;     // split form: [H] merge tickets, zero between launches
   unsigned* head_done;   // fused form: [H] finished q/k/v row groups of the head, zero between launches
   int* err;              // set to 1 if a bounded wait gives up
+  const unsigned* wait_shard;  // chain launch (fused == 2): shard counters of the QKV phase of this layer
+  int wait_blocks;
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
   unsigned expect;       // fused form: row groups per head (3 * head_size / R)
   int fused;
@@ -635,7 +631,14 @@ __device__ __forceinline__ double head_dot(const double* qd, KP kp, int hs) {   
 // stage q and the new k / v rows in LDS.  Not fused: plain copies, no wait.
 __device__ __forceinline__ void attn_stage(const AttnArgs& a, int h, int tid, double* qs, float* kn, float* vn) {
   const int hs = a.head_size;
-  if (a.fused) {
+  if (a.fused == 2) {
+    chain_wait(a.wait_shard, a.wait_blocks, a.err, tid);
+    for (int i = tid; i < hs; i += 256) {
+      qs[i] = (double)ld_sc1(a.q + (size_t)h * hs + i);
+      kn[i] = ld_sc1(a.knew + (size_t)h * hs + i);
+      vn[i] = ld_sc1(a.vnew + (size_t)h * hs + i);
+    }
+  } else if (a.fused) {
     if (tid == 0) {
       unsigned spins = 0;
       while (ld_sc1(a.head_done + (size_t)h * CTR_STRIDE) < a.expect) {
@@ -716,7 +719,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
   STAMP(0);
   attn_stage(a, h, tid, qs, kn, vn);
   STAMP(1);
-  if (a.fused && tid == 0) __hip_atomic_store(a.head_done + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.fused == 1 && tid == 0) __hip_atomic_store(a.head_done + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // ---- scores (llama2.ts:249-254): one thread per timestep, i ascending in fp64 -- the reference's own
   // summation order, no cross-lane reduction (a lanes-per-row layout with DPP reductions measured slower)
@@ -770,7 +773,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
         for (int j = 0; j < W; ++j) o[j] = (float)((double)o[j] + at * (double)vn[e0 + j]);
       }
 #pragma unroll
-      for (int j = 0; j < W; ++j) a.xb[(size_t)h * hs + e0 + j] = o[j];
+      for (int j = 0; j < W; ++j) { if (a.fused == 2) st_sc1(a.xb + (size_t)h * hs + e0 + j, o[j]); else a.xb[(size_t)h * hs + e0 + j] = o[j]; }
     }
   } else {
     double o[W];
@@ -804,7 +807,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
     for (int i = tid; i < hs; i += 256) {
       double sacc = 0.0;
       for (int g2 = 0; g2 < G; ++g2) sacc += pacc[(size_t)g2 * hs + i];
-      a.xb[(size_t)h * hs + i] = (float)sacc;
+      if (a.fused == 2) st_sc1(a.xb + (size_t)h * hs + i, (float)sacc); else a.xb[(size_t)h * hs + i] = (float)sacc;
     }
     STAMP(5);
   }
@@ -927,7 +930,7 @@ __device__ __forceinline__ void attn_split_body(const AttnArgs& a, char* smem, c
   for (int i = tid; i < hs; i += 256) {
     double num = 0.0;
     for (int s2 = 0; s2 < NS; ++s2) num += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + i);
-    a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
+    if (a.fused == 2) st_sc1(a.xb + (size_t)h * hs + i, (float)(num / Lsum)); else a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
   }
   for (int t = tid; t < T; t += 256) {          // probabilities for parity reads of RunState.att
     const double ws = exp(ld_sc1(hp + (size_t)(t / chunk) * rec + hs + 1) - M);
@@ -935,7 +938,7 @@ __device__ __forceinline__ void attn_split_body(const AttnArgs& a, char* smem, c
   }
   if (tid == 0) {   // every split of this head has passed its wait and taken its ticket: re-arm both counters
     __hip_atomic_store(a.counter + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.fused) __hip_atomic_store(a.head_done + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.fused == 1) __hip_atomic_store(a.head_done + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -998,6 +1001,104 @@ __global__ void __launch_bounds__(1024) argmax_advance_kernel(const float* logit
     tokens_out[step] = bi;
     tokpos[0] = bi; tokpos[1] = tokpos[1] + 1; tokpos[2] = step + 1;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chain launch: ONE kernel per token.  Workgroups are grouped into phases by block id -- per layer
+// [QKV | attention | WO | W13 | W2], then the classifier (and the greedy argmax) -- and a workgroup of phase q
+// only ever waits on phase q-1, i.e. on LOWER block ids.  The dispatcher hands workgroups out in block-id
+// order, so everything a waiting workgroup depends on is already running or done: no grid barrier, no
+// co-residency requirement, and a phase's workgroups start (and stream their first two weight batches) in the
+// slots the previous phase's tail frees -- the HBM pipe never drains at a phase boundary.  Every hand-off is
+// write-through stores + completion counters + L1-bypassing loads (see chain_signal / chain_wait); waits are
+// bounded and set `err` instead of hanging, the host then falls back to one launch per phase.
+struct ChainPhase {
+  PhaseArgs pa;      // GEMV phases
+  AttnArgs aa;       // attention phases
+  int mode;          // MODE_* or CHAIN_ATTN / CHAIN_ARGMAX
+  int U;             // 2 or 4
+  int split;         // attention: 1 = split form
+  int nblocks;
+};
+enum { CHAIN_ATTN = 5, CHAIN_ARGMAX = 6 };
+
+struct ChainLaunch {
+  const ChainPhase* phases;   // [5*L + 1 (+1)]
+  int L;                      // layers
+  int off[6];                 // first block of each role inside a layer, off[5] = blocks per layer
+  int cls_first, cls_blocks;  // classifier phase
+  int has_argmax;
+  // argmax role
+  const float* logits; int V; int* tokpos; int* tokens_out;
+  unsigned long long* tl;     // diagnostic timeline (L2_STAMPS builds): {start, after-wait, end} per workgroup, 100 MHz ticks
+};
+
+template <int MODE>
+__device__ __forceinline__ void chain_gemv(const ChainPhase& ph, char* smem, int vb) {
+  if (ph.U == 4) phase_body<MODE, 2, 4, 4, true>(ph.pa, smem, vb, ph.nblocks);
+  else phase_body<MODE, 2, 2, 4, true>(ph.pa, smem, vb, ph.nblocks);
+}
+
+__global__ void __launch_bounds__(256) chain_kernel(const ChainLaunch cl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  int pidx, vb;
+  const int per_layer = cl.off[5];
+  if (bid < cl.L * per_layer) {
+    const int layer = bid / per_layer, rem = bid - layer * per_layer;
+    const int role = (rem >= cl.off[1]) + (rem >= cl.off[2]) + (rem >= cl.off[3]) + (rem >= cl.off[4]);
+    pidx = layer * 5 + role;
+    vb = rem - cl.off[role];
+  } else if (bid < cl.cls_first + cl.cls_blocks) {
+    pidx = cl.L * 5;
+    vb = bid - cl.cls_first;
+  } else {
+    pidx = cl.L * 5 + 1;
+    vb = 0;
+  }
+  const ChainPhase& ph = cl.phases[pidx];
+#ifdef L2_STAMPS
+  if (cl.tl && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); cl.tl[(size_t)bid * 2] = t_; }
+#endif
+  switch (ph.mode) {
+    case MODE_QKV: chain_gemv<MODE_QKV>(ph, smem, vb); break;
+    case MODE_WO: chain_gemv<MODE_WO>(ph, smem, vb); break;
+    case MODE_W13: chain_gemv<MODE_W13>(ph, smem, vb); break;
+    case MODE_W2: chain_gemv<MODE_W2>(ph, smem, vb); break;
+    case MODE_CLS: chain_gemv<MODE_CLS>(ph, smem, vb); break;
+    case CHAIN_ATTN: {
+      const AttnArgs& aa = ph.aa;
+      if (ph.split) attn_split_body<true>(aa, smem, vb % aa.n_heads, vb / aa.n_heads);
+      else attn_body<true>(aa, smem, vb);
+      chain_signal(ph.pa.done_shard, vb, tid);
+      break;
+    }
+    default: {   // greedy argmax (llama2.ts:364-366) + advance {token,pos,step}; logits arrive write-through
+      chain_wait(ph.pa.wait_shard, ph.pa.wait_blocks, ph.pa.err, tid);
+      float* sv = reinterpret_cast<float*>(smem);
+      int* si = reinterpret_cast<int*>(smem) + 16;
+      float bv = -INFINITY; int bi = 0x7fffffff;
+      for (int i = tid; i < cl.V; i += 256) { const float v = ld_sc1(cl.logits + i); if (v > bv) { bv = v; bi = i; } }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64); const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
+      __syncthreads();
+      if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        if (bi == 0x7fffffff) bi = 0;
+        const int step = cl.tokpos[2];
+        cl.tokens_out[step] = bi;
+        cl.tokpos[0] = bi; cl.tokpos[1] = cl.tokpos[1] + 1; cl.tokpos[2] = step + 1;
+      }
+      break;
+    }
+  }
+#ifdef L2_STAMPS
+  if (cl.tl && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); cl.tl[(size_t)bid * 2 + 1] = t_; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

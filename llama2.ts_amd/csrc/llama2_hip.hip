@@ -115,6 +115,15 @@ struct l2_ctx {
   int* h_err = nullptr;             // pinned + mapped: set by a kernel whose bounded wait gave up
   int* h_err_dev = nullptr;
   int opt_fuse = 0;                 // L2_FUSE_ATTN: attention inside the QKV launch (experimental)
+  // chain launch: one kernel per token (kernels.hip.h chain_kernel)
+  int opt_chain = 0;
+  int chain_cap = 768;              // workgroups per GEMV phase
+  unsigned* chain_ctr = nullptr;    // per phase: 16 shard lines, 1 top line, 8 flag lines
+  size_t chain_ctr_bytes = 0;
+  float* chain_act = nullptr;       // per-layer activations: no buffer is rewritten inside one launch (see build_chain)
+  size_t chain_act_stride = 0;      // floats per layer
+  double* chain_part = nullptr;     // per-layer split-attention partials
+  struct ChainSet { ChainPhase* d_phases = nullptr; ChainLaunch cl; size_t lds = 0; int blocks = 0; bool built = false; } chain[3][2];
   int* tokpos = nullptr;    // device {token,pos,step,0}
   int* h_tokpos = nullptr;  // pinned
   int* d_tokens = nullptr;  // device, S ints
@@ -197,6 +206,10 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->attn_part) hipFree(c->attn_part);
   if (c->attn_counter) hipFree(c->attn_counter);
   if (c->head_done) hipFree(c->head_done);
+  if (c->chain_ctr) hipFree(c->chain_ctr);
+  if (c->chain_act) hipFree(c->chain_act);
+  if (c->chain_part) hipFree(c->chain_part);
+  for (auto& lv : c->chain) for (auto& cs : lv) if (cs.d_phases) hipFree(cs.d_phases);
   if (c->h_err) hipHostFree(c->h_err);
   if (c->tokpos) hipFree(c->tokpos);
   if (c->d_tokens) hipFree(c->d_tokens);
@@ -295,6 +308,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     CK(hipHostMalloc(&c->h_err, sizeof(int), hipHostMallocMapped));
     *c->h_err = 0;
     CK(hipHostGetDevicePointer((void**)&c->h_err_dev, c->h_err, 0));
+    c->opt_chain = env_int("L2_CHAIN", 0);
+    c->chain_cap = env_int("L2_CHAIN_CAP", 768);
     c->opt_fuse = env_int("L2_FUSE_ATTN", 0);   // measured: no gain (the last head's attention latency stays exposed), off by default
   }
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
@@ -648,58 +663,237 @@ __global__ void tp_residual_kernel(float* x, const float* res_emb, const double*
 #define LCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(L2_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 // Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
-static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
-  const float* emb = c->w[L2_T_TOKEN_EMBEDDING];
+// PhaseArgs of each phase of layer l (shared by the per-phase launches and the chain launch)
+static PhaseArgs base_args(const l2_ctx* c) {
+  PhaseArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tokpos = c->tokpos; a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG];
+  a.head_size = c->hs; a.dim = c->d; a.err = c->h_err_dev;
+  return a;
+}
+static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs + RoPE + KV-cache store (llama2.ts:216-240)
+  PhaseArgs a = base_args(c);
+  const size_t loff = (size_t)l * c->S * c->d_loc;
+  a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l;
+  a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
+  a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
+  a.in = c->x; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr;
+  a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * l;
+  a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff; a.aux = c->k; a.aux2 = c->v;
+  a.n = c->d; a.rows = 3 * c->d_loc; a.dim = c->d_loc;
+  return a;
+}
+static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (llama2.ts:270-273)
+  PhaseArgs a = base_args(c);
+  a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l;
+  a.in = c->xb; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; a.res = c->x; a.out = c->x; a.aux = c->xb2;
+  a.n = c->d_loc; a.rows = c->d;
+  if (c->tp_path) a.partial = c->partial;
+  return a;
+}
+static PhaseArgs w13_args(const l2_ctx* c, int l) {   // rmsnorm + w1,w3 GEMVs + SwiGLU (llama2.ts:276-289)
+  PhaseArgs a = base_args(c);
+  a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l;
+  a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
+  a.in = c->x; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * l;
+  a.out = c->hb; a.aux = c->hb2;
+  a.n = c->d; a.rows = c->h_loc;
+  return a;
+}
+static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (llama2.ts:292-295)
+  PhaseArgs a = base_args(c);
+  a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l;
+  a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = c->tp_path ? nullptr : c->xb;
+  a.n = c->h_loc; a.rows = c->d;
+  if (c->tp_path) a.partial = c->partial;
+  return a;
+}
+static PhaseArgs cls_args(const l2_ctx* c, bool to_host) {   // final rmsnorm + classifier (llama2.ts:299-302)
+  PhaseArgs a = base_args(c);
+  a.w0 = c->w[L2_T_WCLS];
+  a.in = c->x; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xn;
+  a.aux2 = (to_host && c->opt_zero_copy && !c->tp_path) ? c->h_logits_dev : nullptr;
+  a.n = c->d; a.rows = c->V_loc;
+  return a;
+}
+
+// ---- chain launch -----------------------------------------------------------------------------
+#ifdef L2_STAMPS
+static unsigned long long* g_chain_tl = nullptr; static int g_chain_blocks = 0; static ChainLaunch g_chain_off;
+extern "C" int l2_debug_chain_timeline(unsigned long long* out, int* nblocks, int* off6, int* L, int* cls) {
+  hipDeviceSynchronize();
+  if (out) hipMemcpy(out, g_chain_tl, (size_t)g_chain_blocks * 16, hipMemcpyDeviceToHost);
+  *nblocks = g_chain_blocks; for (int i = 0; i < 6; ++i) off6[i] = g_chain_off.off[i]; *L = g_chain_off.L; cls[0] = g_chain_off.cls_first; cls[1] = g_chain_off.cls_blocks;
+  return 0;
+}
+#endif
+static bool can_chain(const l2_ctx* c) {
+  return c->opt_chain && !c->tp_path && (c->d % 4 == 0) && (c->h % 4 == 0) && attn_vec(c);
+}
+
+static unsigned* chain_line(const l2_ctx* c, int phase, int line) { return c->chain_ctr + ((size_t)phase * 16 + line) * CTR_STRIDE; }
+
+static void chain_wire(const l2_ctx* c, PhaseArgs& a, int q, int prev_blocks) {   // counters of phase q, wait on phase q-1
+  a.done_shard = chain_line(c, q, 0);
+  const bool wait = q > 0 && !env_int("L2_CHAIN_NOWAIT", 0);   // NOWAIT: timing experiment only (wrong results)
+  a.wait_shard = wait ? chain_line(c, q - 1, 0) : nullptr;
+  a.wait_blocks = prev_blocks;
+  a.err = c->h_err_dev;
+}
+
+static int chain_blocks(const l2_ctx* c, int mode, int rows) {
+  const int groups = (rows * (mode == MODE_W13 ? 2 : 1) + 1) / 2;
+  int b = (groups + 3) / 4;
+  if (b > c->chain_cap) b = c->chain_cap;
+  return b < 1 ? 1 : b;
+}
+
+static size_t chain_phase_lds(int mode, int n, int U) {
+  const int n4 = n / 4, cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi;
+  const int round4 = 4 * 256, nstage4 = ((npad4 + round4 - 1) / round4) * round4;
+  const bool norm = (mode == MODE_QKV || mode == MODE_W13 || mode == MODE_CLS);
+  return (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
+}
+
+static int chain_U(int n) { const int n4 = n / 4; return (n4 > 128 && n4 <= 256) ? 4 : 2; }
+
+static int build_chain(l2_ctx* c, int level, int greedy) {
+  l2_ctx::ChainSet& cs = c->chain[level][greedy];
+  if (cs.built) return L2_OK;
+  const int nph = 5 * c->L + 1 + (greedy ? 1 : 0);
+  if (!c->chain_ctr) {
+    c->chain_ctr_bytes = (size_t)(5 * c->L + 2) * 16 * CTR_STRIDE * 4;
+    // uncached (fine-grained) memory: a polled flag must never be served from a stale line of the poller's L2
+    HIPCHK(hipExtMallocWithFlags((void**)&c->chain_ctr, c->chain_ctr_bytes, hipDeviceMallocUncached));
+    HIPCHK(hipMemset(c->chain_ctr, 0, c->chain_ctr_bytes));
+  }
+  // Per-XCD L2s are not coherent: a buffer that one XCD rewrites inside a launch can be served stale from
+  // another XCD's L2 even to an L1-bypassing load (observed: xb of layer 1 read as layer 0's).  So inside one
+  // chain launch every activation buffer is written exactly once: each layer has its own q/k/v/xb/x/hb/att
+  // (kernel boundaries between tokens make the reuse across launches safe, as for the per-phase launches).
+  const size_t dl = c->d_loc, rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;
+  const size_t o_q = 0, o_k = dl, o_v = 2 * dl, o_xb = 3 * dl, o_xm = 4 * dl, o_hb = o_xm + c->d, o_xo = o_hb + c->h_loc,
+               o_att = o_xo + c->d, stride = (o_att + (size_t)c->H_loc * c->S + 63) & ~(size_t)63;
+  if (!c->chain_act) {
+    c->chain_act_stride = stride;
+    HIPCHK(hipMalloc(&c->chain_act, stride * c->L * sizeof(float)));
+    HIPCHK(hipMemset(c->chain_act, 0, stride * c->L * sizeof(float)));
+    HIPCHK(hipMalloc(&c->chain_part, (size_t)c->L * c->H_loc * 8 * rec * sizeof(double)));
+  }
+  auto act = [&](int l, size_t off) { return c->chain_act + (size_t)l * stride + off; };
+  std::vector<ChainPhase> ph(nph);
+  memset(ph.data(), 0, sizeof(ChainPhase) * nph);
+  const int splits = splits_of(c, level);
+  const bool split = splits > 1 && !c->opt_exact;
+  size_t lds = 0;
+  int off[6] = {0, 0, 0, 0, 0, 0};
+  int prev_blocks = 0;
   for (int l = 0; l < c->L; ++l) {
-    const size_t loff = (size_t)l * c->S * c->d_loc;
-    PhaseArgs a;
-    memset(&a, 0, sizeof(a));
-    a.tokpos = c->tokpos; a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG];
-    a.head_size = c->hs;
-    // 1. rmsnorm + q,k,v GEMVs + RoPE + KV-cache store (llama2.ts:216-240)
-    a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l;
-    a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
-    a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
-    a.in = c->x; a.emb = (l == 0) ? emb : nullptr;
-    a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * l;
-    a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff; a.aux = c->k; a.aux2 = c->v;
-    a.n = c->d; a.rows = 3 * c->d_loc; a.dim = c->d_loc;
+    PhaseArgs pa[5] = {qkv_args(c, l), base_args(c), wo_args(c, l), w13_args(c, l), w2_args(c, l)};
+    const int modes[5] = {MODE_QKV, CHAIN_ATTN, MODE_WO, MODE_W13, MODE_W2};
+    int run = 0;
+    for (int r = 0; r < 5; ++r) {
+      ChainPhase& p = ph[l * 5 + r];
+      p.mode = modes[r];
+      p.pa = pa[r];
+      // per-layer buffers: x_in(l) = x_out(l-1) (the embedding row in layer 0)
+      const float* x_in = l > 0 ? act(l - 1, o_xo) : nullptr;
+      if (r == 0) { p.pa.in = x_in; p.pa.out = act(l, o_q); p.pa.aux = act(l, o_k); p.pa.aux2 = act(l, o_v); }
+      if (r == 2) { p.pa.in = act(l, o_xb); p.pa.res = x_in; p.pa.out = act(l, o_xm); }
+      if (r == 3) { p.pa.in = act(l, o_xm); p.pa.out = act(l, o_hb); }
+      if (r == 4) { p.pa.in = act(l, o_hb); p.pa.res = act(l, o_xm); p.pa.out = act(l, o_xo); }
+      if (r == 1) {
+        int G;
+        c->cur_splits = splits;
+        fill_attn_args(c, l, p.aa, &G);
+        p.split = split ? 1 : 0;
+        p.nblocks = c->H_loc * (split ? splits : 1);
+        const size_t al = attn_lds(c, p.aa, G, split);
+        if (al > lds) lds = al;
+      } else {
+        p.U = chain_U(p.pa.n);
+        p.nblocks = chain_blocks(c, p.mode, p.pa.rows);
+        const size_t pl = chain_phase_lds(p.mode, p.pa.n, p.U);
+        if (pl > lds) lds = pl;
+      }
+      chain_wire(c, p.pa, l * 5 + r, prev_blocks);
+      prev_blocks = p.nblocks;
+      if (r == 1) {
+        p.aa.fused = 2; p.aa.wait_shard = p.pa.wait_shard; p.aa.wait_blocks = p.pa.wait_blocks; p.aa.err = c->h_err_dev;
+        p.aa.q = act(l, o_q); p.aa.knew = act(l, o_k); p.aa.vnew = act(l, o_v); p.aa.xb = act(l, o_xb);
+        p.aa.att = act(l, o_att); p.aa.part = c->chain_part + (size_t)l * c->H_loc * 8 * rec;
+      }
+      if (l == 0) { off[r] = run; }
+      run += p.nblocks;
+    }
+    if (l == 0) off[5] = run;
+  }
+  ChainPhase& pc = ph[5 * c->L];
+  pc.mode = MODE_CLS;
+  pc.pa = cls_args(c, !greedy);
+  pc.pa.in = act(c->L - 1, o_xo);
+  pc.U = chain_U(pc.pa.n);
+  pc.nblocks = chain_blocks(c, MODE_CLS, pc.pa.rows);
+  chain_wire(c, pc.pa, 5 * c->L, prev_blocks);
+  { const size_t pl = chain_phase_lds(MODE_CLS, pc.pa.n, pc.U); if (pl > lds) lds = pl; }
+  if (greedy) {
+    ChainPhase& pg = ph[5 * c->L + 1];
+    pg.mode = CHAIN_ARGMAX;
+    pg.pa = base_args(c);
+    chain_wire(c, pg.pa, 5 * c->L + 1, pc.nblocks);
+    pg.nblocks = 1;
+  }
+  HIPCHK(hipMalloc(&cs.d_phases, sizeof(ChainPhase) * nph));
+  HIPCHK(hipMemcpy(cs.d_phases, ph.data(), sizeof(ChainPhase) * nph, hipMemcpyHostToDevice));
+  ChainLaunch& cl = cs.cl;
+  memset(&cl, 0, sizeof(cl));
+  cl.phases = cs.d_phases; cl.L = c->L;
+  for (int i = 0; i < 6; ++i) cl.off[i] = off[i];
+  cl.cls_first = c->L * off[5]; cl.cls_blocks = pc.nblocks; cl.has_argmax = greedy;
+  cl.logits = c->logits; cl.V = c->V; cl.tokpos = c->tokpos; cl.tokens_out = c->d_tokens;
+  cs.blocks = cl.cls_first + cl.cls_blocks + (greedy ? 1 : 0);
+#ifdef L2_STAMPS
+  { unsigned long long* tl = nullptr; HIPCHK(hipMalloc(&tl, (size_t)cs.blocks * 16)); HIPCHK(hipMemset(tl, 0, (size_t)cs.blocks * 16)); cl.tl = tl; g_chain_tl = tl; g_chain_blocks = cs.blocks; g_chain_off = cl; }
+#endif
+  cs.lds = lds;
+  cs.built = true;
+  return L2_OK;
+}
+
+static int enqueue_chain(l2_ctx* c, hipStream_t st, bool to_host, bool greedy) {
+  int level = 0;
+  for (int i = 0; i < 3; ++i) if (splits_of(c, i) == c->cur_splits) level = i;
+  (void)to_host;
+  int rc = build_chain(c, level, greedy ? 1 : 0);
+  if (rc) return rc;
+  const l2_ctx::ChainSet& cs = c->chain[level][greedy ? 1 : 0];
+  LCHK(hipMemsetAsync(c->chain_ctr, 0, c->chain_ctr_bytes, st));     // re-arm every counter and flag
+  hipLaunchKernelGGL(chain_kernel, dim3(cs.blocks), dim3(256), cs.lds, st, cs.cl);
+  LCHK(hipGetLastError());
+  return L2_OK;
+}
+
+// Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
+static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
+  if (can_chain(c)) return enqueue_chain(c, st, to_host, false);
+  for (int l = 0; l < c->L; ++l) {
+    PhaseArgs a = qkv_args(c, l);
     if (can_fuse_attn(c)) {   // 1+2 in one launch: attention waits per head on the q/k/v rows of this position
       LCHK(launch_qkv_attn(c, l, a, st));
     } else {
       LCHK(launch_phase<MODE_QKV>(c, a, st));
-      // 2. attention (llama2.ts:244-267)
-      LCHK(launch_attn(c, l, st));
+      LCHK(launch_attn(c, l, st));   // attention (llama2.ts:244-267)
     }
-    // 3. wo GEMV + residual (llama2.ts:270-273)
-    memset(&a, 0, sizeof(a));
-    a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
-    a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l;
-    a.in = c->xb; a.emb = (l == 0) ? emb : nullptr; a.res = c->x; a.out = c->x; a.aux = c->xb2;
-    a.n = c->d_loc; a.rows = c->d;
-    if (c->tp_path) a.partial = c->partial;
+    a = wo_args(c, l);
     LCHK(launch_phase<MODE_WO>(c, a, st));
     if (c->tp_path) {
       NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st));
-      hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? emb : nullptr, c->partial, c->xb2, c->tokpos, c->d);
+      hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->partial, c->xb2, c->tokpos, c->d);
       LCHK(hipGetLastError());
     }
-    // 4. rmsnorm + w1,w3 GEMVs + SwiGLU (llama2.ts:276-289)
-    memset(&a, 0, sizeof(a));
-    a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
-    a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l;
-    a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
-    a.in = c->x; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * l;
-    a.out = c->hb; a.aux = c->hb2;
-    a.n = c->d; a.rows = c->h_loc;
+    a = w13_args(c, l);
     LCHK(launch_phase<MODE_W13>(c, a, st));
-    // 5. w2 GEMV + residual (llama2.ts:292-295)
-    memset(&a, 0, sizeof(a));
-    a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
-    a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l;
-    a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = c->tp_path ? nullptr : c->xb;
-    a.n = c->h_loc; a.rows = c->d;
-    if (c->tp_path) a.partial = c->partial;
+    a = w2_args(c, l);
     LCHK(launch_phase<MODE_W2>(c, a, st));
     if (c->tp_path) {
       NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st));
@@ -707,14 +901,7 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
       LCHK(hipGetLastError());
     }
   }
-  // final rmsnorm + classifier (llama2.ts:299-302)
-  PhaseArgs a;
-  memset(&a, 0, sizeof(a));
-  a.tokpos = c->tokpos; a.head_size = c->hs; a.dim = c->d;
-  a.w0 = c->w[L2_T_WCLS];
-  a.in = c->x; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xn;
-  a.aux2 = (to_host && c->opt_zero_copy && !c->tp_path) ? c->h_logits_dev : nullptr;
-  a.n = c->d; a.rows = c->V_loc;
+  PhaseArgs a = cls_args(c, to_host);
   LCHK(launch_phase<MODE_CLS>(c, a, st));
   if (c->tp_path) NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st));
   return L2_OK;
@@ -734,6 +921,7 @@ static int ensure_ready(l2_ctx* c) {
 }
 
 static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step: forward, argmax, advance
+  if (can_chain(c)) return enqueue_chain(c, st, false, true);
   int rc = enqueue_forward(c, st);
   if (rc) return rc;
   hipLaunchKernelGGL(argmax_advance_kernel, dim3(1), dim3(1024), 0, st, c->logits, c->V, c->tokpos, c->d_tokens);
@@ -767,6 +955,7 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   const int lvl = split_level(c, pos);
   c->cur_splits = splits_of(c, lvl);
+  if (can_chain(c)) { rc = build_chain(c, lvl, 0); if (rc) return rc; }   // allocations must precede any capture
   if (c->opt_graph) {
     if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc) return rc; }
     HIPCHK(hipGraphLaunch(c->g_step[lvl], c->stream));
@@ -794,6 +983,7 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   HIPCHK(hipSetDevice(c->device));
   c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (can_chain(c)) for (int s = 0; s < steps; ++s) { rc = build_chain(c, split_level(c, pos0 + s), 1); if (rc) return rc; }
   if (c->opt_graph) {   // capture what this run needs before the timed region
     for (int s = 0; s < steps; ++s) {
       const int lvl = split_level(c, pos0 + s);
@@ -868,9 +1058,15 @@ extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t
 extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
   if (!c) return fail(L2_E_ARG, "null context");
   switch (key) {
-    case L2_OPT_EXACT_ATTENTION: if (c->opt_exact != !!value) { c->opt_exact = !!value; destroy_graphs(c); } return L2_OK;
+    case L2_OPT_EXACT_ATTENTION:
+      if (c->opt_exact != !!value) {
+        c->opt_exact = !!value;
+        destroy_graphs(c);
+        for (auto& lv : c->chain) for (auto& cs : lv) { if (cs.d_phases) hipFree(cs.d_phases); cs.d_phases = nullptr; cs.built = false; }
+      }
+      return L2_OK;
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
-    case L2_OPT_MEGAKERNEL: return value ? fail(L2_E_ARG, "megakernel path not built in this version") : L2_OK;
+    case L2_OPT_MEGAKERNEL: if (c->opt_chain != !!value) { c->opt_chain = !!value; destroy_graphs(c); } return L2_OK;
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }
@@ -880,7 +1076,7 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
   switch (key) {
     case L2_OPT_EXACT_ATTENTION: *value = c->opt_exact; return L2_OK;
     case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
-    case L2_OPT_MEGAKERNEL: *value = 0; return L2_OK;
+    case L2_OPT_MEGAKERNEL: *value = c->opt_chain; return L2_OK;
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }

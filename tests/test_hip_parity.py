@@ -221,3 +221,24 @@ def test_long_context_crosses_every_split_level_token_exact(built):
         if pos in keep:
             assert np.abs(got - g["logits"][keep[pos]]).max() <= TOL, pos
     ctx.close()
+
+
+@pytest.mark.parametrize("name,steps", [("tiny", 64), ("stories15M", 48)])
+def test_chain_launch_matches_reference(built, name, steps):
+    """Experimental one-kernel-per-token chain launch (L2_OPT_MEGAKERNEL): phases ordered by block id, in-launch
+    hand-offs through write-through stores and completion counters.  Must give the reference's tokens and logits;
+    a bounded wait that gives up surfaces as an L2Error, never as a hang."""
+    meta, g = load_gold(name)
+    ctx = runtime.Context(meta["header"])
+    ctx.synth_fill(meta["seed"])
+    ctx.set_option(runtime.OPT_MEGAKERNEL, 1)
+    assert ctx.get_option(runtime.OPT_MEGAKERNEL) == 1
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    for pos, tok in enumerate(meta["tokens_fed"][:steps]):
+        got = np.array(ctx.forward(tok, pos), copy=True)
+        assert runtime.argmax(got) == meta["argmax"][pos], (name, pos)
+        if pos in keep:
+            assert np.abs(got - g["logits"][keep[pos]]).max() <= TOL
+    toks = ctx.decode_greedy(1, 0, steps)
+    assert toks.tolist() == meta["argmax"][:steps]
+    ctx.close()
