@@ -55,13 +55,13 @@ def cpu_baseline(name, hdr, seed):
             o.forward(1, 0)
             t0 = time.perf_counter()
             tok = 1
-            for pos in range(1, 4):
+            for pos in range(1, 7):
                 tok = O.argmax(o.forward(tok, pos))
-            t[layers] = (time.perf_counter() - t0) / 3.0
+            t[layers] = (time.perf_counter() - t0) / 6.0
             o.close()
         per_layer = (t[3] - t[1]) / 2.0
         sec = t[1] + (L - 1) * per_layer
-        sample = "oracle on 1- and 3-layer models of this width, 3 tokens each, extrapolated to %d layers" % L
+        sample = "oracle on 1- and 3-layer models of this width, 6 tokens each, extrapolated to %d layers" % L
     else:
         o = O.Oracle(hdr, seed)
         steps = 8
@@ -120,13 +120,14 @@ def main():
             dist.broadcast(idbuf, 0)
             tp = {"rank": rank, "size": world, "id": bytes(idbuf.numpy().tobytes())}
 
-    cfg, ctx = run_single(args, hdr, local_rank, tp)
+    device = int(os.environ.get("L2_BENCH_FORCE_DEVICE", local_rank))   # test hook: several ranks on one GPU (replicas only)
+    cfg, ctx = run_single(args, hdr, device, tp)
 
     def sync_all():
         if dist is not None:
             dist.barrier()
             import torch
-            torch.cuda.synchronize(local_rank)
+            torch.cuda.synchronize(device)
 
     ctx.bench_decode(1, 0, W)                  # W untimed warm-up steps (captures the graph too)
     sync_all()

@@ -127,17 +127,6 @@ __device__ __forceinline__ f4 ldg_nt(const float* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
 }
 
-// Sum over aligned groups of `lpr` lanes (power of two); the total is valid in the LAST lane of each group.
-__device__ __forceinline__ double seg_sum(double v, int lpr) {
-  if (lpr >= 2) v += dpp_f64<0xB1, 0xf>(v);
-  if (lpr >= 4) v += dpp_f64<0x4E, 0xf>(v);
-  if (lpr >= 8) v += dpp_f64<0x141, 0xf>(v);
-  if (lpr >= 16) v += dpp_f64<0x140, 0xf>(v);
-  if (lpr >= 32) v += dpp_f64<0x142, 0xa>(v);
-  if (lpr >= 64) v += dpp_f64<0x143, 0xc>(v);
-  return v;
-}
-
 // ------------------------------------------------------------------------------------------------
 // One dependency phase of a layer = prologue (stage the input vector in LDS, optional rmsnorm) +
 // GEMV over this phase's matrix rows + fused epilogue.
@@ -662,26 +651,8 @@ __device__ __forceinline__ void attn_stage(const AttnArgs& a, int h, int tid, do
   __syncthreads();
 }
 
-// One batch of NB passes of the score / value sweeps: all NB row loads are issued before the first use (addresses
-// clamped, never predicated: a predicated load makes hipcc serialise the batch behind vmcnt(0) waits).
-template <int NB>
-__device__ __forceinline__ void score_batch(const float* kbase, int dim, int tb, int G, int grp, int pos, int lpr, int sub,
-                                            const double (&qv)[4], double rsq, float* att) {
-  f4 kr[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) kr[b] = *reinterpret_cast<const f4*>(kbase + (size_t)min(tb + b * G + grp, pos - 1) * dim);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int t = tb + b * G + grp;
-    double p = qv[0] * (double)kr[b].x;
-    p += qv[1] * (double)kr[b].y;
-    p += qv[2] * (double)kr[b].z;
-    p += qv[3] * (double)kr[b].w;
-    p = seg_sum(p, lpr);
-    if (sub == lpr - 1 && t < pos) att[t] = (float)(p / rsq);
-  }
-}
-
+// One batch of NB passes of the value sweep: all NB row loads are issued before the first use (addresses clamped,
+// never predicated: a predicated load makes hipcc serialise the batch behind vmcnt(0) waits).
 template <int NB>
 __device__ __forceinline__ void value_batch(const float* vbase, int dim, int tb, int G, int grp, int pos, const float* att, double (&o)[4]) {
   f4 vr[NB];
