@@ -90,6 +90,17 @@ int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, con
  * copied to HBM before the call returns. */
 int l2_upload(l2_ctx* ctx, int tensor_kind, int layer, const float* host, size_t n_floats);
 
+/* Next row of SURVEY.md 8(f2): the checkpoint load path (FileHandleReader + readWeights, llama2.ts:44-68,
+ * 112-129) done natively: reads the 28-byte header of the llama2.c-v0 file at `path`, creates the context and
+ * streams every tensor to HBM through two pinned staging buffers (file reads overlap the host-to-device
+ * copies), so host memory never holds more than 2 x 64 MiB of a 27 GB checkpoint.  Tensor-parallel ranks pass
+ * their rank / size / id and receive only their slices; tp_size 1 ignores them.  `bytes_read` (optional)
+ * returns the file bytes consumed.  Equivalent to l2_create + one l2_upload per Float32Array. */
+int l2_load_checkpoint(const char* path, int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out,
+                       uint64_t* bytes_read);
+/* The 7 header ints of a context (what readConfig parsed). */
+int l2_get_header(l2_ctx* ctx, int32_t cfg_out[7]);
+
 /* Fill every tensor on the device with the repo's deterministic synthetic generator (same values as
  * oracle/llama2_oracle.c:orc_synth_tensor); used by bench.py for shapes too large to ship. */
 int l2_synth_fill(l2_ctx* ctx, uint32_t seed);

@@ -394,6 +394,80 @@ extern "C" int l2_upload(l2_ctx* c, int kind, int layer, const float* host, size
   return L2_OK;
 }
 
+// ---- native checkpoint loader -------------------------------------------------
+extern "C" int l2_get_header(l2_ctx* c, int32_t cfg_out[7]) {
+  if (!c || !cfg_out) return fail(L2_E_ARG, "null argument");
+  memcpy(cfg_out, c->hdr, sizeof(c->hdr));
+  return L2_OK;
+}
+
+extern "C" int l2_load_checkpoint(const char* path, int device, int tp_rank, int tp_size, const void* nccl_id,
+                                  l2_ctx** out, uint64_t* bytes_read) {
+  if (!path || !out) return fail(L2_E_ARG, "null argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(L2_E_ARG, "cannot open checkpoint %s", path);
+  int32_t hdr[7];
+  if (fread(hdr, 4, 7, f) != 7) { fclose(f); return fail(L2_E_ARG, "checkpoint %s: short header", path); }
+  l2_ctx* c = nullptr;
+  int rc = (tp_size > 1) ? l2_create_tp(hdr, device, tp_rank, tp_size, nccl_id, &c) : l2_create(hdr, device, &c);
+  if (rc) { fclose(f); return rc; }
+  // two pinned staging buffers: fread into one while the other is in flight to the device
+  const size_t CH = (size_t)64 << 20;
+  float* stage[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  bool pending[2] = {false, false};
+  auto cleanup = [&](int code) {
+    for (int i = 0; i < 2; ++i) { if (stage[i]) hipHostFree(stage[i]); if (done[i]) hipEventDestroy(done[i]); }
+    fclose(f);
+    if (code) l2_destroy(c);
+    return code;
+  };
+  for (int i = 0; i < 2; ++i) {
+    if (hipHostMalloc(&stage[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreate(&done[i]) != hipSuccess)
+      return cleanup(fail(L2_E_HIP, "cannot allocate pinned staging"));
+  }
+  uint64_t total = 28;
+  int cur = 0;
+  for (int kind = 0; kind < L2_T_COUNT; ++kind) {
+    if (kind == L2_T_WCLS && c->shared) continue;
+    const Slice sl = tensor_slice(c, kind);
+    const size_t full_layer = sl.full_rows * sl.full_cols;
+    for (int layer = 0; layer < c->layers_of[kind]; ++layer) {
+      float* dst = c->w[kind] + c->layer_elems[kind] * (size_t)layer;
+      // stream the layer in whole-row chunks; a rank keeps only its rows / columns
+      const size_t rows_per_chunk = CH / (sl.full_cols * sizeof(float)) ? CH / (sl.full_cols * sizeof(float)) : 1;
+      if (sl.full_cols * sizeof(float) > CH) return cleanup(fail(L2_E_CONFIG, "row of %zu floats exceeds the staging buffer", sl.full_cols));
+      for (size_t r0 = 0; r0 < sl.full_rows; r0 += rows_per_chunk) {
+        const size_t nr = (sl.full_rows - r0 < rows_per_chunk) ? sl.full_rows - r0 : rows_per_chunk;
+        if (pending[cur]) { if (hipEventSynchronize(done[cur]) != hipSuccess) return cleanup(fail(L2_E_HIP, "staging sync failed")); pending[cur] = false; }
+        if (fread(stage[cur], sizeof(float), nr * sl.full_cols, f) != nr * sl.full_cols)
+          return cleanup(fail(L2_E_ARG, "checkpoint %s truncated in tensor kind %d", path, kind));
+        total += nr * sl.full_cols * sizeof(float);
+        // intersect [r0, r0+nr) with the rank's rows [row0, row0+rows)
+        const size_t a = r0 > sl.row0 ? r0 : sl.row0;
+        const size_t b = (r0 + nr < sl.row0 + sl.rows) ? r0 + nr : sl.row0 + sl.rows;
+        if (a < b) {
+          const float* src = stage[cur] + (a - r0) * sl.full_cols + sl.col0;
+          float* d = dst + (a - sl.row0) * sl.cols;
+          hipError_t e = hipMemcpy2DAsync(d, sl.cols * sizeof(float), src, sl.full_cols * sizeof(float), sl.cols * sizeof(float),
+                                          b - a, hipMemcpyHostToDevice, c->stream);
+          if (e != hipSuccess) return cleanup(fail(L2_E_HIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e)));
+          hipEventRecord(done[cur], c->stream);
+          pending[cur] = true;
+        }
+        cur ^= 1;
+      }
+      (void)full_layer;
+      c->uploaded[kind][layer] = 1;
+    }
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return cleanup(fail(L2_E_HIP, "upload sync failed"));
+  if (bytes_read) *bytes_read = total;
+  *out = c;
+  return cleanup(L2_OK);
+}
+
 // deterministic exp / sincos from IEEE basic operations (same recipe as the oracle's generator)
 static double det_exp(double x) {
   const double y = x / 1024.0;

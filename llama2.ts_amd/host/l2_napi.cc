@@ -34,6 +34,8 @@ struct Api {
   decltype(&l2_decode_greedy) decode_greedy;
   decltype(&l2_read_state) read_state;
   decltype(&l2_set_option) set_option;
+  decltype(&l2_load_checkpoint) load_checkpoint;
+  decltype(&l2_get_header) get_header;
 } api;
 
 std::string g_load_error;
@@ -53,7 +55,7 @@ bool load_library(const char* hint) {
   api.name = (decltype(api.name))dlsym(api.so, "l2_" #name);               \
   if (!api.name) { g_load_error = "missing symbol l2_" #name; dlclose(api.so); api.so = nullptr; return false; }
   BIND(abi_version) BIND(device_count) BIND(last_error) BIND(create) BIND(destroy) BIND(upload) BIND(synth_fill)
-  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(read_state) BIND(set_option)
+  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(read_state) BIND(set_option) BIND(load_checkpoint) BIND(get_header)
 #undef BIND
   if (api.abi_version() != L2_ABI_VERSION) { g_load_error = "ABI version mismatch"; dlclose(api.so); api.so = nullptr; return false; }
   return true;
@@ -168,6 +170,32 @@ napi_value Create(napi_env env, napi_callback_info info) {
   napi_value ext;
   napi_create_external(env, slot, finalize_ctx, nullptr, &ext);
   return ext;
+}
+
+// loadCheckpoint(path, device) -> { ctx, header: Int32Array(7) }   (native readWeights)
+napi_value LoadCheckpoint(napi_env env, napi_callback_info info) {
+  ARGS(2)
+  if (!api.so) return throw_err(env, "call open() first");
+  char path[4096] = "";
+  size_t n = 0;
+  napi_get_value_string_utf8(env, argv[0], path, sizeof(path), &n);
+  int32_t dev;
+  if (!get_i32(env, argv[1], &dev)) return nullptr;
+  l2_ctx* c = nullptr;
+  uint64_t bytes = 0;
+  int rc = api.load_checkpoint(path, dev, 0, 1, nullptr, &c, &bytes);
+  if (rc) return throw_l2(env, rc);
+  Slot* slot = new Slot{c, 0, false, false};
+  napi_value ext, ab, ta, obj;
+  napi_create_external(env, slot, finalize_ctx, nullptr, &ext);
+  void* data;
+  napi_create_arraybuffer(env, 28, &data, &ab);
+  api.get_header(c, (int32_t*)data);
+  napi_create_typedarray(env, napi_int32_array, 7, ab, 0, &ta);
+  napi_create_object(env, &obj);
+  napi_set_named_property(env, obj, "ctx", ext);
+  napi_set_named_property(env, obj, "header", ta);
+  return obj;
 }
 
 napi_value Destroy(napi_env env, napi_callback_info info) {
@@ -289,7 +317,7 @@ napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"upload", Upload}, {"synthFill", SynthFill},
       {"forward", Forward}, {"logitsBuffer", LogitsBuffer}, {"decodeGreedy", DecodeGreedy}, {"readState", ReadState},
-      {"setOption", SetOption}, {"deviceCount", DeviceCount}};
+      {"setOption", SetOption}, {"deviceCount", DeviceCount}, {"loadCheckpoint", LoadCheckpoint}};
   for (auto& f : fns) {
     napi_value v;
     napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);

@@ -273,13 +273,22 @@ function main() {
   const device = parseInt(process.env.L2_DEVICE || "0");
 
   // checkpoint: 7-int header, then the tensors in llama2.c-v0 order (llama2.ts:427-436)
-  const fileHandle = fs.openSync(checkpoint, "r");
-  const configBuffer = Buffer.alloc(28);
-  fs.readSync(fileHandle, configBuffer, 0, 28, 0);
-  const config = readConfig(new BufferReader(configBuffer));
-  const ctx = be.create(config.header, device);
-  const weights = readWeights(config, new FileHandleReader(fileHandle, 28), config.shared_weights, be, ctx);
-  fs.closeSync(fileHandle);
+  let config, ctx, weights;
+  if (process.env.L2_NATIVE_LOADER == "1") {
+    // opt-in extra (SURVEY.md 8(f2)): the library reads the file itself through pinned staging buffers
+    const r = be.loadCheckpoint(checkpoint, device);
+    config = readConfig(new BufferReader(Buffer.from(r.header.buffer, r.header.byteOffset, 28)));
+    ctx = r.ctx;
+    weights = { ctx, uploaded: ["(native loader)"] };
+  } else {
+    const fileHandle = fs.openSync(checkpoint, "r");
+    const configBuffer = Buffer.alloc(28);
+    fs.readSync(fileHandle, configBuffer, 0, 28, 0);
+    config = readConfig(new BufferReader(configBuffer));
+    ctx = be.create(config.header, device);
+    weights = readWeights(config, new FileHandleReader(fileHandle, 28), config.shared_weights, be, ctx);
+    fs.closeSync(fileHandle);
+  }
 
   if (steps <= 0 || steps > config.seq_len) steps = config.seq_len;
 

@@ -31,7 +31,7 @@ OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_MEGAKERNEL = 1, 2, 3
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
                "l2_decode_greedy", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
-               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode"]
+               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header"]
 
 
 class L2Error(RuntimeError):
@@ -74,6 +74,8 @@ def lib():
     L.l2_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.l2_bench_gemv.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
     L.l2_bench_decode.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
+    L.l2_load_checkpoint.argtypes = [C.c_char_p, i32, i32, i32, vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.l2_get_header.argtypes = [vp, vp]
     for name in ABI_SYMBOLS:   # fail at load time, not at first use, if the .so is stale
         getattr(L, name)
     _lib = L
@@ -270,6 +272,20 @@ def argmax(arr):
         if a[i] > bv:
             best, bv = i, a[i]
     return best
+
+
+def load_checkpoint_native(path, device=0):
+    """Same as load_checkpoint but through l2_load_checkpoint (pinned double-buffered streaming)."""
+    h = C.c_void_p()
+    n = C.c_uint64()
+    _check(lib().l2_load_checkpoint(path.encode(), device, 0, 1, None, C.byref(h), C.byref(n)))
+    hdr = (C.c_int32 * 7)()
+    _check(lib().l2_get_header(h, hdr))
+    ctx = Context.__new__(Context)
+    ctx.cfg = Config(tuple(hdr))
+    ctx._h, ctx.tp_rank, ctx.tp_size, ctx._logits_view = h, 0, 1, None
+    weights = TransformerWeights(ctx)
+    return ctx.cfg, newRunState(ctx.cfg, weights), weights, n.value
 
 
 def load_checkpoint(path, device=0):

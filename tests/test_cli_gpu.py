@@ -69,3 +69,10 @@ def test_cli_usage_and_errors(workdir):
     assert rc == 1 and "Usage:" in err               # flag without value (llama2.ts:410)
     rc, _, err = run_cli(workdir, ["-t", "0", "-i", "中"])
     assert rc == 1 and "character not found in vocab" in err   # llama2.ts:310
+
+
+def test_cli_native_loader_prints_the_same(workdir):
+    meta = json.load(open(os.path.join(GOLD, "cli_prompt.json")))
+    rc, out, err = run_cli(workdir, meta["argv"], {"L2_NATIVE_LOADER": "1"})
+    assert rc == 0, err
+    assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])

@@ -242,3 +242,26 @@ def test_chain_launch_matches_reference(built, name, steps):
     toks = ctx.decode_greedy(1, 0, steps)
     assert toks.tolist() == meta["argmax"][:steps]
     ctx.close()
+
+
+def test_native_checkpoint_loader_equals_per_array_upload(built, tmp_path):
+    """l2_load_checkpoint vs readWeights + l2_upload: same bytes in HBM, same logits."""
+    import time
+    meta, g = load_gold("stories15M")
+    path = str(tmp_path / "m.bin")
+    O.synth_write(meta["header"], meta["seed"], path)
+    t0 = time.time()
+    cfg, state, weights, nbytes = runtime.load_checkpoint_native(path)
+    t1 = time.time()
+    cfg2, state2, weights2 = runtime.load_checkpoint(path)
+    t2 = time.time()
+    assert nbytes == os.path.getsize(path) == 60816028 and cfg.header == tuple(meta["header"])
+    for kind, layers, count in runtime.tensor_shapes(cfg):
+        for layer in ([0, layers - 1] if layers else [0]):
+            a = weights.ctx.read_tensor(kind, layer, 0, count)
+            b = weights2.ctx.read_tensor(kind, layer, 0, count)
+            assert np.array_equal(bits(a), bits(b)), (kind, layer)
+    runtime.transformer(1, 0, cfg, state, weights)
+    assert np.abs(state.logits - g["logits"][0]).max() <= TOL
+    print("\nnative loader %.0f MB/s, readWeights+l2_upload %.0f MB/s" % (nbytes / 1e6 / (t1 - t0), nbytes / 1e6 / (t2 - t1)))
+    weights.ctx.close(); weights2.ctx.close()
