@@ -265,3 +265,41 @@ def test_native_checkpoint_loader_equals_per_array_upload(built, tmp_path):
     assert np.abs(state.logits - g["logits"][0]).max() <= TOL
     print("\nnative loader %.0f MB/s, readWeights+l2_upload %.0f MB/s" % (nbytes / 1e6 / (t1 - t0), nbytes / 1e6 / (t2 - t1)))
     weights.ctx.close(); weights2.ctx.close()
+
+
+def test_full_size_7b_properties(built):
+    """BASELINE.json's full Llama-2-7B shape (27 GB of synthetic weights generated on the device): properties that
+    do not need a CPU pass over 27 GB -- the captured-graph and eager paths agree bit for bit, the bit-faithful and
+    default attention agree within the gate, the split-attention and chain launches give the same tokens, the
+    greedy stream is reproducible, and logits are finite with softmax rows summing to one."""
+    hdr = configs.header("llama2_7b")
+    ctx = runtime.Context(hdr)
+    ctx.synth_fill(11)
+    a = [np.array(ctx.forward(t, p), copy=True) for p, t in enumerate([1, 5, 9])]
+    ctx.set_option(runtime.OPT_USE_GRAPH, 0)
+    b = [np.array(ctx.forward(t, p), copy=True) for p, t in enumerate([1, 5, 9])]
+    assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, b))
+    ctx.set_option(runtime.OPT_EXACT_ATTENTION, 1)
+    c = [np.array(ctx.forward(t, p), copy=True) for p, t in enumerate([1, 5, 9])]
+    assert max(float(np.abs(x - y).max()) for x, y in zip(a, c)) <= 1e-5
+    ctx.set_option(runtime.OPT_EXACT_ATTENTION, 0)
+    ctx.set_option(runtime.OPT_USE_GRAPH, 1)
+    assert np.isfinite(a[2]).all()
+    att = ctx.read_state("att").reshape(ctx.cfg.n_heads, ctx.cfg.seq_len)[:, :3]
+    assert np.allclose(att.sum(axis=1), 1.0, atol=1e-5)
+    t1 = ctx.decode_greedy(1, 0, 12)
+    t2 = ctx.decode_greedy(1, 0, 12)
+    assert t1.tolist() == t2.tolist()
+    ctx.set_option(runtime.OPT_MEGAKERNEL, 1)
+    t3 = ctx.decode_greedy(1, 0, 12)
+    assert t3.tolist() == t1.tolist()
+    ctx.close()
+    os.environ["L2_ATTN_SPLITS"] = "8"
+    try:
+        ctx = runtime.Context(hdr)
+    finally:
+        del os.environ["L2_ATTN_SPLITS"]
+    ctx.synth_fill(11)
+    t4 = ctx.decode_greedy(1, 0, 12)
+    assert t4.tolist() == t1.tolist()
+    ctx.close()
