@@ -149,7 +149,7 @@ def main():
         "metric": "decode tokens/sec + achieved HBM GB/s (% peak), 1 GPU" if world == 1 else "decode tokens/sec (whole job)",
         "value": round(value, 3), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(1e3 * wall / K, 5), "higher_is_better": True,
-        "scaling": "strong" if shards else "weak", "vs_baseline": None, "dtype": "f32 storage, f64 accumulate",
+        "scaling": "strong" if shards else "weak", "vs_baseline": None, "dtype": "f64", "storage_dtype": "f32",
         "data": "synthetic (seeded hash generator, llama2.c-v0 layout)",
         "config": {"workload": "%s batch-1 greedy decode, %d tokens from BOS (-t 0 -s 1 -n %d)" % (args.config, K, K),
                    "header": list(hdr), "parallelism": ("tp%d" % world) if shards else ("replicas%d" % world if world > 1 else "single"),

@@ -598,7 +598,13 @@ static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
   // persistent grid: 2 workgroups (8 waves) per CU, each wave looping over row groups with both register sets
   // full, measured best on the 7B shapes (129.6 us of GEMV per layer vs 134.1 at 6 per CU)
   const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : 256 * 2;
-  if (grid > cap) grid = cap;
+  if (grid > cap) {
+    // balanced: every wave gets the same number k of row groups (w1/w3 of 7B: 5504 groups on 2048 waves would
+    // leave a third of the chip idle in the last round; 459 workgroups x 4 waves x 3 groups covers it evenly)
+    const int waves_cap = cap * g.nwaves;
+    const int k = (groups + waves_cap - 1) / waves_cap;
+    grid = (groups + g.nwaves * k - 1) / (g.nwaves * k);
+  }
   g.grid = grid < 1 ? 1 : grid;
   return g;
 }
