@@ -122,6 +122,13 @@ float* l2_logits_host(l2_ctx* ctx);
  * Does not stop at BOS (the caller truncates, llama2.ts:499). */
 int l2_decode_greedy(l2_ctx* ctx, int first_token, int pos0, int steps, int32_t* tokens_out);
 
+/* Next row of SURVEY.md 8(f3): prompt ingestion.  The reference runs one transformer() per prompt token and
+ * ignores the logits (llama2.ts:471-473); this feeds `n_tokens` tokens at positions pos0 .. pos0+n_tokens-1 in
+ * chunks of 16 that share every weight read (fp64 MFMA GEMMs), leaves the KV cache exactly as the n_tokens
+ * separate calls would, and returns the logits of the LAST position in logits_out (may be NULL).  Shapes whose
+ * dim / hidden_dim are not multiples of 16 fall back to n_tokens l2_forward calls. */
+int l2_prefill(l2_ctx* ctx, const int32_t* tokens, int n_tokens, int pos0, float* logits_out);
+
 /* Copy a RunState buffer to the host (parity tests).  For per-layer caches `layer` selects the
  * [S][d] slab (-1: all layers).  After a forward, X holds the final-normed x as in llama2.ts:299. */
 int l2_read_state(l2_ctx* ctx, int which, int layer, float* out, size_t n_floats);

@@ -582,6 +582,7 @@ struct AttnArgs {
   int fused;
   int dim, head_size, seq_len, n_heads, nsplit;
   int exact;             // 1: fp32-rounded t-sequential value accumulate (llama2.ts:263)
+  int pos_plus1;         // prefill: position of this query + 1 (0: read it from tokpos)
   int lpr;               // lanes per timestep row (power of two >= ceil(head_size / vecw))
 };
 
@@ -681,7 +682,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
   double* pacc = red + 8;                                                         // G * hs doubles
 
   const int tid = threadIdx.x;
-  const int pos = a.tokpos[1];
+  const int pos = a.pos_plus1 ? a.pos_plus1 - 1 : a.tokpos[1];
   constexpr int W = VEC ? 4 : 1;
   const int lpr = a.lpr, sub = tid & (lpr - 1), grp = tid / lpr, G = 256 / lpr;
   const int e0 = sub * W;                       // first element of this lane inside the head
@@ -719,7 +720,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
   for (int t = tid; t <= pos; t += 256) {
     const float pr = (float)((double)att[t] / sum);             // llama2.ts:192
     att[t] = pr;
-    a.att[(size_t)h * S + t] = pr;
+    if (a.att) a.att[(size_t)h * S + t] = pr;
   }
   __syncthreads();
   STAMP(3);
@@ -788,6 +789,22 @@ template <bool VEC>
 __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   attn_body<VEC>(a, smem, blockIdx.x);
+}
+
+// Prefill: grid (head, query).  Query p of the chunk sits at position pos0 + p and sees cache rows 0..pos0+p,
+// all written by the chunk's QKV GEMM in an earlier launch.
+template <bool VEC>
+__global__ void __launch_bounds__(256) pf_attn_kernel(const AttnArgs a, int pos0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  AttnArgs b = a;
+  const int p = blockIdx.y, pos = pos0 + p;
+  b.q = a.q + (size_t)p * a.dim;
+  b.xb = a.xb + (size_t)p * a.dim;
+  b.knew = a.kc + (size_t)pos * a.dim;
+  b.vnew = a.vc + (size_t)pos * a.dim;
+  b.att = nullptr;
+  b.pos_plus1 = pos + 1;
+  attn_body<VEC>(b, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

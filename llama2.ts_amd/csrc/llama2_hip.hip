@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "kernels.hip.h"
+#include "prefill.hip.h"
 
 using namespace l2k;
 
@@ -123,6 +124,9 @@ struct l2_ctx {
   float* chain_act = nullptr;       // per-layer activations: no buffer is rewritten inside one launch (see build_chain)
   size_t chain_act_stride = 0;      // floats per layer
   double* chain_part = nullptr;     // per-layer split-attention partials
+  // prefill (prefill.hip.h): 16-token chunk buffers
+  float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_xb = nullptr, *pf_hb = nullptr;
+  int* pf_tok = nullptr;
   struct ChainSet { ChainPhase* d_phases = nullptr; ChainLaunch cl; size_t lds = 0; int blocks = 0; bool built = false; } chain[3][2];
   int* tokpos = nullptr;    // device {token,pos,step,0}
   int* h_tokpos = nullptr;  // pinned
@@ -208,6 +212,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->head_done) hipFree(c->head_done);
   if (c->chain_ctr) hipFree(c->chain_ctr);
   if (c->chain_act) hipFree(c->chain_act);
+  { float* pb[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_xb, c->pf_hb}; for (float* b : pb) if (b) hipFree(b); if (c->pf_tok) hipFree(c->pf_tok); }
   if (c->chain_part) hipFree(c->chain_part);
   for (auto& lv : c->chain) for (auto& cs : lv) if (cs.d_phases) hipFree(cs.d_phases);
   if (c->h_err) hipHostFree(c->h_err);
@@ -1055,6 +1060,101 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
 }
 
 extern "C" float* l2_logits_host(l2_ctx* c) { return c ? c->h_logits : nullptr; }
+
+// ---- prefill -----------------------------------------------------------------
+static bool can_prefill(const l2_ctx* c) {
+  return !c->tp_path && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
+}
+
+static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
+  hipStream_t st = c->stream;
+  const size_t d = c->d, h = c->h;
+  if (!c->pf_x) {
+    HIPCHK(hipMalloc(&c->pf_x, PF_T * d * 4)); HIPCHK(hipMalloc(&c->pf_xn, PF_T * (d > h ? d : h) * 4));
+    HIPCHK(hipMalloc(&c->pf_q, PF_T * d * 4)); HIPCHK(hipMalloc(&c->pf_xb, PF_T * d * 4)); HIPCHK(hipMalloc(&c->pf_hb, PF_T * h * 4));
+    HIPCHK(hipMalloc(&c->pf_tok, PF_T * sizeof(int)));
+    HIPCHK(hipMemset(c->pf_xb, 0, PF_T * d * 4)); HIPCHK(hipMemset(c->pf_q, 0, PF_T * d * 4));
+  }
+  int32_t tk[PF_T] = {0};
+  for (int i = 0; i < n; ++i) tk[i] = tokens[i];
+  HIPCHK(hipMemcpyAsync(c->pf_tok, tk, sizeof(tk), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));   // tk is on the stack
+  hipLaunchKernelGGL(pf_embed_kernel, dim3(PF_T), dim3(256), 0, st, c->pf_x, c->w[L2_T_TOKEN_EMBEDDING], c->pf_tok, c->d, n);
+  LCHK(hipGetLastError());
+  for (int l = 0; l < c->L; ++l) {
+    const size_t loff = (size_t)l * c->S * c->d;
+    PfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG]; a.head_size = c->hs; a.dim = c->d; a.pos0 = pos0; a.nvalid = n;
+    a.x = c->pf_x;
+    // rmsnorm + q,k,v + RoPE + cache rows (llama2.ts:216-240)
+    hipLaunchKernelGGL(pf_norm_kernel, dim3(PF_T), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_ATT] + d * l, c->d);
+    a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
+    a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
+    a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
+    hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV>), dim3(a.rows / 16), dim3(256), 0, st, a);
+    LCHK(hipGetLastError());
+    // attention, one workgroup per (head, query) (llama2.ts:244-267)
+    {
+      AttnArgs aa;
+      int G;
+      c->cur_splits = 1;
+      fill_attn_args(c, l, aa, &G);
+      aa.q = c->pf_q; aa.xb = c->pf_xb; aa.att = nullptr;
+      const size_t lds = attn_lds(c, aa, G, false);
+      hipLaunchKernelGGL((pf_attn_kernel<true>), dim3(c->H, n), dim3(256), lds, st, aa, pos0);
+      LCHK(hipGetLastError());
+    }
+    // wo + residual (llama2.ts:270-273)
+    a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
+    hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO>), dim3(a.rows / 16), dim3(256), 0, st, a);
+    // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
+    hipLaunchKernelGGL(pf_norm_kernel, dim3(PF_T), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
+    a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
+    a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
+    hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13>), dim3(a.rows / 16), dim3(256), 0, st, a);
+    // w2 + residual (llama2.ts:292-295)
+    a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
+    hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2>), dim3(a.rows / 16), dim3(256), 0, st, a);
+    LCHK(hipGetLastError());
+  }
+  return L2_OK;
+}
+
+extern "C" int l2_prefill(l2_ctx* c, const int32_t* tokens, int n_tokens, int pos0, float* logits_out) {
+  if (!c || !tokens) return fail(L2_E_ARG, "null argument");
+  if (n_tokens <= 0 || pos0 < 0 || pos0 + n_tokens > c->S) return fail(L2_E_ARG, "positions %d..%d outside [0, seq_len=%d)", pos0, pos0 + n_tokens - 1, c->S);
+  for (int i = 0; i < n_tokens; ++i) if (tokens[i] < 0 || tokens[i] >= c->V) return fail(L2_E_ARG, "token %d outside [0, vocab_size=%d)", tokens[i], c->V);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  if (!can_prefill(c)) {   // shapes the 16x16 tiles do not cover: the reference's own one-token-per-call loop
+    for (int i = 0; i < n_tokens; ++i) { rc = l2_forward(c, tokens[i], pos0 + i, (i == n_tokens - 1) ? logits_out : nullptr); if (rc) return rc; }
+    return L2_OK;
+  }
+  HIPCHK(hipSetDevice(c->device));
+  int done = 0;
+  while (done < n_tokens) {
+    const int n = (n_tokens - done < PF_T) ? n_tokens - done : PF_T;
+    rc = prefill_chunk(c, tokens + done, n, pos0 + done);
+    if (rc) return rc;
+    done += n;
+  }
+  // logits of the last position only (llama2.ts:299-302): the decode classifier on the last row of the chunk
+  const int last = (n_tokens - 1) % PF_T;
+  c->h_tokpos[0] = tokens[n_tokens - 1]; c->h_tokpos[1] = pos0 + n_tokens - 1; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
+  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  PhaseArgs a = cls_args(c, true);
+  a.in = c->pf_x + (size_t)last * c->d;
+  LCHK(launch_phase<MODE_CLS>(c, a, c->stream));
+  if (!(c->opt_zero_copy && !c->tp_path))
+    HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->ran_forward = true;
+  if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
+  return L2_OK;
+}
+
+
 
 static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool timed, float* ms) {
   if (!c) return fail(L2_E_ARG, "null context");

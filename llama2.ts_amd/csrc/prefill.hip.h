@@ -1,0 +1,150 @@
+// prefill.hip.h -- batched prompt ingestion.
+//
+// The reference feeds a prompt one token per transformer() call and throws the logits away
+// (llama2.ts:471-473), i.e. it streams every weight once per prompt token.  Up to 16 prompt positions share
+// the weights here: each phase becomes a (16 tokens) x (rows) x (n) GEMM, the first true dense contraction on
+// this path, and runs on the matrix cores: v_mfma_f64_16x16x4_f64 with the fp32 operands widened to fp64, so the
+// numeric contract is unchanged (exact products, fp64 accumulation, one fp32 rounding per stored element;
+// SURVEY.md 8(a-N)).  At 16 tokens the fp64 MFMA rate (16 B of weights per clock per CU) is about the HBM rate,
+// so a 16-token chunk costs about one decode step instead of sixteen.
+//
+// Tile orientation: M = tokens (A operand = activations), N = 16 output rows (B operand = weight rows), K = n.
+// Operand lanes (MI355X guide, f64 MFMA): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; results
+// C[row i = (l>>4) + 4*reg][col j = l&15].  Every lane loads one float4 of its activation row and one of its
+// weight row per 16-column block; the four MFMAs of a block take element 0..3 of both, so A and B see the same
+// (permuted) k order.  The four waves of a workgroup take the 16-column blocks round-robin (split K) and their
+// partial tiles are added in a fixed order through LDS.
+#pragma once
+#include "kernels.hip.h"
+
+namespace l2k {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+enum { PF_T = 16 };   // tokens per chunk
+
+struct PfArgs {
+  const float* w0;     // QKV: wq  W13: w1  else the matrix
+  const float* w1;     // QKV: wk  W13: w3
+  const float* w2;     // QKV: wv
+  const float* xin;    // [16][n] activations (normed x, attention output, or hb)
+  float* x;            // [16][dim] residual stream (WO / W2: updated in place)
+  float* out;          // QKV: q [16][dim]   W13: hb [16][rows]
+  float* kc; float* vc;        // QKV: cache slabs of this layer
+  const float* fr; const float* fi;
+  int n, rows, dim, head_size;
+  int pos0, nvalid;    // first position of the chunk, tokens in it (<= 16)
+};
+
+__global__ void __launch_bounds__(256) pf_embed_kernel(float* x, const float* emb, const int* tokens, int dim, int nvalid) {
+  const int t = blockIdx.x;
+  for (int i = threadIdx.x; i < dim; i += 256) x[(size_t)t * dim + i] = (t < nvalid) ? emb[(size_t)tokens[t] * dim + i] : 0.0f;
+}
+
+// rmsnorm of every token row (llama2.ts:172-179): one workgroup per token
+__global__ void __launch_bounds__(256) pf_norm_kernel(float* xn, const float* x, const float* w, int dim) {
+  __shared__ double red[8];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)t * dim;
+  double ss = 0.0;
+  for (int j = tid; j < dim; j += 256) { const double v = xr[j]; ss += v * v; }
+  ss = block_sum(ss, red, tid, 256);
+  ss /= (double)dim;
+  ss = 1.0 / sqrt(1e-5 + ss);
+  for (int j = tid; j < dim; j += 256) xn[(size_t)t * dim + j] = (float)((double)w[j] * (ss * (double)xr[j]));
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) pf_gemm_kernel(const PfArgs a) {
+  __shared__ double part[2][3][4][64];   // [tile (W13 has two)][waves 1..3][reg][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.n, nblk = n >> 4;                 // 16-column blocks
+  const int row0 = blockIdx.x * 16;                 // output rows of this tile
+  int m = 0, i0 = row0;
+  const float* wbase = a.w0;
+  if (MODE == MODE_QKV) { m = row0 / a.dim; i0 = row0 - m * a.dim; wbase = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2; }
+  const int j = lane & 15, kq = lane >> 4;
+  const float* wrow = wbase + (size_t)(i0 + j) * n + 4 * kq;
+  const float* wrow3 = (MODE == MODE_W13) ? a.w1 + (size_t)(i0 + j) * n + 4 * kq : nullptr;
+  const float* xrow = a.xin + (size_t)j * n + 4 * kq;       // token j as the A row
+
+  d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0};
+  constexpr int UN = 4;
+  for (int s0 = wave; s0 < nblk; s0 += 4 * UN) {
+    f4 wv[UN], xv[UN], w3[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int s = min(s0 + 4 * u, nblk - 1);      // clamped (never predicated) loads; masked below
+      wv[u] = ldg_nt(wrow + 16 * s);
+      if (MODE == MODE_W13) w3[u] = ldg_nt(wrow3 + 16 * s);
+      xv[u] = *reinterpret_cast<const f4*>(xrow + 16 * s);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (s0 + 4 * u < nblk) {
+        const double x0 = xv[u].x, x1 = xv[u].y, x2 = xv[u].z, x3 = xv[u].w;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)wv[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)wv[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)wv[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)wv[u].w, acc, 0, 0, 0);
+        if (MODE == MODE_W13) {
+          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)w3[u].x, acc3, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)w3[u].y, acc3, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)w3[u].z, acc3, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)w3[u].w, acc3, 0, 0, 0);
+        }
+      }
+    }
+  }
+  // split-K partials of waves 1..3 -> wave 0, added in wave order
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      part[0][wave - 1][r][lane] = acc[r];
+      if (MODE == MODE_W13) part[1][wave - 1][r][lane] = acc3[r];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc[r] = ((acc[r] + part[0][0][r][lane]) + part[0][1][r][lane]) + part[0][2][r][lane];
+    if (MODE == MODE_W13) acc3[r] = ((acc3[r] + part[1][0][r][lane]) + part[1][1][r][lane]) + part[1][2][r][lane];
+  }
+
+  // ---- epilogue: lane holds tokens t = kq + 4r (r = 0..3) of output index i = i0 + j
+  const int i = i0 + j;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = kq + 4 * r;
+    const float sv = (float)acc[r];                                  // matmul store (llama2.ts:201)
+    if (MODE == MODE_QKV) {
+      const int pos = a.pos0 + t;
+      if (m == 2) {
+        if (t < a.nvalid) a.vc[(size_t)pos * a.dim + i] = sv;         // llama2.ts:240
+      } else {
+        // RoPE pair (i even, i+1) sits in adjacent lanes (llama2.ts:224-235)
+        const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv), 0xB1, 0xf, 0xf, false));
+        const float s0 = (j & 1) ? other : sv, s1 = (j & 1) ? sv : other;
+        const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
+        const int cidx = (t < a.nvalid) ? idx : 0;
+        const double fcr = a.fr[cidx], fci = a.fi[cidx];
+        const float o = (j & 1) ? (float)((double)s0 * fci + (double)s1 * fcr) : (float)((double)s0 * fcr - (double)s1 * fci);
+        if (t < a.nvalid) {
+          if (m == 0) a.out[(size_t)t * a.dim + i] = o;
+          else a.kc[(size_t)pos * a.dim + i] = o;                      // llama2.ts:239
+        }
+      }
+    } else if (MODE == MODE_W13) {
+      const float h1 = sv, h3 = (float)acc3[r];
+      const double v = h1;
+      const float sl = (float)(v * (1.0 / (1.0 + exp(-v))));          // llama2.ts:285
+      a.out[(size_t)t * a.rows + i] = (float)((double)sl * (double)h3);  // llama2.ts:289
+    } else {   // WO / W2: residual accum (llama2.ts:273, 295)
+      float* xp = a.x + (size_t)t * a.dim + i;
+      *xp = *xp + sv;
+    }
+  }
+}
+
+}  // namespace l2k

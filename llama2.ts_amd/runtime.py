@@ -31,7 +31,7 @@ OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_MEGAKERNEL = 1, 2, 3
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
                "l2_decode_greedy", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
-               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header"]
+               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill"]
 
 
 class L2Error(RuntimeError):
@@ -76,6 +76,7 @@ def lib():
     L.l2_bench_decode.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
     L.l2_load_checkpoint.argtypes = [C.c_char_p, i32, i32, i32, vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.l2_get_header.argtypes = [vp, vp]
+    L.l2_prefill.argtypes = [vp, vp, i32, i32, vp]
     for name in ABI_SYMBOLS:   # fail at load time, not at first use, if the .so is stale
         getattr(L, name)
     _lib = L
@@ -163,6 +164,12 @@ class Context:
             return self.logits_host()
         _check(lib().l2_forward(self._h, int(token), int(pos), out.ctypes.data))
         return out
+
+    def prefill(self, tokens, pos0=0):
+        """Feed a run of (prompt) tokens at pos0.. in 16-token chunks; returns the logits of the last position."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        _check(lib().l2_prefill(self._h, t.ctypes.data, t.size, int(pos0), None))
+        return self.logits_host()
 
     def logits_host(self):
         if self._logits_view is None:

@@ -303,3 +303,54 @@ def test_full_size_7b_properties(built):
     t4 = ctx.decode_greedy(1, 0, 12)
     assert t4.tolist() == t1.tolist()
     ctx.close()
+
+
+@pytest.mark.parametrize("name,n", [("tiny", 1), ("tiny", 5), ("tiny", 16), ("tiny", 17), ("tiny", 40), ("ragged", 7), ("stories15M", 21)])
+def test_prefill_equals_token_by_token(built, name, n):
+    """l2_prefill (16-token chunks on fp64 MFMA) must leave the KV cache and the last logits exactly
+    where n separate transformer() calls -- what the reference does with a prompt, llama2.ts:471-473 -- leave them,
+    and decoding must continue identically.  `ragged` (dims not multiples of 16) takes the fallback path."""
+    meta, g = load_gold(name)
+    toks = meta["tokens_fed"][:n]
+    a = runtime.Context(meta["header"]); a.synth_fill(meta["seed"])
+    b = runtime.Context(meta["header"]); b.synth_fill(meta["seed"])
+    for pos, t in enumerate(toks):
+        la = np.array(a.forward(t, pos), copy=True)
+    lb = np.array(b.prefill(toks, 0), copy=True)
+    assert np.abs(la - lb).max() <= 1e-5
+    assert runtime.argmax(lb) == meta["argmax"][n - 1]
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    if n - 1 in keep:
+        assert np.abs(lb - g["logits"][keep[n - 1]]).max() <= TOL        # the TRUE reference's logits
+    d, S, L = b.cfg.dim, b.cfg.seq_len, b.cfg.n_layers
+    for nm in ("key_cache", "value_cache"):
+        ca = a.read_state(nm).reshape(L, S, d)[:, :n]
+        cb = b.read_state(nm).reshape(L, S, d)[:, :n]
+        assert np.abs(ca - cb).max() <= 1e-6, nm
+    ta, tb = runtime.argmax(la), runtime.argmax(lb)
+    for pos in range(n, min(n + 6, S)):                                   # keep decoding on both
+        la = np.array(a.forward(ta, pos), copy=True)
+        lb = np.array(b.forward(tb, pos), copy=True)
+        assert np.abs(la - lb).max() <= 1e-5
+        ta, tb = runtime.argmax(la), runtime.argmax(lb)
+        assert ta == tb == meta["argmax"][pos]
+    a.close(); b.close()
+
+
+def test_prefill_prompt_golden_and_errors(built):
+    meta, g = load_gold("stories15M_prompt")          # -i "Once upon a time": BOS + 4 prompt ids are teacher-forced
+    ctx = runtime.Context(meta["header"]); ctx.synth_fill(meta["seed"])
+    lg = np.array(ctx.prefill(meta["tokens_fed"][:5], 0), copy=True)
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    assert np.abs(lg - g["logits"][keep[4]]).max() <= TOL
+    tok = runtime.argmax(lg)
+    for pos in range(5, 24):
+        assert tok == meta["tokens_fed"][pos]
+        lg = ctx.forward(tok, pos)
+        tok = runtime.argmax(lg)
+    assert np.abs(lg - g["logits"][keep[23]]).max() <= TOL
+    with pytest.raises(runtime.L2Error):
+        ctx.prefill([1, 2, 3], 255)                    # runs past seq_len
+    with pytest.raises(runtime.L2Error):
+        ctx.prefill([1, 40000], 0)                     # token out of range
+    ctx.close()
