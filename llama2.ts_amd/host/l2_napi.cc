@@ -36,6 +36,7 @@ struct Api {
   decltype(&l2_set_option) set_option;
   decltype(&l2_load_checkpoint) load_checkpoint;
   decltype(&l2_get_header) get_header;
+  decltype(&l2_prefill) prefill;
 } api;
 
 std::string g_load_error;
@@ -55,7 +56,7 @@ bool load_library(const char* hint) {
   api.name = (decltype(api.name))dlsym(api.so, "l2_" #name);               \
   if (!api.name) { g_load_error = "missing symbol l2_" #name; dlclose(api.so); api.so = nullptr; return false; }
   BIND(abi_version) BIND(device_count) BIND(last_error) BIND(create) BIND(destroy) BIND(upload) BIND(synth_fill)
-  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(read_state) BIND(set_option) BIND(load_checkpoint) BIND(get_header)
+  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(read_state) BIND(set_option) BIND(load_checkpoint) BIND(get_header) BIND(prefill)
 #undef BIND
   if (api.abi_version() != L2_ABI_VERSION) { g_load_error = "ABI version mismatch"; dlclose(api.so); api.so = nullptr; return false; }
   return true;
@@ -249,6 +250,26 @@ napi_value Forward(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// prefill(handle, Int32Array tokens, pos0, Float32Array|null)   (prompt ingestion)
+napi_value Prefill(napi_env env, napi_callback_info info) {
+  ARGS(4)
+  l2_ctx* c;
+  int32_t pos0;
+  float* out;
+  size_t n;
+  if (!get_ctx(env, argv[0], &c) || !get_i32(env, argv[2], &pos0) || !get_f32_array(env, argv[3], &out, &n, true)) return nullptr;
+  napi_typedarray_type tt;
+  size_t len;
+  void* p;
+  napi_value ab;
+  size_t off;
+  if (napi_get_typedarray_info(env, argv[1], &tt, &len, &p, &ab, &off) != napi_ok || tt != napi_int32_array)
+    return throw_err(env, "expected Int32Array tokens");
+  int rc = api.prefill(c, (const int32_t*)p, (int)len, pos0, out);
+  if (rc) return throw_l2(env, rc);
+  return nullptr;
+}
+
 // logitsBuffer(handle, vocab_size) -> ArrayBuffer over the pinned host logits (zero copy RunState.logits)
 napi_value LogitsBuffer(napi_env env, napi_callback_info info) {
   ARGS(2)
@@ -317,7 +338,7 @@ napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"upload", Upload}, {"synthFill", SynthFill},
       {"forward", Forward}, {"logitsBuffer", LogitsBuffer}, {"decodeGreedy", DecodeGreedy}, {"readState", ReadState},
-      {"setOption", SetOption}, {"deviceCount", DeviceCount}, {"loadCheckpoint", LoadCheckpoint}};
+      {"setOption", SetOption}, {"deviceCount", DeviceCount}, {"loadCheckpoint", LoadCheckpoint}, {"prefill", Prefill}};
   for (auto& f : fns) {
     napi_value v;
     napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);

@@ -309,6 +309,18 @@ function main() {
   let num_prompt_tokens = 0;
   if (prompt != null) num_prompt_tokens = bpe_encode(prompt, vocab, vocab_scores, config.vocab_size, prompt_tokens);
 
+  // opt-in extra (SURVEY.md 8(f3)): feed the teacher-forced prompt positions in one batched call instead of one
+  // transformer() each (the reference ignores their logits anyway, llama2.ts:471-473)
+  let prefilled = 0;
+  if (process.env.L2_PREFILL == "1" && num_prompt_tokens > 1) {
+    const n = Math.min(num_prompt_tokens, steps);
+    const fed = new Int32Array(n);
+    fed[0] = 1;
+    for (let i = 1; i < n; i++) fed[i] = prompt_tokens[i - 1];
+    be.prefill(ctx, fed, 0, null);
+    prefilled = n;
+  }
+
   // opt-in extra (SURVEY.md 8(f1)): keep the greedy loop on the device, `chunk` tokens per call
   const deviceGreedy = process.env.L2_DEVICE_GREEDY == "1" && temperature == 0.0;
 
@@ -320,7 +332,7 @@ function main() {
       if (ahead.length == 0) ahead = Array.from(be.decodeGreedy(ctx, token, pos, Math.min(16, steps - pos)));
       next = /** @type {number} */ (ahead.shift());
     } else {
-      transformer(token, pos, config, state, weights, be);
+      if (pos >= prefilled) transformer(token, pos, config, state, weights, be);
       if (pos < num_prompt_tokens) {
         next = prompt_tokens[pos];                // teacher-forced prompt (llama2.ts:471-473)
       } else if (temperature == 0.0) {

@@ -76,3 +76,11 @@ def test_cli_native_loader_prints_the_same(workdir):
     rc, out, err = run_cli(workdir, meta["argv"], {"L2_NATIVE_LOADER": "1"})
     assert rc == 0, err
     assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
+
+
+@pytest.mark.parametrize("name", ["cli_prompt", "cli_topp"])
+def test_cli_batched_prefill_prints_the_same(workdir, name):
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    rc, out, err = run_cli(workdir, meta["argv"], {"L2_PREFILL": "1"})
+    assert rc == 0, err
+    assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
