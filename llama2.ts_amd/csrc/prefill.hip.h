@@ -71,34 +71,42 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
   const float* wrow3 = (MODE == MODE_W13) ? a.w1 + (size_t)(i0 + j) * n + 4 * kq : nullptr;
   const float* xrow = a.xin + (size_t)j * n + 4 * kq;       // token j as the A row
 
-  d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0};
-  constexpr int UN = 4;
-  for (int s0 = wave; s0 < nblk; s0 += NW * UN) {
+  // two independent accumulator chains per tile (even / odd k steps): a dependent MFMA cannot issue back to back
+  d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0}, acc3b = {0.0, 0.0, 0.0, 0.0};
+  constexpr int UN = (MODE == MODE_W13) ? 4 : 8;
+  // a wave takes PAIRS of adjacent 16-column blocks (one whole 128-byte line of every weight row per two loads),
+  // pairs round-robin over the NW waves
+  const int npair = (nblk + 1) >> 1;
+  for (int p0 = wave; p0 < npair; p0 += NW * (UN / 2)) {
     f4 wv[UN], xv[UN], w3[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int s = min(s0 + NW * u, nblk - 1);     // clamped (never predicated) loads; masked below
+      const int s = min(2 * (p0 + NW * (u >> 1)) + (u & 1), nblk - 1);     // clamped (never predicated) loads; masked below
       wv[u] = ldg_nt(wrow + 16 * s);
       if (MODE == MODE_W13) w3[u] = ldg_nt(wrow3 + 16 * s);
       xv[u] = *reinterpret_cast<const f4*>(xrow + 16 * s);
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (s0 + NW * u < nblk) {
+      if (2 * (p0 + NW * (u >> 1)) + (u & 1) < nblk) {
         const double x0 = xv[u].x, x1 = xv[u].y, x2 = xv[u].z, x3 = xv[u].w;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)wv[u].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)wv[u].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)wv[u].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)wv[u].w, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)wv[u].y, accb, 0, 0, 0);
         if (MODE == MODE_W13) {
           acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)w3[u].x, acc3, 0, 0, 0);
-          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)w3[u].y, acc3, 0, 0, 0);
+          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)w3[u].y, acc3b, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)wv[u].z, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)wv[u].w, accb, 0, 0, 0);
+        if (MODE == MODE_W13) {
           acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)w3[u].z, acc3, 0, 0, 0);
-          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)w3[u].w, acc3, 0, 0, 0);
+          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)w3[u].w, acc3b, 0, 0, 0);
         }
       }
     }
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r] += accb[r]; acc3[r] += acc3b[r]; }
   // split-K partials of waves 1..NW-1 -> wave 0, added in wave order
   if (wave > 0) {
 #pragma unroll
