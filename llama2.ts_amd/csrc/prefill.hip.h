@@ -73,37 +73,54 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
 
   // two independent accumulator chains per tile (even / odd k steps): a dependent MFMA cannot issue back to back
   d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0}, acc3b = {0.0, 0.0, 0.0, 0.0};
-  constexpr int UN = (MODE == MODE_W13) ? 4 : 8;
-  // a wave takes PAIRS of adjacent 16-column blocks (one whole 128-byte line of every weight row per two loads),
-  // pairs round-robin over the NW waves
-  const int npair = (nblk + 1) >> 1;
-  for (int p0 = wave; p0 < npair; p0 += NW * (UN / 2)) {
-    f4 wv[UN], xv[UN], w3[UN];
+  constexpr int UN = 4;                              // 16-column blocks per batch (two register sets of them)
+  // a wave takes UN ADJACENT 16-column blocks per batch (256 contiguous bytes of every weight row: DRAM pages see
+  // runs, not 64-byte pieces), batches round-robin over the NW waves; batch b+1 loads while batch b is on the matrix pipe
+  const int npair = (nblk + UN - 1) / UN;            // batches of UN blocks
+  struct Batch { f4 wv[UN], xv[UN], w3[UN]; };
+  auto blk = [&](int p0, int u) { return p0 * UN + u; };
+  auto load = [&](Batch& b, int p0) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int s = min(2 * (p0 + NW * (u >> 1)) + (u & 1), nblk - 1);     // clamped (never predicated) loads; masked below
-      wv[u] = ldg_nt(wrow + 16 * s);
-      if (MODE == MODE_W13) w3[u] = ldg_nt(wrow3 + 16 * s);
-      xv[u] = *reinterpret_cast<const f4*>(xrow + 16 * s);
+      const int sb = min(blk(p0, u), nblk - 1);     // clamped (never predicated) loads; masked in mma()
+      b.wv[u] = ldg_nt(wrow + 16 * sb);
+      if (MODE == MODE_W13) b.w3[u] = ldg_nt(wrow3 + 16 * sb);
+      b.xv[u] = *reinterpret_cast<const f4*>(xrow + 16 * sb);
     }
+  };
+  auto mma = [&](const Batch& b, int p0) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (2 * (p0 + NW * (u >> 1)) + (u & 1) < nblk) {
-        const double x0 = xv[u].x, x1 = xv[u].y, x2 = xv[u].z, x3 = xv[u].w;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)wv[u].x, acc, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)wv[u].y, accb, 0, 0, 0);
+      if (blk(p0, u) < nblk) {
+        const double x0 = b.xv[u].x, x1 = b.xv[u].y, x2 = b.xv[u].z, x3 = b.xv[u].w;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)b.wv[u].x, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)b.wv[u].y, accb, 0, 0, 0);
         if (MODE == MODE_W13) {
-          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)w3[u].x, acc3, 0, 0, 0);
-          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)w3[u].y, acc3b, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)b.w3[u].x, acc3, 0, 0, 0);
+          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)b.w3[u].y, acc3b, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)wv[u].z, acc, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)wv[u].w, accb, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)b.wv[u].z, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)b.wv[u].w, accb, 0, 0, 0);
         if (MODE == MODE_W13) {
-          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)w3[u].z, acc3, 0, 0, 0);
-          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)w3[u].w, acc3b, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)b.w3[u].z, acc3, 0, 0, 0);
+          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)b.w3[u].w, acc3b, 0, 0, 0);
         }
       }
     }
+  };
+  constexpr int PSTEP = NW;                          // batches advance by the wave count
+  Batch A, B;
+  int p0 = wave;
+  if (p0 < npair) load(A, p0);
+  while (p0 < npair) {
+    const int p1 = p0 + PSTEP;
+    load(B, p1 < npair ? p1 : p0);                   // unconditional (clamped) prefetch keeps the waits counted
+    mma(A, p0);
+    if (p1 >= npair) break;
+    const int p2 = p1 + PSTEP;
+    load(A, p2 < npair ? p2 : p1);
+    mma(B, p1);
+    p0 = p2;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) { acc[r] += accb[r]; acc3[r] += acc3b[r]; }
