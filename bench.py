@@ -89,7 +89,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="llama2_7b", choices=sorted(configs.CONFIGS))
     ap.add_argument("--seed", type=int, default=configs.DEFAULT_SEED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
