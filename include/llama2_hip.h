@@ -140,7 +140,8 @@ int l2_get_option(l2_ctx* ctx, int key, int* value);
 int l2_timer_start(l2_ctx* ctx);
 int l2_timer_stop(l2_ctx* ctx, float* elapsed_ms);   /* synchronises */
 /* Launch only the dominant kernel (the weight-streaming GEMV of one matrix kind of one layer)
- * `iters` times back to back and return the average device time per launch. */
+ * `iters` times back to back and return the average device time per launch.  Scratch use of the RunState
+ * buffers: the activations and cache row `pos` are clobbered, call it outside a decode. */
 int l2_bench_gemv(l2_ctx* ctx, int tensor_kind, int layer, int iters, float* avg_ms);
 /* `steps` forwards (greedy feed, device-resident) timed with events: total device ms. */
 int l2_bench_decode(l2_ctx* ctx, int first_token, int pos0, int steps, float* total_ms);
