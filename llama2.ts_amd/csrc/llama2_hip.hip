@@ -116,6 +116,9 @@ struct l2_ctx {
   int* h_err = nullptr;             // pinned + mapped: set by a kernel whose bounded wait gave up
   int* h_err_dev = nullptr;
   int opt_fuse = 0;                 // L2_FUSE_ATTN: attention inside the QKV launch (experimental)
+  std::vector<hipEvent_t> probe;    // in-situ probe: event pairs around every launch of the dominant kernel
+  size_t probe_used = 0;
+  bool probe_on = false;
   // chain launch: one kernel per token (kernels.hip.h chain_kernel)
   int opt_chain = 0;
   int chain_cap = 768;              // workgroups per GEMV phase
@@ -209,6 +212,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->partial) hipFree(c->partial);
   if (c->attn_part) hipFree(c->attn_part);
   if (c->attn_counter) hipFree(c->attn_counter);
+  for (hipEvent_t e : c->probe) hipEventDestroy(e);
   if (c->head_done) hipFree(c->head_done);
   if (c->chain_ctr) hipFree(c->chain_ctr);
   if (c->chain_act) hipFree(c->chain_act);
@@ -979,7 +983,9 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
       LCHK(hipGetLastError());
     }
     a = w13_args(c, l);
+    if (c->probe_on && c->probe_used + 2 <= c->probe.size()) LCHK(hipEventRecord(c->probe[c->probe_used++], st));
     LCHK(launch_phase<MODE_W13>(c, a, st));
+    if (c->probe_on && (c->probe_used & 1)) LCHK(hipEventRecord(c->probe[c->probe_used++], st));
     a = w2_args(c, l);
     LCHK(launch_phase<MODE_W2>(c, a, st));
     if (c->tp_path) {
@@ -1204,6 +1210,33 @@ extern "C" int l2_decode_greedy(l2_ctx* c, int first_token, int pos0, int steps,
 extern "C" int l2_bench_decode(l2_ctx* c, int first_token, int pos0, int steps, float* total_ms) {
   if (!total_ms) return fail(L2_E_ARG, "null total_ms");
   return run_greedy(c, first_token, pos0, steps, true, total_ms);
+}
+
+// The dominant kernel (rmsnorm + w1/w3 GEMV + SwiGLU) timed IN SITU: `steps` greedy decode steps launched eagerly
+// with a HIP event pair around every one of its launches on the library's stream; mean duration in microseconds.
+extern "C" int l2_bench_dominant_in_situ(l2_ctx* c, int first_token, int pos0, int steps, float* avg_us, int* launches) {
+  if (!c || !avg_us) return fail(L2_E_ARG, "null argument");
+  if (steps <= 0 || pos0 < 0 || pos0 + steps > c->S) return fail(L2_E_ARG, "bad step range");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t need = (size_t)2 * c->L * steps;
+  while (c->probe.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->probe.push_back(e); }
+  const int saved_graph = c->opt_graph, saved_chain = c->opt_chain;
+  c->opt_graph = 0; c->opt_chain = 0;
+  c->probe_used = 0; c->probe_on = true;
+  int rc = run_greedy(c, first_token, pos0, steps, false, nullptr);
+  c->probe_on = false; c->opt_graph = saved_graph; c->opt_chain = saved_chain;
+  if (rc) return rc;
+  double total = 0.0;
+  size_t n = 0;
+  for (size_t i = 0; i + 1 < c->probe_used; i += 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->probe[i], c->probe[i + 1]));
+    total += ms; ++n;
+  }
+  if (!n) return fail(L2_E_STATE, "no launches were probed");
+  *avg_us = (float)(1e3 * total / (double)n);
+  if (launches) *launches = (int)n;
+  return L2_OK;
 }
 
 extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t n_floats) {

@@ -31,7 +31,7 @@ OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_MEGAKERNEL = 1, 2, 3
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
                "l2_decode_greedy", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
-               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill"]
+               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ"]
 
 
 class L2Error(RuntimeError):
@@ -77,6 +77,7 @@ def lib():
     L.l2_load_checkpoint.argtypes = [C.c_char_p, i32, i32, i32, vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.l2_get_header.argtypes = [vp, vp]
     L.l2_prefill.argtypes = [vp, vp, i32, i32, vp]
+    L.l2_bench_dominant_in_situ.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(i32)]
     for name in ABI_SYMBOLS:   # fail at load time, not at first use, if the .so is stale
         getattr(L, name)
     _lib = L
@@ -214,6 +215,11 @@ class Context:
         ms = C.c_float()
         _check(lib().l2_bench_gemv(self._h, kind, layer, iters, C.byref(ms)))
         return ms.value
+
+    def bench_dominant_in_situ(self, first_token, pos0, steps):
+        us, n = C.c_float(), C.c_int()
+        _check(lib().l2_bench_dominant_in_situ(self._h, first_token, pos0, steps, C.byref(us), C.byref(n)))
+        return us.value, n.value
 
     def bench_decode(self, first_token, pos0, steps):
         ms = C.c_float()
