@@ -1098,7 +1098,12 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
     a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
     a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
-    hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
+    { const int nw_ = env_int("L2_PF_NW_QKV", 4);
+      if (nw_ == 1) hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 1>), dim3(a.rows / 16), dim3(64), 0, st, a);
+      else if (nw_ == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 2>), dim3(a.rows / 16), dim3(128), 0, st, a);
+      else if (nw_ == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 4>), dim3(a.rows / 16), dim3(256), 0, st, a);
+      else if (nw_ == 8) hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a); }
     LCHK(hipGetLastError());
     // attention, one workgroup per (head, query) (llama2.ts:244-267)
     {
@@ -1113,15 +1118,30 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     }
     // wo + residual (llama2.ts:270-273)
     a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
-    hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a);
+    { const int nw_ = env_int("L2_PF_NW_WO", 4);
+      if (nw_ == 1) hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 1>), dim3(a.rows / 16), dim3(64), 0, st, a);
+      else if (nw_ == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 2>), dim3(a.rows / 16), dim3(128), 0, st, a);
+      else if (nw_ == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 4>), dim3(a.rows / 16), dim3(256), 0, st, a);
+      else if (nw_ == 8) hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a); }
     // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
     hipLaunchKernelGGL(pf_norm_kernel, dim3(PF_T), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
     a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
     a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
-    hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
+    { const int nw_ = env_int("L2_PF_NW_W13", 4);
+      if (nw_ == 1) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 1>), dim3(a.rows / 16), dim3(64), 0, st, a);
+      else if (nw_ == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 2>), dim3(a.rows / 16), dim3(128), 0, st, a);
+      else if (nw_ == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 4>), dim3(a.rows / 16), dim3(256), 0, st, a);
+      else if (nw_ == 8) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a); }
     // w2 + residual (llama2.ts:292-295)
     a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
-    hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a);
+    { const int nw_ = env_int("L2_PF_NW_W2", 4);
+      if (nw_ == 1) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 1>), dim3(a.rows / 16), dim3(64), 0, st, a);
+      else if (nw_ == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 2>), dim3(a.rows / 16), dim3(128), 0, st, a);
+      else if (nw_ == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 4>), dim3(a.rows / 16), dim3(256), 0, st, a);
+      else if (nw_ == 8) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a); }
     LCHK(hipGetLastError());
   }
   return L2_OK;

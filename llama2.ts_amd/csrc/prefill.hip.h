@@ -14,7 +14,7 @@
 // weight row per 16-column block; the four MFMAs of a block take element 0..3 of both, so A and B see the same
 // (permuted) k order.  The NW waves of a workgroup take the 16-column blocks round-robin (split K) and their
 // partial tiles are added in a fixed order through LDS.  First version: a 16-token chunk of the 7B shape takes
-// 9.8 ms (7.9x faster than sixteen decode steps, about 2x one decode step; tools/prefill_bench.py).
+// 8.6 ms (9x faster than sixteen decode steps, about 1.8x one decode step; tools/prefill_bench.py).
 #pragma once
 #include "kernels.hip.h"
 
@@ -55,11 +55,11 @@ __global__ void __launch_bounds__(256) pf_norm_kernel(float* xn, const float* x,
   for (int j = tid; j < dim; j += 256) xn[(size_t)t * dim + j] = (float)((double)w[j] * (ss * (double)xr[j]));
 }
 
-// NW waves per workgroup share one 16-row tile and split K NW ways (matrices with few tiles -- wo, w2 -- need the
-// deeper split to put several waves on every SIMD).
+// NW waves per workgroup share one 16-row tile and split K NW ways.  Measured (7B shapes, L2_PF_NW_*): 4 waves per
+// tile is best everywhere (8.6 ms per 16-token chunk; 1-2 waves starve wo / w2, 8-16 waves lose to the combine).
 template <int MODE, int NW>
 __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
-  __shared__ double part[(MODE == MODE_W13) ? 2 : 1][NW - 1][4][64];   // [tile (W13 has two)][waves 1..NW-1][reg][lane]
+  __shared__ double part[(MODE == MODE_W13) ? 2 : 1][NW > 1 ? NW - 1 : 1][4][64];   // [tile (W13 has two)][waves 1..NW-1][reg][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = a.n, nblk = n >> 4;                 // 16-column blocks
   const int row0 = blockIdx.x * 16;                 // output rows of this tile
