@@ -47,12 +47,27 @@ __global__ void __launch_bounds__(256) pf_norm_kernel(float* xn, const float* x,
   __shared__ double red[8];
   const int t = blockIdx.x, tid = threadIdx.x;
   const float* xr = x + (size_t)t * dim;
+  constexpr int MAXE = 16;                       // the row stays in registers up to dim = 4096; longer rows re-read the tail
+  float v[MAXE], g[MAXE];
   double ss = 0.0;
-  for (int j = tid; j < dim; j += 256) { const double v = xr[j]; ss += v * v; }
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int j = tid + 256 * e;
+    v[e] = (j < dim) ? xr[j] : 0.0f;
+    g[e] = (j < dim) ? w[j] : 0.0f;
+  }
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) ss += (double)v[e] * (double)v[e];
+  for (int j = tid + 256 * MAXE; j < dim; j += 256) { const double u = xr[j]; ss += u * u; }
   ss = block_sum(ss, red, tid, 256);
   ss /= (double)dim;
   ss = 1.0 / sqrt(1e-5 + ss);
-  for (int j = tid; j < dim; j += 256) xn[(size_t)t * dim + j] = (float)((double)w[j] * (ss * (double)xr[j]));
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int j = tid + 256 * e;
+    if (j < dim) xn[(size_t)t * dim + j] = (float)((double)g[e] * (ss * (double)v[e]));
+  }
+  for (int j = tid + 256 * MAXE; j < dim; j += 256) xn[(size_t)t * dim + j] = (float)((double)w[j] * (ss * (double)xr[j]));
 }
 
 // NW waves per workgroup share one 16-row tile and split K NW ways.  Measured (7B shapes, L2_PF_NW_*): 4 waves per
