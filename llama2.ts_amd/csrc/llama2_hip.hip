@@ -17,6 +17,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -87,6 +92,43 @@ static int rccl_bind() {
     if (r_ != 0) return fail(L2_E_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
   } while (0)
 
+// ---- Loopback communicator (L2_TP_LOOPBACK=1): a TEST HOOK, not a product path ---------------------
+// The driver's multi-GPU node is the only place RCCL runs with more than one rank, and it is not reachable from
+// the 1-GPU development boxes.  With L2_TP_LOOPBACK=1 the G ranks of a tensor-parallel group are G contexts of
+// ONE process on ONE device, each driven by its own host thread (tests/test_tp_gpu.py); the two collectives are
+// then plain device work between host-side thread barriers: every rank sums the G published fp64 partial vectors
+// in rank order (all-reduce) or copies the G logits slices (all-gather).  Everything else -- shard slicing,
+// fp64 partial GEMVs, the single rounding in tp_residual_kernel, the greedy loop on gathered logits -- is the
+// code the RCCL path runs.  Groups are keyed by the 128-byte id the caller passes to l2_create_tp.
+struct LoopGroup {
+  int G = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned gen = 0;
+  bool broken = false;
+  const void* ptrs[16] = {};
+  bool wait() {   // generation barrier; false after 60 s (a rank died: fail instead of hanging the box)
+    std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
+    const unsigned g = gen;
+    if (++arrived == G) { arrived = 0; ++gen; cv.notify_all(); return true; }
+    if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g || broken; })) { broken = true; cv.notify_all(); return false; }
+    return !broken;
+  }
+};
+static std::mutex g_loop_mu;
+static std::map<std::string, std::shared_ptr<LoopGroup>> g_loop_groups;
+
+struct LoopPtrs { const double* p[16]; };
+__global__ void loop_sum_kernel(double* out, const LoopPtrs in, int G, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = in.p[0][i];
+  for (int r = 1; r < G; ++r) s += in.p[r][i];
+  out[i] = s;
+}
+
 // ------------------------------------------------------------------------------------------------
 struct l2_ctx {
   int32_t hdr[7];
@@ -98,6 +140,8 @@ struct l2_ctx {
   int G = 1, rank = 0;
   int d_loc, h_loc, H_loc, V_loc;
   nccl_comm comm = nullptr;
+  std::shared_ptr<LoopGroup> loop;   // L2_TP_LOOPBACK test hook (see LoopGroup)
+  double* loop_tmp = nullptr;
   bool tp_path = false;   // WO/W2 write fp64 partials + all-reduce; logits all-gathered (G > 1, or forced for tests)
 
   float* w[L2_T_COUNT] = {};
@@ -204,6 +248,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   destroy_graphs(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  if (c->loop_tmp) hipFree(c->loop_tmp);
   for (int k = 0; k < L2_T_COUNT; ++k)
     if (c->w[k] && !(k == L2_T_WCLS && c->shared)) hipFree(c->w[k]);  // shared wcls aliases the embedding table
   float* bufs[] = {c->x, c->xb, c->xb2, c->hb, c->hb2, c->q, c->k, c->v, c->att, c->logits, c->kc, c->vc, c->xn};
@@ -338,6 +383,14 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   if (G > 1 && env_int("L2_TP_NO_COMM", 0)) {
     // shard-layout tests on a single GPU: the slices are real, the communicator is absent and every
     // forward on this context fails with L2_E_COMM
+  } else if (G > 1 && env_int("L2_TP_LOOPBACK", 0)) {
+    if (G > 16 || !nccl_id) { l2_destroy(c); return fail(L2_E_ARG, "loopback groups need an id and at most 16 ranks"); }
+    if (hipMalloc(&c->loop_tmp, (size_t)d * 8) != hipSuccess) { l2_destroy(c); return fail(L2_E_HIP, "hipMalloc failed"); }
+    std::lock_guard<std::mutex> lk(g_loop_mu);
+    auto& grp = g_loop_groups[std::string((const char*)nccl_id, 128)];
+    if (!grp) { grp = std::make_shared<LoopGroup>(); grp->G = G; }
+    if (grp->G != G) { l2_destroy(c); return fail(L2_E_ARG, "loopback group size mismatch"); }
+    c->loop = grp;
   } else if (c->tp_path) {
     int rc = rccl_bind();
     if (rc) { l2_destroy(c); return rc; }
@@ -965,6 +1018,35 @@ static int enqueue_chain(l2_ctx* c, hipStream_t st, bool to_host, bool greedy) {
 }
 
 // Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
+// The two collectives of the tensor-parallel step: RCCL, or the loopback test hook.
+static int tp_all_reduce(l2_ctx* c, hipStream_t st) {
+  if (!c->loop) { NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st)); return L2_OK; }
+  LoopGroup& g = *c->loop;
+  HIPCHK(hipStreamSynchronize(st));
+  { std::lock_guard<std::mutex> lk(g.mu); g.ptrs[c->rank] = c->partial; }
+  if (!g.wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");
+  LoopPtrs in;
+  for (int r = 0; r < g.G; ++r) in.p[r] = (const double*)g.ptrs[r];
+  hipLaunchKernelGGL(loop_sum_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->loop_tmp, in, g.G, c->d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  if (!g.wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");   // every rank has read every partial
+  HIPCHK(hipMemcpyAsync(c->partial, c->loop_tmp, (size_t)c->d * 8, hipMemcpyDeviceToDevice, st));
+  return L2_OK;
+}
+static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
+  if (!c->loop) { NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st)); return L2_OK; }
+  LoopGroup& g = *c->loop;
+  HIPCHK(hipStreamSynchronize(st));
+  { std::lock_guard<std::mutex> lk(g.mu); g.ptrs[c->rank] = c->logits_loc; }
+  if (!g.wait()) return fail(L2_E_COMM, "loopback all-gather: a rank never arrived");
+  for (int r = 0; r < g.G; ++r)
+    HIPCHK(hipMemcpyAsync(c->logits + (size_t)r * c->V_loc, g.ptrs[r], (size_t)c->V_loc * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (!g.wait()) return fail(L2_E_COMM, "loopback all-gather: a rank never arrived");
+  return L2_OK;
+}
+
 static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
   if (can_chain(c)) return enqueue_chain(c, st, to_host, false);
   for (int l = 0; l < c->L; ++l) {
@@ -978,7 +1060,7 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
     a = wo_args(c, l);
     LCHK(launch_phase<MODE_WO>(c, a, st));
     if (c->tp_path) {
-      NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st));
+      { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->partial, c->xb2, c->tokpos, c->d);
       LCHK(hipGetLastError());
     }
@@ -989,14 +1071,14 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
     a = w2_args(c, l);
     LCHK(launch_phase<MODE_W2>(c, a, st));
     if (c->tp_path) {
-      NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st));
+      { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, nullptr, c->partial, nullptr, c->tokpos, c->d);
       LCHK(hipGetLastError());
     }
   }
   PhaseArgs a = cls_args(c, to_host);
   LCHK(launch_phase<MODE_CLS>(c, a, st));
-  if (c->tp_path) NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st));
+  if (c->tp_path) { const int rc_ = tp_all_gather_logits(c, st); if (rc_) return rc_; }
   return L2_OK;
 }
 
@@ -1004,7 +1086,7 @@ static int enqueue_forward(l2_ctx* c, hipStream_t st) { return enqueue_forward_i
 static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
 
 static int ensure_ready(l2_ctx* c) {
-  if (c->tp_path && !c->comm) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
+  if (c->tp_path && !c->comm && !c->loop) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
   for (int k = 0; k < L2_T_COUNT; ++k) {
     if (k == L2_T_WCLS && c->shared) continue;
     for (size_t l = 0; l < c->uploaded[k].size(); ++l)

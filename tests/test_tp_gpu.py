@@ -1,7 +1,8 @@
 """Tensor-parallel shard layout on one GPU (no communicator): every rank's slices, whether generated on the
 device or cut out of full host arrays by l2_upload, must equal llama2_ts_amd.tp.tensor_slice of the oracle's
-tensors.  The collectives themselves need >1 GPU and are exercised by bench.py --gpus N on the driver's node;
-their arithmetic is covered over gloo in test_tp_gloo.py."""
+tensors.  RCCL with more than one rank needs >1 GPU (bench.py --gpus N on the driver's node); here the RCCL calls
+run with a 1-rank communicator, and the complete G-rank step runs through the library's loopback test hook
+(G contexts, G host threads, one device).  The collectives' arithmetic is also covered over gloo in test_tp_gloo.py."""
 import os
 
 import numpy as np
@@ -70,3 +71,64 @@ def test_rccl_path_with_a_one_rank_communicator():
         ctx.close()
     finally:
         del os.environ["L2_TP_FORCE_COMM"]
+
+
+def _run_group(name, G, n_forward, n_greedy, exact=False):
+    """G ranks of one tensor-parallel group as G host threads on one device (L2_TP_LOOPBACK test hook in
+    llama2_hip.hip: the collectives become device sums/copies between thread barriers; everything else is the
+    code the RCCL path runs).  Returns per-rank (logits[n_forward][V], greedy tokens)."""
+    import json
+    import threading
+    here = os.path.dirname(__file__)
+    meta = json.load(open(os.path.join(here, "golden", name + ".json")))
+    gid = bytes([G, len(name)] + [7] * 126)
+    out, errs = [None] * G, [None] * G
+
+    def rank_main(r):
+        try:
+            ctx = runtime.Context(meta["header"], tp_rank=r, tp_size=G, nccl_id=gid)
+            ctx.synth_fill(meta["seed"])
+            if exact:
+                ctx.set_option(1, 1)
+            logits = [np.array(ctx.forward(tok, pos), copy=True) for pos, tok in enumerate(meta["tokens_fed"][:n_forward])]
+            toks = ctx.decode_greedy(meta["tokens_fed"][0], 0, n_greedy).tolist() if n_greedy else []
+            out[r] = (np.stack(logits), toks)
+            ctx.close()
+        except BaseException as e:   # surfaced by the main thread
+            errs[r] = e
+
+    os.environ["L2_TP_LOOPBACK"] = "1"
+    try:
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(180)
+        assert not any(t.is_alive() for t in threads), "a rank hung"
+    finally:
+        del os.environ["L2_TP_LOOPBACK"]
+    for e in errs:
+        if e is not None:
+            raise e
+    return meta, out
+
+
+@pytest.mark.parametrize("name,G,steps", [("tiny", 2, 24), ("tiny", 4, 24), ("stories15M", 2, 16),
+                                          ("llama2_7b_L2", 4, 6), ("llama2_7b_L2", 8, 6)])
+def test_tensor_parallel_group_matches_reference(name, G, steps):
+    """The whole tensor-parallel step with G > 1 ranks -- row / column slices, fp64 partials of wo and w2 summed
+    across ranks and rounded once, logits gathered, greedy loop on the gathered logits -- against the goldens of
+    the TRUE reference.  Every rank must hold the same full logits."""
+    meta, out = _run_group(name, G, steps, steps)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    for r in range(G):
+        logits, toks = out[r]
+        kept = meta.get("logit_positions") or list(range(len(g["logits"])))    # big vocabularies keep a few positions
+        for row, pos in enumerate(kept):
+            if pos < steps:
+                err = float(np.abs(logits[pos] - g["logits"][row]).max())
+                assert err <= 1e-4, (r, pos, err)
+        assert [int(runtime.argmax(row)) for row in logits] == meta["argmax"][:steps]
+        assert np.array_equal(logits, out[0][0])          # identical on every rank
+        if meta["tokens_fed"][:steps] == [1] + meta["argmax"][:steps - 1]:   # the golden run was greedy from BOS
+            assert toks == meta["argmax"][:steps]
