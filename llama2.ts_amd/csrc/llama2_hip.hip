@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -397,7 +398,14 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     nccl_uid uid;
     if (nccl_id) memcpy(&uid, nccl_id, sizeof(uid));
     else if (g_rccl.GetUniqueId(&uid) != 0) { l2_destroy(c); return fail(L2_E_COMM, "ncclGetUniqueId failed"); }
+    // RCCL 2.26 prints a version banner to stdout at init; the host's stdout is the generated text
+    // (llama2.ts:500) or bench.py's one JSON line, so the banner is sent to stderr instead
+    fflush(stdout);
+    const int saved_out = dup(1);
+    if (saved_out >= 0) dup2(2, 1);
     int r = g_rccl.CommInitRank(&c->comm, G, uid, rank);
+    fflush(stdout);
+    if (saved_out >= 0) { dup2(saved_out, 1); close(saved_out); }
     if (r != 0) { l2_destroy(c); return fail(L2_E_COMM, "ncclCommInitRank failed: %d", r); }
   }
   *out = c;
