@@ -324,6 +324,77 @@ int orc_argmax(const float* v, int n) { /* llama2.ts:364-366 */
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Samplers (llama2.ts:348-394, 476-493)                                                       */
+
+uint32_t orc_random_u32(uint64_t* rng) { /* llama2.ts:349-354; the BigInt product is not masked before >> 32, bits 32..63 are the same */
+  uint64_t s = *rng;
+  s ^= s >> 12;
+  s ^= s << 25;
+  s ^= s >> 27;
+  *rng = s;
+  return (uint32_t)((s * 0x2545F4914F6CDD1Dull) >> 32);
+}
+
+float orc_random_f32(uint64_t* rng) { /* llama2.ts:357-360: two fp64 divisions (exact), ONE rounding at the Float32Array store */
+  const double v = ((double)orc_random_u32(rng) / 256.0) / 16777216.0;
+  return (float)v;
+}
+
+int orc_sample(const float* probs, int n, uint64_t* rng) { /* llama2.ts:368-376 */
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) sum = sum + (double)probs[i];
+  const double rand_value = (double)orc_random_f32(rng) * sum;
+  double cum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    cum += (double)probs[i];
+    if (rand_value < cum) return i;
+  }
+  return 0;
+}
+
+typedef struct { int index; float prob; } orc_probindex;
+static void orc_merge_sort_desc(orc_probindex* a, orc_probindex* tmp, int n) { /* stable, like V8's TimSort (Array.prototype.sort, Node >= 11) */
+  if (n < 2) return;
+  const int h = n / 2;
+  orc_merge_sort_desc(a, tmp, h);
+  orc_merge_sort_desc(a + h, tmp, n - h);
+  int i = 0, j = h, k = 0;
+  while (i < h && j < n) tmp[k++] = (a[j].prob > a[i].prob) ? a[j++] : a[i++];   /* comparator b.prob - a.prob: equal keeps the left one first */
+  while (i < h) tmp[k++] = a[i++];
+  while (j < n) tmp[k++] = a[j++];
+  memcpy(a, tmp, (size_t)n * sizeof(*a));
+}
+
+int orc_sample_topp(const float* probs, int n, double topp, uint64_t* rng) { /* llama2.ts:378-394 */
+  orc_probindex* pi = (orc_probindex*)malloc((size_t)n * sizeof(*pi) * 2);
+  for (int i = 0; i < n; ++i) { pi[i].index = i; pi[i].prob = probs[i]; }
+  orc_merge_sort_desc(pi, pi + n, n);
+  double cum = 0.0;
+  int last = 0;
+  for (int i = 0; i < n; ++i) {
+    cum += (double)pi[i].prob;
+    if (cum > topp) { last = i; break; }
+  }
+  const double rand_value = (double)orc_random_f32(rng) * cum;
+  cum = 0.0;
+  int out = 0;
+  for (int i = 0; i < last; ++i) {   /* i < lastIdx: the element that crossed topp is never returned (:390) */
+    cum += (double)pi[i].prob;
+    if (rand_value < cum) { out = pi[i].index; break; }
+  }
+  free(pi);
+  return out;                         /* fall-through returns id 0 (:393) */
+}
+
+int orc_next_token(float* logits, int n, double temperature, double topp, uint64_t* rng) { /* llama2.ts:476-493 */
+  if (temperature == 0.0) return orc_argmax(logits, n);
+  for (int q = 0; q < n; ++q) logits[q] = (float)((double)logits[q] / temperature);
+  orc_softmax(logits, n);
+  if (topp <= 0 || topp >= 1) return orc_sample(logits, n, rng);
+  return orc_sample_topp(logits, n, topp, rng);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Forward                                                                                     */
 
 static void rope_and_store(orc_model* m, int l, int pos) {

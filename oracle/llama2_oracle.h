@@ -93,6 +93,17 @@ void orc_forward(orc_model* m, int token, int pos, float* logits_out);
 /* argmax (llama2.ts:364-366): first maximum, strict '>'. */
 int orc_argmax(const float* v, int n);
 
+/* Samplers downstream of the path.  `rng` is the 64-bit xorshift* state the reference keeps in
+ * the BigInt `rng_seed` (llama2.ts:348-355), non-zero. */
+uint32_t orc_random_u32(uint64_t* rng);                                            /* :349-354 */
+float orc_random_f32(uint64_t* rng);                                               /* :357-360 (rounds, so 1.0f is possible) */
+int orc_sample(const float* probs, int n, uint64_t* rng);                          /* :368-376 */
+int orc_sample_topp(const float* probs, int n, double topp, uint64_t* rng);        /* :378-394 (stable sort, never returns element lastIdx) */
+/* The branch at llama2.ts:476-493: greedy when temperature == 0, else logits /= temperature (in place, fp32
+ * stores), softmax in place, then sample or sample_topp (topp <= 0 or >= 1: plain sample).  Mutates `logits`
+ * exactly as the reference mutates state.logits. */
+int orc_next_token(float* logits, int n, double temperature, double topp, uint64_t* rng);
+
 /* Building blocks, exported so kernels can be checked one at a time. */
 void orc_rmsnorm(float* o, const float* x, const float* w, int size);             /* :172-179 */
 void orc_softmax(float* x, int size);                                               /* :181-194 */

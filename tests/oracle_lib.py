@@ -49,6 +49,16 @@ def lib():
         L.orc_forward_tp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_argmax.restype = C.c_int
         L.orc_argmax.argtypes = [C.c_void_p, C.c_int]
+        L.orc_random_u32.restype = C.c_uint32
+        L.orc_random_u32.argtypes = [C.POINTER(C.c_uint64)]
+        L.orc_random_f32.restype = C.c_float
+        L.orc_random_f32.argtypes = [C.POINTER(C.c_uint64)]
+        L.orc_sample.restype = C.c_int
+        L.orc_sample.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        L.orc_sample_topp.restype = C.c_int
+        L.orc_sample_topp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_uint64)]
+        L.orc_next_token.restype = C.c_int
+        L.orc_next_token.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_uint64)]
         L.orc_tensor_count.restype = C.c_uint64
         L.orc_tensor_count.argtypes = [C.c_void_p, C.c_int]
         L.orc_tensor_offset.restype = C.c_uint64
@@ -132,6 +142,26 @@ class Oracle:
         toks = np.zeros(steps, dtype=np.int32)
         sec = lib().orc_time_forward(self._m, 0, steps, toks.ctypes.data)
         return sec, toks
+
+
+class Rng:
+    """The reference's BigInt xorshift* state (llama2.ts:348-355) as a uint64."""
+
+    def __init__(self, seed):
+        self.state = C.c_uint64(int(seed))
+
+    def u32(self):
+        return lib().orc_random_u32(C.byref(self.state))
+
+    def f32(self):
+        return lib().orc_random_f32(C.byref(self.state))
+
+
+def next_token(logits, temperature, topp, rng):
+    """llama2.ts:476-493 on a COPY of `logits` (the reference mutates state.logits); returns (token, probabilities)."""
+    v = np.array(logits, dtype=np.float32, copy=True)
+    tok = lib().orc_next_token(v.ctypes.data, v.size, float(temperature), float(topp), C.byref(rng.state))
+    return tok, v
 
 
 def argmax(v):

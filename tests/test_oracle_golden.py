@@ -88,3 +88,41 @@ def test_tp_restatement_matches_single_rank():
         b = o2.forward_tp(tok, pos, 2)
         assert O.argmax(a) == O.argmax(b)
         assert np.abs(a - b).max() <= 1e-6
+
+
+N_PROMPT = {"cli_temp": 0, "cli_topp": 4}   # "once" -> 4 single-character ids with the synthetic tokenizer (tokens_fed[1:5])
+
+
+@pytest.mark.parametrize("name", ["cli_temp", "cli_topp"])
+def test_sampler_restatement_reproduces_the_reference_run(name):
+    """temperature / top-p sampling + the xorshift* RNG (llama2.ts:348-394, 476-493).  The TRUE
+    reference was run with -t/-p/-s as recorded in the fixture; feeding its logits through the oracle's sampler with
+    the same seed must pick the same token at every sampled position."""
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    argv = dict(zip(meta["argv"][::2], meta["argv"][1::2]))
+    temperature, topp, seed = float(argv.get("-t", 1.0)), float(argv.get("-p", 1.0)), int(argv["-s"])
+    o = O.Oracle(meta["header"], meta["seed"])
+    rng = O.Rng(seed)
+    fed = meta["tokens_fed"]
+    for pos, tok in enumerate(fed[:-1]):
+        lg = o.forward(tok, pos)
+        assert hashlib.sha256(lg.tobytes()).hexdigest() == meta["logits_sha256"][pos]
+        if pos < N_PROMPT[name]:
+            continue                       # teacher-forced prompt position: logits ignored, no RNG draw (llama2.ts:471-473)
+        nxt, _ = O.next_token(lg, temperature, topp, rng)
+        assert nxt == fed[pos + 1], (name, pos)
+
+
+def test_rng_known_answers():
+    """xorshift* with the reference's constants: first outputs for seed 42, and the fp32 conversion rounds (a u32
+    within 128 of 2^32 yields exactly 1.0f, unlike llama2.c's shift)."""
+    r = O.Rng(42)
+    s = 42
+    for _ in range(4):
+        s ^= s >> 12
+        s ^= (s << 25) & 0xFFFFFFFFFFFFFFFF
+        s ^= s >> 27
+        assert r.u32() == ((s * 0x2545F4914F6CDD1D) >> 32) & 0xFFFFFFFF
+    r2, r3 = O.Rng(7), O.Rng(7)
+    u = r2.u32()
+    assert r3.f32() == np.float32((u / 256) / 16777216.0)
