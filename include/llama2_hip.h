@@ -122,6 +122,17 @@ float* l2_logits_host(l2_ctx* ctx);
  * Does not stop at BOS (the caller truncates, llama2.ts:499). */
 int l2_decode_greedy(l2_ctx* ctx, int first_token, int pos0, int steps, int32_t* tokens_out);
 
+/* Rest of SURVEY.md 8(f1): the sampled branch of the loop (llama2.ts:480-493) kept on the device -- temperature
+ * scaling and softmax in place of state.logits (:481-485), `sample` (:368-376) or, when 0 < topp < 1, `sample_topp`
+ * (:378-394: stable descending sort, the element that crosses topp is never returned, fall-through returns id 0),
+ * driven by the reference's xorshift* generator (:348-360).  `*rng_state` is the 64-bit state the reference keeps in
+ * the BigInt `rng_seed` (what `-s` parsed, non-zero); it is advanced by one draw per sampled token and written back.
+ * Every running sum is accumulated sequentially in index order on the device, as the reference does, so the SAME
+ * token ids come out for the same seed.  temperature == 0 is l2_decode_greedy (no draw).  Like l2_decode_greedy it
+ * does not stop at BOS. */
+int l2_decode_sample(l2_ctx* ctx, int first_token, int pos0, int steps, double temperature, double topp,
+                     uint64_t* rng_state, int32_t* tokens_out);
+
 /* Next row of SURVEY.md 8(f3): prompt ingestion.  The reference runs one transformer() per prompt token and
  * ignores the logits (llama2.ts:471-473); this feeds `n_tokens` tokens at positions pos0 .. pos0+n_tokens-1 in
  * chunks of 16 that share every weight read (fp64 MFMA GEMMs), leaves the KV cache exactly as the n_tokens

@@ -28,6 +28,7 @@
 
 #include "kernels.hip.h"
 #include "prefill.hip.h"
+#include "sampler.h"
 
 using namespace l2k;
 
@@ -141,6 +142,9 @@ struct l2_ctx {
   int G = 1, rank = 0;
   int d_loc, h_loc, H_loc, V_loc;
   nccl_comm comm = nullptr;
+  l2s::Sampler samp;                 // device sampler (l2_decode_sample), created on first use
+  hipGraphExec_t g_sample[3][2] = {};  // [attention split level][plain sample / top-p]
+  int samp_mode = 0;
   std::shared_ptr<LoopGroup> loop;   // L2_TP_LOOPBACK test hook (see LoopGroup)
   double* loop_tmp = nullptr;
   bool tp_path = false;   // WO/W2 write fp64 partials + all-reduce; logits all-gathered (G > 1, or forced for tests)
@@ -231,6 +235,7 @@ static void destroy_graphs(l2_ctx* c) {
   for (int i = 0; i < 3; ++i) {
     if (c->g_step[i]) { hipGraphExecDestroy(c->g_step[i]); c->g_step[i] = nullptr; }
     if (c->g_greedy[i]) { hipGraphExecDestroy(c->g_greedy[i]); c->g_greedy[i] = nullptr; }
+    for (int m = 0; m < 2; ++m) if (c->g_sample[i][m]) { hipGraphExecDestroy(c->g_sample[i][m]); c->g_sample[i][m] = nullptr; }
   }
 }
 
@@ -250,6 +255,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   destroy_graphs(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   if (c->loop_tmp) hipFree(c->loop_tmp);
+  l2s::destroy(&c->samp);
   for (int k = 0; k < L2_T_COUNT; ++k)
     if (c->w[k] && !(k == L2_T_WCLS && c->shared)) hipFree(c->w[k]);  // shared wcls aliases the embedding table
   float* bufs[] = {c->x, c->xb, c->xb2, c->hb, c->hb2, c->q, c->k, c->v, c->att, c->logits, c->kc, c->vc, c->xn};
@@ -1112,6 +1118,13 @@ static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step:
   return L2_OK;
 }
 
+static int enqueue_sample(l2_ctx* c, hipStream_t st) {  // device-resident sampled step: forward, temperature/softmax/sample(_topp), advance
+  int rc = enqueue_forward(c, st);
+  if (rc) return rc;
+  LCHK(l2s::enqueue(c->samp, c->logits, c->samp_mode == 1, c->tokpos, c->d_tokens, st));
+  return L2_OK;
+}
+
 static int capture(l2_ctx* c, int (*enq)(l2_ctx*, hipStream_t), hipGraphExec_t* out) {
   hipGraph_t graph = nullptr;
   LCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1306,6 +1319,49 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
   if (*c->h_err) { *c->h_err = 0; return fail(L2_E_HIP, "in-kernel hand-off wait timed out (attention never saw its head's q/k/v rows)"); }
+  return L2_OK;
+}
+
+extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps, double temperature, double topp,
+                                uint64_t* rng_state, int32_t* tokens_out) {
+  if (!c || (!tokens_out && steps > 0) || !rng_state) return fail(L2_E_ARG, "null argument");
+  if (temperature == 0.0) return l2_decode_greedy(c, first_token, pos0, steps, tokens_out);   // llama2.ts:477-479, no RNG draw
+  if (!(temperature == temperature) || !(topp == topp)) return fail(L2_E_ARG, "temperature / topp is NaN");
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  if (steps < 0 || pos0 < 0 || pos0 + steps > c->S) return fail(L2_E_ARG, "positions %d..%d outside [0, %d)", pos0, pos0 + steps, c->S);
+  if (first_token < 0 || first_token >= c->V) return fail(L2_E_ARG, "token %d outside [0, %d)", first_token, c->V);
+  if (steps == 0) return L2_OK;
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->samp.V) {
+    if (c->V > l2s::MAX_VOCAB) return fail(L2_E_CONFIG, "device sampler supports vocabularies up to %d", (int)l2s::MAX_VOCAB);
+    HIPCHK(l2s::create(&c->samp, c->V));
+  }
+  const double params[2] = {temperature, topp};
+  c->samp_mode = (topp <= 0 || topp >= 1) ? 0 : 1;        // llama2.ts:486: plain sample unless 0 < topp < 1
+  c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
+  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->samp.params, params, sizeof(params), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->samp.rng, rng_state, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));                 // the host sources above are stack / caller memory
+  const bool graph = c->opt_graph && !c->opt_chain && !c->loop;
+  for (int s = 0; s < steps; ++s) {
+    const int lvl = split_level(c, pos0 + s);
+    c->cur_splits = splits_of(c, lvl);
+    if (graph) {
+      hipGraphExec_t& g = c->g_sample[lvl][c->samp_mode];
+      if (!g) { rc = capture(c, enqueue_sample, &g); if (rc) return rc; }
+      HIPCHK(hipGraphLaunch(g, c->stream));
+    } else {
+      rc = enqueue_sample(c, c->stream);
+      if (rc) return rc;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(rng_state, c->samp.rng, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(tokens_out, c->d_tokens, (size_t)steps * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->ran_forward = true;
+  if (*c->h_err) { *c->h_err = 0; return fail(L2_E_HIP, "in-kernel hand-off wait timed out"); }
   return L2_OK;
 }
 

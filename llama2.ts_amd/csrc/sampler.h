@@ -1,0 +1,33 @@
+// Device-side temperature / top-p sampling (llama2.ts:348-394 and 476-493): the part of the
+// reference's decode loop that sits between transformer() and the next token, kept on the GPU so that a sampled
+// run needs no 128 KB logits hand-off and no host sort of 32 000 objects per token.  sampler.hip holds the
+// kernels; this is the interface llama2_hip.hip uses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace l2s {
+
+struct Sampler {
+  int V = 0;
+  float* probs = nullptr;        // (V) scaled logits -> exps -> probabilities, in place like state.logits
+  float* probs_sorted = nullptr; // (V) descending (top-p)
+  int* idx = nullptr;            // (V) 0..V-1
+  int* idx_sorted = nullptr;     // (V) token ids in descending-probability order, ties by id (stable sort)
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  double* params = nullptr;      // device {temperature, topp}
+  unsigned long long* rng = nullptr;   // device xorshift* state (the reference's BigInt rng_seed)
+};
+
+enum { MAX_VOCAB = 512 * 1024 };   // boundary-prefix table: 1024 segments of 512
+
+hipError_t create(Sampler* s, int V);
+void destroy(Sampler* s);
+// Enqueue one sampled step after the classifier: reads `logits` (V floats, left untouched), picks the next token
+// exactly as llama2.ts:480-493 does, then advances {token, pos, step} in `tokpos` and stores the token in
+// tokens_out[step] -- the same protocol as argmax_advance_kernel.  `topp_mode`: the sample_topp branch
+// (0 < topp < 1); temperature and topp themselves are read from s.params at run time.
+hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, hipStream_t st);
+
+}  // namespace l2s

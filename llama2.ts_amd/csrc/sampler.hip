@@ -1,0 +1,230 @@
+// Device-side sampling for libllama2hip.so (gfx950): temperature scaling, softmax, sample / sample_topp and the
+// xorshift* RNG of wizzard0/llama2.ts (llama2.ts:348-394, 476-493), restated so that the SAME token comes out.
+//
+// What makes that non-trivial: the reference's sums are sequential fp64 accumulations of fp32 values
+// (softmax :189, sample :369/:373, sample_topp :385/:391) and the chosen index depends on comparing a random
+// threshold against those running sums.  A parallel (tree) sum differs in the last bits and can flip an index,
+// so every running sum here is produced by ONE lane adding in index order -- ~10 cycles per element, ~130 us per
+// pass over 32 000 values -- while everything that is elementwise (divide, exp, normalise, search) uses the
+// whole 1024-thread workgroup.  The index search avoids a second full sequential pass: the running sum is
+// recorded at every 512th element; once the threshold is known the (monotone) boundary values locate the
+// segment of the first crossing and only that segment is re-accumulated from its exact starting value.
+// The descending stable sort of sample_topp (Array.prototype.sort is stable in V8 >= 7.0) is rocPRIM's radix sort
+// on (probability, id) pairs: stable, so ties stay in id order.
+#include "sampler.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace l2s {
+
+#pragma clang fp contract(off)
+
+constexpr int NT = 1024;     // threads of the one workgroup
+constexpr int CH = 8192;     // floats staged in LDS per chunk
+constexpr int SEG = 512;     // spacing of recorded running sums
+constexpr int MAXSEG = MAX_VOCAB / SEG;
+
+__device__ __forceinline__ float random_f32(unsigned long long* rng) {   // llama2.ts:349-360
+  unsigned long long s = *rng;
+  s ^= s >> 12;
+  s ^= s << 25;
+  s ^= s >> 27;
+  *rng = s;
+  const unsigned u = (unsigned)((s * 0x2545F4914F6CDD1Dull) >> 32);
+  return (float)(((double)u / 256.0) / 16777216.0);      // one rounding at the Float32Array store (:358)
+}
+
+__device__ __forceinline__ void advance(int* tokpos, int* tokens_out, int next) {
+  const int step = tokpos[2];
+  tokens_out[step] = next;
+  tokpos[0] = next; tokpos[1] = tokpos[1] + 1; tokpos[2] = step + 1;
+}
+
+// Running sum of buf[0..n) added to `acc` in index order by the calling lane; records the value after every
+// element whose global index + 1 is a multiple of SEG.  Stops after the first element at which acc > limit
+// (limit = +inf: never) and returns that local index, else -1.
+__device__ __forceinline__ int seq_accumulate(const float* buf, int n, int g0, double& acc, double* bound, double limit) {
+  double a = acc;
+  for (int i = 0; i < n; ++i) {
+    a += (double)buf[i];
+    const int g = g0 + i;
+    if (bound && ((g + 1) & (SEG - 1)) == 0) bound[g / SEG] = a;
+    if (a > limit) { acc = a; return i; }
+  }
+  acc = a;
+  return -1;
+}
+
+// logits -> probabilities exactly as llama2.ts:481-485 + softmax :181-194 does it in place on state.logits.
+__device__ __forceinline__ void softmax_in_place(const float* logits, int V, double T, float* probs, int* idx, float* buf, float* redf, double* shd) {
+  const int tid = threadIdx.x;
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += NT) {
+    const float x = (float)((double)logits[i] / T);        // state.logits[q] /= temperature (:482)
+    probs[i] = x;
+    mx = fmaxf(mx, x);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((tid & 63) == 0) redf[tid >> 6] = mx;
+  __syncthreads();
+  mx = redf[0];
+  for (int w = 1; w < NT / 64; ++w) mx = fmaxf(mx, redf[w]);
+  double sum = 0.0;                                          // lane 0 only
+  for (int c0 = 0; c0 < V; c0 += CH) {
+    const int n = min(CH, V - c0);
+    for (int i = tid; i < n; i += NT) {
+      const float e = (float)exp((double)probs[c0 + i] - (double)mx);   // stored to fp32 (:187)
+      probs[c0 + i] = e;
+      buf[i] = e;
+    }
+    __syncthreads();
+    if (tid == 0) seq_accumulate(buf, n, c0, sum, nullptr, INFINITY);    // sum of the ROUNDED values, in order (:189)
+    __syncthreads();
+  }
+  if (tid == 0) shd[0] = sum;
+  __syncthreads();
+  sum = shd[0];
+  for (int i = tid; i < V; i += NT) {
+    probs[i] = (float)((double)probs[i] / sum);             // :192
+    if (idx) idx[i] = i;
+  }
+  __syncthreads();
+}
+
+// After lane 0 knows the threshold r and the recorded boundary sums: first index i < limit_idx with
+// r < (running sum through i), or -1.  `vals` are the values in accumulation order.
+__device__ __forceinline__ int first_crossing(const float* vals, int limit_idx, double r, const double* bound, float* buf, int* shi) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int seg = -1;
+    for (int s = 0; s * SEG < limit_idx; ++s) {
+      const bool complete = (s + 1) * SEG <= limit_idx;      // its last element is below limit_idx
+      if (!complete || r < bound[s]) { seg = s; break; }     // partial last segment: scan it; complete one: crossing is inside
+    }
+    shi[0] = seg;
+  }
+  __syncthreads();
+  const int seg = shi[0];
+  if (seg < 0) return -1;
+  const int g0 = seg * SEG, n = min(SEG, limit_idx - g0);
+  for (int i = tid; i < n; i += NT) buf[i] = vals[g0 + i];
+  __syncthreads();
+  if (tid == 0) {
+    double a = seg ? bound[seg - 1] : 0.0;                   // exact running sum at the segment start
+    int hit = -1;
+    for (int i = 0; i < n; ++i) {
+      a += (double)buf[i];
+      if (r < a) { hit = g0 + i; break; }
+    }
+    shi[1] = hit;
+  }
+  __syncthreads();
+  return shi[1];
+}
+
+// temperature + softmax + sample (llama2.ts:480-487, 368-376) + advance.
+__global__ void __launch_bounds__(NT) sample_kernel(const float* logits, int V, const double* params, float* probs,
+                                                     unsigned long long* rng, int* tokpos, int* tokens_out) {
+  __shared__ __attribute__((aligned(16))) float buf[CH];
+  __shared__ float redf[NT / 64];
+  __shared__ double shd[2];
+  __shared__ int shi[2];
+  __shared__ double bound[MAXSEG];
+  const int tid = threadIdx.x;
+  softmax_in_place(logits, V, params[0], probs, nullptr, buf, redf, shd);
+  double cum = 0.0;
+  for (int c0 = 0; c0 < V; c0 += CH) {
+    const int n = min(CH, V - c0);
+    for (int i = tid; i < n; i += NT) buf[i] = probs[c0 + i];
+    __syncthreads();
+    if (tid == 0) seq_accumulate(buf, n, c0, cum, bound, INFINITY);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (V & (SEG - 1)) bound[V / SEG] = cum;                 // close the last, partial segment
+    shd[1] = (double)random_f32(rng) * cum;                  // randValue = random_f32() * sum (:370)
+  }
+  __syncthreads();
+  const int hit = first_crossing(probs, V, shd[1], bound, buf, shi);
+  if (tid == 0) advance(tokpos, tokens_out, hit < 0 ? 0 : hit);   // fall-through returns 0 (:375)
+}
+
+// Stage 1 of the top-p branch: temperature + softmax, and the identity permutation for the sort.
+__global__ void __launch_bounds__(NT) softmax_kernel(const float* logits, int V, const double* params, float* probs, int* idx) {
+  __shared__ __attribute__((aligned(16))) float buf[CH];
+  __shared__ float redf[NT / 64];
+  __shared__ double shd[2];
+  softmax_in_place(logits, V, params[0], probs, idx, buf, redf, shd);
+}
+
+// Stage 3: sample_topp (llama2.ts:378-394) on the sorted pairs + advance.
+__global__ void __launch_bounds__(NT) topp_kernel(const float* sorted, const int* sorted_idx, int V, const double* params,
+                                                   unsigned long long* rng, int* tokpos, int* tokens_out) {
+  __shared__ __attribute__((aligned(16))) float buf[CH];
+  __shared__ double shd[2];
+  __shared__ int shi[3];
+  __shared__ double bound[MAXSEG];
+  const int tid = threadIdx.x;
+  const double topp = params[1];
+  double cum = 0.0;
+  if (tid == 0) shi[2] = -1;
+  __syncthreads();
+  for (int c0 = 0; c0 < V; c0 += CH) {                      // cumProb until it exceeds topp (:384-386)
+    const int n = min(CH, V - c0);
+    for (int i = tid; i < n; i += NT) buf[i] = sorted[c0 + i];
+    __syncthreads();
+    if (tid == 0) {
+      const int at = seq_accumulate(buf, n, c0, cum, bound, topp);
+      if (at >= 0) shi[2] = c0 + at;
+    }
+    __syncthreads();
+    if (shi[2] >= 0) break;
+  }
+  const int last = shi[2] < 0 ? 0 : shi[2];                  // never crossed: lastIdx stays 0 (:383)
+  if (tid == 0) shd[1] = (double)random_f32(rng) * cum;      // cumProb as the loop left it (:388)
+  __syncthreads();
+  const int hit = first_crossing(sorted, last, shd[1], bound, buf, shi);   // i < lastIdx only (:390)
+  if (tid == 0) advance(tokpos, tokens_out, hit < 0 ? 0 : sorted_idx[hit]);
+}
+
+hipError_t create(Sampler* s, int V) {
+  if (V <= 0 || V > MAX_VOCAB) return hipErrorInvalidValue;
+  s->V = V;
+  hipError_t e;
+#define L2S(x) do { e = (x); if (e != hipSuccess) { destroy(s); return e; } } while (0)
+  L2S(hipMalloc(&s->probs, (size_t)V * 4));
+  L2S(hipMalloc(&s->probs_sorted, (size_t)V * 4));
+  L2S(hipMalloc(&s->idx, (size_t)V * 4));
+  L2S(hipMalloc(&s->idx_sorted, (size_t)V * 4));
+  L2S(hipMalloc(&s->params, 2 * sizeof(double)));
+  L2S(hipMalloc(&s->rng, sizeof(unsigned long long)));
+  s->sort_temp_bytes = 0;
+  L2S(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, s->sort_temp_bytes, s->probs, s->probs_sorted, s->idx, s->idx_sorted, V, 0, 32, nullptr));
+  L2S(hipMalloc(&s->sort_temp, s->sort_temp_bytes ? s->sort_temp_bytes : 16));
+#undef L2S
+  return hipSuccess;
+}
+
+void destroy(Sampler* s) {
+  void* bufs[] = {s->probs, s->probs_sorted, s->idx, s->idx_sorted, s->params, s->rng, s->sort_temp};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  *s = Sampler();
+}
+
+hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, hipStream_t st) {
+  if (!topp_mode) {
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.rng, tokpos, tokens_out);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.idx);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  size_t bytes = s.sort_temp_bytes;
+  e = hipcub::DeviceRadixSort::SortPairsDescending(s.sort_temp, bytes, s.probs, s.probs_sorted, s.idx, s.idx_sorted, s.V, 0, 32, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(topp_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.rng, tokpos, tokens_out);
+  return hipGetLastError();
+}
+
+}  // namespace l2s

@@ -32,6 +32,7 @@ struct Api {
   decltype(&l2_forward) forward;
   decltype(&l2_logits_host) logits_host;
   decltype(&l2_decode_greedy) decode_greedy;
+  decltype(&l2_decode_sample) decode_sample;
   decltype(&l2_read_state) read_state;
   decltype(&l2_set_option) set_option;
   decltype(&l2_load_checkpoint) load_checkpoint;
@@ -56,7 +57,7 @@ bool load_library(const char* hint) {
   api.name = (decltype(api.name))dlsym(api.so, "l2_" #name);               \
   if (!api.name) { g_load_error = "missing symbol l2_" #name; dlclose(api.so); api.so = nullptr; return false; }
   BIND(abi_version) BIND(device_count) BIND(last_error) BIND(create) BIND(destroy) BIND(upload) BIND(synth_fill)
-  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(read_state) BIND(set_option) BIND(load_checkpoint) BIND(get_header) BIND(prefill)
+  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(decode_sample) BIND(read_state) BIND(set_option) BIND(load_checkpoint) BIND(get_header) BIND(prefill)
 #undef BIND
   if (api.abi_version() != L2_ABI_VERSION) { g_load_error = "ABI version mismatch"; dlclose(api.so); api.so = nullptr; return false; }
   return true;
@@ -302,6 +303,36 @@ napi_value DecodeGreedy(napi_env env, napi_callback_info info) {
   return ta;
 }
 
+// decodeSample(handle, firstToken, pos0, steps, temperature, topp, Uint32Array[2] rng {lo, hi}) -> Int32Array
+// The sampled branch (llama2.ts:480-493) on the device.  The 64-bit xorshift* state travels as two uint32 halves
+// (updated in place) so that the binding needs no BigInt support from the N-API level.
+napi_value DecodeSample(napi_env env, napi_callback_info info) {
+  ARGS(7)
+  l2_ctx* c;
+  int32_t first, pos0, steps;
+  double temperature, topp;
+  if (!get_ctx(env, argv[0], &c) || !get_i32(env, argv[1], &first) || !get_i32(env, argv[2], &pos0) || !get_i32(env, argv[3], &steps))
+    return nullptr;
+  if (napi_get_value_double(env, argv[4], &temperature) != napi_ok || napi_get_value_double(env, argv[5], &topp) != napi_ok)
+    return throw_err(env, "temperature and topp must be numbers");
+  napi_typedarray_type tt;
+  size_t len = 0;
+  void* rdata = nullptr;
+  if (napi_get_typedarray_info(env, argv[6], &tt, &len, &rdata, nullptr, nullptr) != napi_ok || tt != napi_uint32_array || len != 2)
+    return throw_err(env, "rng must be a Uint32Array of length 2 {lo, hi}");
+  if (steps < 0) return throw_err(env, "steps < 0");
+  uint32_t* halves = (uint32_t*)rdata;
+  uint64_t state = ((uint64_t)halves[1] << 32) | halves[0];
+  napi_value ab, ta;
+  void* data;
+  napi_create_arraybuffer(env, (size_t)steps * 4, &data, &ab);
+  int rc = api.decode_sample(c, first, pos0, steps, temperature, topp, &state, (int32_t*)data);
+  if (rc) return throw_l2(env, rc);
+  halves[0] = (uint32_t)state; halves[1] = (uint32_t)(state >> 32);
+  napi_create_typedarray(env, napi_int32_array, (size_t)steps, ab, 0, &ta);
+  return ta;
+}
+
 // readState(handle, which, layer, Float32Array)
 napi_value ReadState(napi_env env, napi_callback_info info) {
   ARGS(4)
@@ -337,7 +368,7 @@ napi_value DeviceCount(napi_env env, napi_callback_info) {
 napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"upload", Upload}, {"synthFill", SynthFill},
-      {"forward", Forward}, {"logitsBuffer", LogitsBuffer}, {"decodeGreedy", DecodeGreedy}, {"readState", ReadState},
+      {"forward", Forward}, {"logitsBuffer", LogitsBuffer}, {"decodeGreedy", DecodeGreedy}, {"decodeSample", DecodeSample}, {"readState", ReadState},
       {"setOption", SetOption}, {"deviceCount", DeviceCount}, {"loadCheckpoint", LoadCheckpoint}, {"prefill", Prefill}};
   for (auto& f : fns) {
     napi_value v;

@@ -323,6 +323,10 @@ function main() {
 
   // opt-in extra (SURVEY.md 8(f1)): keep the greedy loop on the device, `chunk` tokens per call
   const deviceGreedy = process.env.L2_DEVICE_GREEDY == "1" && temperature == 0.0;
+  // ... and the sampled branch too (llama2.ts:480-493): temperature, softmax, sample / sample_topp and the RNG run on
+  // the device, which hands back token ids and the advanced rng_seed (needs 0 <= rng_seed < 2^64, as xorshift keeps it)
+  const deviceSampler = process.env.L2_DEVICE_SAMPLER == "1" && temperature != 0.0 && rng_seed >= 0n && rng_seed < (1n << 64n);
+  const rngHalves = new Uint32Array(2);
 
   let start = 0, next = 0, token = 1, pos = 0;   // token 1 = BOS (llama2.ts:463)
   /** @type {number[]} */
@@ -330,6 +334,13 @@ function main() {
   while (pos < steps) {
     if (deviceGreedy && pos >= num_prompt_tokens) {
       if (ahead.length == 0) ahead = Array.from(be.decodeGreedy(ctx, token, pos, Math.min(16, steps - pos)));
+      next = /** @type {number} */ (ahead.shift());
+    } else if (deviceSampler && pos >= num_prompt_tokens) {
+      if (ahead.length == 0) {
+        rngHalves[0] = Number(rng_seed & 0xffffffffn); rngHalves[1] = Number(rng_seed >> 32n);
+        ahead = Array.from(be.decodeSample(ctx, token, pos, Math.min(16, steps - pos), temperature, topp, rngHalves));
+        rng_seed = (BigInt(rngHalves[1]) << 32n) | BigInt(rngHalves[0]);
+      }
       next = /** @type {number} */ (ahead.shift());
     } else {
       if (pos >= prefilled) transformer(token, pos, config, state, weights, be);

@@ -30,7 +30,7 @@ OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_MEGAKERNEL = 1, 2, 3
 # every symbol include/llama2_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
-               "l2_decode_greedy", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
+               "l2_decode_greedy", "l2_decode_sample", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
                "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ"]
 
 
@@ -67,6 +67,7 @@ def lib():
     L.l2_logits_host.argtypes = [vp]
     L.l2_logits_host.restype = vp
     L.l2_decode_greedy.argtypes = [vp, i32, i32, i32, vp]
+    L.l2_decode_sample.argtypes = [vp, i32, i32, i32, C.c_double, C.c_double, C.POINTER(C.c_uint64), vp]
     L.l2_read_state.argtypes = [vp, i32, i32, vp, sz]
     L.l2_set_option.argtypes = [vp, i32, i32]
     L.l2_get_option.argtypes = [vp, i32, C.POINTER(i32)]
@@ -182,6 +183,15 @@ class Context:
         out = np.zeros(steps, dtype=np.int32)
         _check(lib().l2_decode_greedy(self._h, int(first_token), int(pos0), int(steps), out.ctypes.data))
         return out
+
+    def decode_sample(self, first_token, pos0, steps, temperature, topp, rng_state):
+        """The sampled branch of the loop (llama2.ts:480-493) on the device.  `rng_state`: the reference's rng_seed as an
+        int; returns (tokens, advanced rng state)."""
+        out = np.zeros(steps, dtype=np.int32)
+        st = C.c_uint64(int(rng_state))
+        _check(lib().l2_decode_sample(self._h, int(first_token), int(pos0), int(steps), float(temperature), float(topp),
+                                      C.byref(st), out.ctypes.data))
+        return out, int(st.value)
 
     def read_state(self, name, layer=-1):
         c = self.cfg

@@ -60,6 +60,17 @@ def test_cli_device_greedy_extra_prints_the_same(workdir):
     assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
 
 
+@pytest.mark.parametrize("name", ["cli_temp", "cli_topp"])
+def test_cli_device_sampler_extra_prints_the_same(workdir, name):
+    """L2_DEVICE_SAMPLER=1: temperature, softmax, sample / sample_topp and the RNG on the GPU (l2_decode_sample),
+    with and without the batched prompt prefill in front of it."""
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    for extra in ({}, {"L2_PREFILL": "1"}):
+        rc, out, err = run_cli(workdir, meta["argv"], dict({"L2_DEVICE_SAMPLER": "1"}, **extra))
+        assert rc == 0, err
+        assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
+
+
 def test_cli_usage_and_errors(workdir):
     r = subprocess.run(["node", HOST], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and r.stderr.decode().startswith("Usage: ... llama2.ts <checkpoint> [options]")

@@ -354,3 +354,67 @@ def test_prefill_prompt_golden_and_errors(built):
     with pytest.raises(runtime.L2Error):
         ctx.prefill([1, 40000], 0)                     # token out of range
     ctx.close()
+
+
+# ---- SURVEY.md 8(f1), the rest of it: temperature / top-p sampling on the device -------------------------------
+
+def _sampled_run(name):
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    argv = dict(zip(meta["argv"][::2], meta["argv"][1::2]))
+    return meta, float(argv.get("-t", 1.0)), float(argv.get("-p", 1.0)), int(argv["-s"])
+
+
+@pytest.mark.parametrize("name,n_prompt", [("cli_temp", 0), ("cli_topp", 4)])
+def test_device_sampler_reproduces_the_reference_run(name, n_prompt):
+    """The TRUE reference was run with -t / -p / -s as recorded in the fixture.  Forcing its prompt tokens and then
+    letting l2_decode_sample pick every following token (device softmax, sequential running sums, stable sort,
+    xorshift* draws) must give the reference's token ids, in one call and in ragged chunks (RNG state carried)."""
+    meta, temperature, topp, seed = _sampled_run(name)
+    fed = meta["tokens_fed"]
+    for chunks in ([len(fed) - 1 - n_prompt], [1, 2, 5, 10 ** 6]):
+        ctx = runtime.Context(meta["header"])
+        ctx.synth_fill(meta["seed"])
+        for pos in range(n_prompt):
+            ctx.forward(fed[pos], pos)                       # teacher-forced prompt positions (llama2.ts:471-473)
+        pos, tok, rng, got = n_prompt, fed[n_prompt], seed, []
+        for n in chunks:
+            n = min(n, len(fed) - 1 - pos)
+            if n <= 0:
+                break
+            toks, rng = ctx.decode_sample(tok, pos, n, temperature, topp, rng)
+            got += toks.tolist()
+            pos += n
+            tok = got[-1]
+        assert got == fed[n_prompt + 1:], (name, chunks)
+        ctx.close()
+
+
+def test_device_sampler_matches_oracle_on_other_settings():
+    """Settings the fixtures do not cover, checked against the oracle's sampler fed with the device's own logits:
+    low / high temperature, top-p that keeps a handful or nearly all of the vocabulary, topp outside (0, 1)."""
+    hdr = configs.header("stories15M")
+    for temperature, topp, seed in [(0.3, 1.0, 5), (1.7, 0.0, 99), (1.0, 0.05, 3), (0.8, 0.999, 123456789), (2.5, 0.5, 2 ** 63 + 11)]:
+        ctx = runtime.Context(hdr)
+        ctx.synth_fill(1)
+        toks, rng_after = ctx.decode_sample(1, 0, 12, temperature, topp, seed)
+        ref = runtime.Context(hdr)
+        ref.synth_fill(1)
+        rng = O.Rng(seed)
+        tok, want = 1, []
+        for pos in range(12):
+            lg = np.array(ref.forward(tok, pos), copy=True)
+            tok, _ = O.next_token(lg, temperature, topp, rng)
+            want.append(tok)
+        assert toks.tolist() == want, (temperature, topp, seed)
+        assert rng_after == rng.state.value
+        ctx.close(); ref.close()
+
+
+def test_device_sampler_temperature_zero_is_greedy():
+    ctx = runtime.Context(configs.header("tiny"))
+    ctx.synth_fill(1)
+    a, rng = ctx.decode_sample(1, 0, 16, 0.0, 0.9, 77)
+    ctx2 = runtime.Context(configs.header("tiny"))
+    ctx2.synth_fill(1)
+    assert a.tolist() == ctx2.decode_greedy(1, 0, 16).tolist() and rng == 77
+    ctx.close(); ctx2.close()
