@@ -133,6 +133,11 @@ int l2_decode_greedy(l2_ctx* ctx, int first_token, int pos0, int steps, int32_t*
 int l2_decode_sample(l2_ctx* ctx, int first_token, int pos0, int steps, double temperature, double topp,
                      uint64_t* rng_state, int32_t* tokens_out);
 
+/* Diagnostic for the sampler's core: sums_out[i] = S_i with S_i = fl(S_{i-1} + values[i]) in fp64 (the reference's
+ * `cumProb += x[i]` / `sum += x[i]` loops), computed on the device by the exact parallel algorithm of sampler.hip.
+ * `values` must be finite and >= 0.  Tests compare it with the serial loop on adversarial vectors. */
+int l2_debug_running_sums(int device, const float* values, size_t n, double* sums_out);
+
 /* Next row of SURVEY.md 8(f3): prompt ingestion.  The reference runs one transformer() per prompt token and
  * ignores the logits (llama2.ts:471-473); this feeds `n_tokens` tokens at positions pos0 .. pos0+n_tokens-1 in
  * chunks of 16 that share every weight read (fp64 MFMA GEMMs), leaves the KV cache exactly as the n_tokens

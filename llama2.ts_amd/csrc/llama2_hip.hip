@@ -1365,6 +1365,20 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   return L2_OK;
 }
 
+extern "C" int l2_debug_running_sums(int device, const float* values, size_t n, double* sums_out) {
+  if (!values || !sums_out || n == 0 || n > (size_t)1 << 28) return fail(L2_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  float* dx = nullptr; double* dp = nullptr;
+  HIPCHK(hipMalloc(&dx, n * 4));
+  if (hipMalloc(&dp, n * 8) != hipSuccess) { hipFree(dx); return fail(L2_E_HIP, "hipMalloc failed"); }
+  hipError_t e = hipMemcpy(dx, values, n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = l2s::running_sums(dx, (int)n, dp, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(sums_out, dp, n * 8, hipMemcpyDeviceToHost);
+  hipFree(dx); hipFree(dp);
+  if (e != hipSuccess) return fail(L2_E_HIP, "running sums: %s", hipGetErrorString(e));
+  return L2_OK;
+}
+
 extern "C" int l2_decode_greedy(l2_ctx* c, int first_token, int pos0, int steps, int32_t* tokens_out) {
   if (!tokens_out && steps > 0) return fail(L2_E_ARG, "null tokens_out");
   int rc = run_greedy(c, first_token, pos0, steps, false, nullptr);

@@ -18,6 +18,8 @@ struct Sampler {
   size_t sort_temp_bytes = 0;
   double* params = nullptr;      // device {temperature, topp}
   unsigned long long* rng = nullptr;   // device xorshift* state (the reference's BigInt rng_seed)
+  double* prefix = nullptr;      // (V) running sums (exact parallel form)
+  bool serial = false;           // L2_SAMPLER_SERIAL=1: one lane accumulates (the straightforward form, kept for A/B)
 };
 
 enum { MAX_VOCAB = 512 * 1024 };   // boundary-prefix table: 1024 segments of 512
@@ -29,5 +31,8 @@ void destroy(Sampler* s);
 // tokens_out[step] -- the same protocol as argmax_advance_kernel.  `topp_mode`: the sample_topp branch
 // (0 < topp < 1); temperature and topp themselves are read from s.params at run time.
 hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, hipStream_t st);
+
+// Diagnostic: running sums S_i = fl(S_{i-1} + x_i) of n non-negative fp32 values, by the exact parallel algorithm.
+hipError_t running_sums(const float* x_dev, int n, double* prefix_dev, hipStream_t st);
 
 }  // namespace l2s

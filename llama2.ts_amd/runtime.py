@@ -30,7 +30,7 @@ OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_MEGAKERNEL = 1, 2, 3
 # every symbol include/llama2_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
-               "l2_decode_greedy", "l2_decode_sample", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
+               "l2_decode_greedy", "l2_decode_sample", "l2_debug_running_sums", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
                "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ"]
 
 
@@ -67,6 +67,7 @@ def lib():
     L.l2_logits_host.argtypes = [vp]
     L.l2_logits_host.restype = vp
     L.l2_decode_greedy.argtypes = [vp, i32, i32, i32, vp]
+    L.l2_debug_running_sums.argtypes = [i32, vp, sz, vp]
     L.l2_decode_sample.argtypes = [vp, i32, i32, i32, C.c_double, C.c_double, C.POINTER(C.c_uint64), vp]
     L.l2_read_state.argtypes = [vp, i32, i32, vp, sz]
     L.l2_set_option.argtypes = [vp, i32, i32]
@@ -101,6 +102,14 @@ class Config:
         self.vocab_size = abs(vocab)
         self.shared_weights = vocab > 0
         self.head_size = self.dim // self.n_heads
+
+
+def running_sums(values, device=0):
+    """S_i = fl(S_{i-1} + values[i]) in fp64, on the device (diagnostic for the sampler's exact parallel accumulation)."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    out = np.empty(v.size, dtype=np.float64)
+    _check(lib().l2_debug_running_sums(int(device), v.ctypes.data, v.size, out.ctypes.data))
+    return out
 
 
 def readConfig(buf):
