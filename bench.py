@@ -153,7 +153,8 @@ def main():
         "data": "synthetic (seeded hash generator, llama2.c-v0 layout)",
         "config": {"workload": "%s batch-1 greedy decode, %d tokens from BOS (-t 0 -s 1 -n %d)" % (args.config, K, K),
                    "header": list(hdr), "parallelism": ("tp%d" % world) if shards else ("replicas%d" % world if world > 1 else "single"),
-                   "loop": "device-resident (forward + argmax on GPU, one hipGraph replay per token)"},
+                   "loop": ("device-resident (forward + argmax on GPU), eager launches with 2L fp64 RCCL all-reduces + 1 all-gather per token"
+                            if shards else "device-resident (forward + argmax on GPU, one hipGraph replay per token)")},
         "device_ms_per_step": round(dev_ms / K, 5),
         "algorithmic_bytes_per_token": int(bpt),
         "hbm_gbs_end_to_end": round(bpt * value / 1e9 / (1 if shards or world == 1 else world), 2),
