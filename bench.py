@@ -200,6 +200,27 @@ def main():
         out["per_kernel"] = per_kernel
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, hdr, args.seed)
+        if not args.no_extra:
+            # the same loop near the end of the context window (attention reads ~S rows per layer; split-attention form)
+            S = hdr[6]
+            if S >= 1024:
+                n_long = 128
+                p0 = S - n_long
+                ctx.bench_decode(1, p0, 8)
+                ms = ctx.bench_decode(1, p0, n_long)
+                b_long = sum(configs.algorithmic_bytes_per_token(hdr, p) for p in range(p0, S)) / n_long
+                out["long_context"] = {"positions": [p0, S - 1], "value": round(n_long / (ms * 1e-3), 3), "unit": "tokens/s",
+                                       "ms_per_step": round(ms / n_long, 5), "algorithmic_bytes_per_token": int(b_long),
+                                       "hbm_frac_end_to_end": round(b_long * n_long / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            # the sampled branch of the loop on the device (l2_decode_sample): reference semantics, same token ids per seed
+            n_s = min(64, hdr[6])
+            samp = {}
+            for nm, t, p in (("sample_t0.9", 0.9, 1.0), ("topp0.9_t0.9", 0.9, 0.9)):
+                ctx.decode_sample(1, 0, 8, t, p, 42)
+                t0 = time.perf_counter()
+                ctx.decode_sample(1, 0, n_s, t, p, 42)
+                samp[nm] = round(n_s / (time.perf_counter() - t0), 3)
+            out["sampled_decode_tok_s"] = samp
     ctx.close()
 
     if rank == 0 and world == 1 and not args.no_extra and args.config == "llama2_7b":

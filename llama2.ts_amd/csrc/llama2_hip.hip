@@ -160,6 +160,8 @@ struct l2_ctx {
   double* attn_part = nullptr;      // split attention partials [H][NS][rec]
   unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
+  int pf_two_tiles = 0;             // L2_PF_TWO_TILES=1: prefill GEMMs take two 16-row tiles per workgroup (measured slower)
+  int pf_un = 4;                    // L2_PF_UN: 16-column blocks per register set in the prefill GEMMs (4 or 8)
   int cur_splits = 1;               // split count of the step being enqueued / captured
   unsigned* head_done = nullptr;    // [H] fused QKV+attention hand-off counters, zero between launches
   int* h_err = nullptr;             // pinned + mapped: set by a kernel whose bounded wait gave up
@@ -357,6 +359,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMemsetAsync(c->logits, 0, (size_t)V * 4, c->stream));
   // split attention scratch (sized for the largest split count)
   c->attn_splits_forced = env_int("L2_ATTN_SPLITS", 0);
+  c->pf_two_tiles = env_int("L2_PF_TWO_TILES", 0);
+  c->pf_un = env_int("L2_PF_UN", 4);
   if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;
   {
     const size_t rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;
@@ -1175,6 +1179,21 @@ static bool can_prefill(const l2_ctx* c) {
   return !c->tp_path && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
 }
 
+// One prefill GEMM: NW waves per workgroup split K; QKV / WO / W2 take two 16-row tiles per workgroup when the
+// matrix height allows it and L2_PF_TWO_TILES=1 (opt-in: measured slower, fewer bytes in flight).
+template <int MODE>
+static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, hipStream_t st) {
+  const int mrows = (MODE == MODE_QKV) ? a.dim : a.rows;
+  const bool two = (MODE != MODE_W13) && c->pf_two_tiles && (mrows % 32 == 0);
+  const int grid = a.rows / (two ? 32 : 16);
+#define L2_PFG2(NW, UNN) do { if (two) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, true, UNN>), dim3(grid), dim3(64 * NW), 0, st, a); \
+                              else hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, false, UNN>), dim3(grid), dim3(64 * NW), 0, st, a); } while (0)
+#define L2_PFG(NW) do { if (c->pf_un == 8) L2_PFG2(NW, 8); else L2_PFG2(NW, 4); } while (0)
+  if (nw <= 4) L2_PFG(4); else L2_PFG(8);
+#undef L2_PFG2
+#undef L2_PFG
+}
+
 static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
   hipStream_t st = c->stream;
   const size_t d = c->d, h = c->h;
@@ -1201,12 +1220,7 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
     a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
     a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
-    { const int nw_ = env_int("L2_PF_NW_QKV", 4);
-      if (nw_ == 1) hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 1>), dim3(a.rows / 16), dim3(64), 0, st, a);
-      else if (nw_ == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 2>), dim3(a.rows / 16), dim3(128), 0, st, a);
-      else if (nw_ == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 4>), dim3(a.rows / 16), dim3(256), 0, st, a);
-      else if (nw_ == 8) hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((pf_gemm_kernel<MODE_QKV, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a); }
+    launch_pf_gemm<MODE_QKV>(c, a, env_int("L2_PF_NW_QKV", 4), st);
     LCHK(hipGetLastError());
     // attention, one workgroup per (head, query) (llama2.ts:244-267)
     {
@@ -1221,30 +1235,15 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     }
     // wo + residual (llama2.ts:270-273)
     a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
-    { const int nw_ = env_int("L2_PF_NW_WO", 4);
-      if (nw_ == 1) hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 1>), dim3(a.rows / 16), dim3(64), 0, st, a);
-      else if (nw_ == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 2>), dim3(a.rows / 16), dim3(128), 0, st, a);
-      else if (nw_ == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 4>), dim3(a.rows / 16), dim3(256), 0, st, a);
-      else if (nw_ == 8) hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((pf_gemm_kernel<MODE_WO, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a); }
+    launch_pf_gemm<MODE_WO>(c, a, env_int("L2_PF_NW_WO", 4), st);
     // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
     hipLaunchKernelGGL(pf_norm_kernel, dim3(PF_T), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
     a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
     a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
-    { const int nw_ = env_int("L2_PF_NW_W13", 4);
-      if (nw_ == 1) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 1>), dim3(a.rows / 16), dim3(64), 0, st, a);
-      else if (nw_ == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 2>), dim3(a.rows / 16), dim3(128), 0, st, a);
-      else if (nw_ == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 4>), dim3(a.rows / 16), dim3(256), 0, st, a);
-      else if (nw_ == 8) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((pf_gemm_kernel<MODE_W13, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a); }
+    launch_pf_gemm<MODE_W13>(c, a, env_int("L2_PF_NW_W13", 4), st);
     // w2 + residual (llama2.ts:292-295)
     a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
-    { const int nw_ = env_int("L2_PF_NW_W2", 4);
-      if (nw_ == 1) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 1>), dim3(a.rows / 16), dim3(64), 0, st, a);
-      else if (nw_ == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 2>), dim3(a.rows / 16), dim3(128), 0, st, a);
-      else if (nw_ == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 4>), dim3(a.rows / 16), dim3(256), 0, st, a);
-      else if (nw_ == 8) hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 8>), dim3(a.rows / 16), dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((pf_gemm_kernel<MODE_W2, 16>), dim3(a.rows / 16), dim3(1024), 0, st, a); }
+    launch_pf_gemm<MODE_W2>(c, a, env_int("L2_PF_NW_W2", 4), st);
     LCHK(hipGetLastError());
   }
   return L2_OK;

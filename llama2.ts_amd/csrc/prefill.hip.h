@@ -72,23 +72,28 @@ __global__ void __launch_bounds__(256) pf_norm_kernel(float* xn, const float* x,
 
 // NW waves per workgroup share one 16-row tile and split K NW ways.  Measured (7B shapes, L2_PF_NW_*): 4 waves per
 // tile is best everywhere (8.6 ms per 16-token chunk; 1-2 waves starve wo / w2, 8-16 waves lose to the combine).
-template <int MODE, int NW>
+// TWO (QKV / WO / W2): the workgroup owns two adjacent 16-row tiles that share every activation fragment, the way
+// W13 always shares it between w1 and w3 -- half the activation-panel reads from L2 and 1.5 instead of 2
+// v_cvt_f64_f32 per MFMA.  Needs the matrix height to be a multiple of 32 (the host falls back to one tile).
+template <int MODE, int NW, bool TWO, int UN>
 __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
-  __shared__ double part[(MODE == MODE_W13) ? 2 : 1][NW > 1 ? NW - 1 : 1][4][64];   // [tile (W13 has two)][waves 1..NW-1][reg][lane]
+  constexpr bool DUAL = (MODE == MODE_W13) || TWO;   // a second weight stream on the same activations
+  __shared__ double part[DUAL ? 2 : 1][NW > 1 ? NW - 1 : 1][4][64];   // [stream][waves 1..NW-1][reg][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = a.n, nblk = n >> 4;                 // 16-column blocks
-  const int row0 = blockIdx.x * 16;                 // output rows of this tile
+  const int row0 = blockIdx.x * ((TWO && MODE != MODE_W13) ? 32 : 16);   // first output row of this workgroup
   int m = 0, i0 = row0;
   const float* wbase = a.w0;
   if (MODE == MODE_QKV) { m = row0 / a.dim; i0 = row0 - m * a.dim; wbase = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2; }
   const int j = lane & 15, kq = lane >> 4;
   const float* wrow = wbase + (size_t)(i0 + j) * n + 4 * kq;
-  const float* wrow3 = (MODE == MODE_W13) ? a.w1 + (size_t)(i0 + j) * n + 4 * kq : nullptr;
+  const float* wrow3 = (MODE == MODE_W13) ? a.w1 + (size_t)(i0 + j) * n + 4 * kq          // w3, same rows
+                       : (TWO ? wbase + (size_t)(i0 + 16 + j) * n + 4 * kq : nullptr);   // the tile below
   const float* xrow = a.xin + (size_t)j * n + 4 * kq;       // token j as the A row
 
   // two independent accumulator chains per tile (even / odd k steps): a dependent MFMA cannot issue back to back
   d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0}, acc3b = {0.0, 0.0, 0.0, 0.0};
-  constexpr int UN = 4;                              // 16-column blocks per batch (two register sets of them)
+  // UN = 16-column blocks per batch (two register sets of them)
   // a wave takes UN ADJACENT 16-column blocks per batch (256 contiguous bytes of every weight row: DRAM pages see
   // runs, not 64-byte pieces), batches round-robin over the NW waves; batch b+1 loads while batch b is on the matrix pipe
   const int npair = (nblk + UN - 1) / UN;            // batches of UN blocks
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
     for (int u = 0; u < UN; ++u) {
       const int sb = min(blk(p0, u), nblk - 1);     // clamped (never predicated) loads; masked in mma()
       b.wv[u] = ldg_nt(wrow + 16 * sb);
-      if (MODE == MODE_W13) b.w3[u] = ldg_nt(wrow3 + 16 * sb);
+      if (DUAL) b.w3[u] = ldg_nt(wrow3 + 16 * sb);
       b.xv[u] = *reinterpret_cast<const f4*>(xrow + 16 * sb);
     }
   };
@@ -110,13 +115,13 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
         const double x0 = b.xv[u].x, x1 = b.xv[u].y, x2 = b.xv[u].z, x3 = b.xv[u].w;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)b.wv[u].x, acc, 0, 0, 0);
         accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)b.wv[u].y, accb, 0, 0, 0);
-        if (MODE == MODE_W13) {
+        if (DUAL) {
           acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)b.w3[u].x, acc3, 0, 0, 0);
           acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)b.w3[u].y, acc3b, 0, 0, 0);
         }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)b.wv[u].z, acc, 0, 0, 0);
         accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)b.wv[u].w, accb, 0, 0, 0);
-        if (MODE == MODE_W13) {
+        if (DUAL) {
           acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)b.w3[u].z, acc3, 0, 0, 0);
           acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)b.w3[u].w, acc3b, 0, 0, 0);
         }
@@ -144,7 +149,7 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       part[0][wave - 1][r][lane] = acc[r];
-      if (MODE == MODE_W13) part[(MODE == MODE_W13) ? 1 : 0][wave - 1][r][lane] = acc3[r];
+      if (DUAL) part[DUAL ? 1 : 0][wave - 1][r][lane] = acc3[r];
     }
   }
   __syncthreads();
@@ -154,41 +159,45 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
 #pragma unroll
     for (int w = 0; w < NW - 1; ++w) {
       acc[r] += part[0][w][r][lane];
-      if (MODE == MODE_W13) acc3[r] += part[(MODE == MODE_W13) ? 1 : 0][w][r][lane];
+      if (DUAL) acc3[r] += part[DUAL ? 1 : 0][w][r][lane];
     }
   }
 
-  // ---- epilogue: lane holds tokens t = kq + 4r (r = 0..3) of output index i = i0 + j
-  const int i = i0 + j;
+  // ---- epilogue: lane holds tokens t = kq + 4r (r = 0..3) of output index i = i0 + j (and i + 16 for the second tile)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int t = kq + 4 * r;
-    const float sv = (float)acc[r];                                  // matmul store (llama2.ts:201)
-    if (MODE == MODE_QKV) {
-      const int pos = a.pos0 + t;
-      if (m == 2) {
-        if (t < a.nvalid) a.vc[(size_t)pos * a.dim + i] = sv;         // llama2.ts:240
-      } else {
-        // RoPE pair (i even, i+1) sits in adjacent lanes (llama2.ts:224-235)
-        const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv), 0xB1, 0xf, 0xf, false));
-        const float s0 = (j & 1) ? other : sv, s1 = (j & 1) ? sv : other;
-        const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
-        const int cidx = (t < a.nvalid) ? idx : 0;
-        const double fcr = a.fr[cidx], fci = a.fi[cidx];
-        const float o = (j & 1) ? (float)((double)s0 * fci + (double)s1 * fcr) : (float)((double)s0 * fcr - (double)s1 * fci);
-        if (t < a.nvalid) {
-          if (m == 0) a.out[(size_t)t * a.dim + i] = o;
-          else a.kc[(size_t)pos * a.dim + i] = o;                      // llama2.ts:239
+  for (int tile = 0; tile < ((TWO && MODE != MODE_W13) ? 2 : 1); ++tile) {
+    const int i = i0 + 16 * tile + j;
+    const d4 av = tile ? acc3 : acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = kq + 4 * r;
+      const float sv = (float)av[r];                                  // matmul store (llama2.ts:201)
+      if (MODE == MODE_QKV) {
+        const int pos = a.pos0 + t;
+        if (m == 2) {
+          if (t < a.nvalid) a.vc[(size_t)pos * a.dim + i] = sv;         // llama2.ts:240
+        } else {
+          // RoPE pair (i even, i+1) sits in adjacent lanes (llama2.ts:224-235)
+          const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv), 0xB1, 0xf, 0xf, false));
+          const float s0 = (j & 1) ? other : sv, s1 = (j & 1) ? sv : other;
+          const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
+          const int cidx = (t < a.nvalid) ? idx : 0;
+          const double fcr = a.fr[cidx], fci = a.fi[cidx];
+          const float o = (j & 1) ? (float)((double)s0 * fci + (double)s1 * fcr) : (float)((double)s0 * fcr - (double)s1 * fci);
+          if (t < a.nvalid) {
+            if (m == 0) a.out[(size_t)t * a.dim + i] = o;
+            else a.kc[(size_t)pos * a.dim + i] = o;                      // llama2.ts:239
+          }
         }
+      } else if (MODE == MODE_W13) {
+        const float h1 = sv, h3 = (float)acc3[r];
+        const double v = h1;
+        const float sl = (float)(v * (1.0 / (1.0 + exp(-v))));          // llama2.ts:285
+        a.out[(size_t)t * a.rows + i] = (float)((double)sl * (double)h3);  // llama2.ts:289
+      } else {   // WO / W2: residual accum (llama2.ts:273, 295)
+        float* xp = a.x + (size_t)t * a.dim + i;
+        *xp = *xp + sv;
       }
-    } else if (MODE == MODE_W13) {
-      const float h1 = sv, h3 = (float)acc3[r];
-      const double v = h1;
-      const float sl = (float)(v * (1.0 / (1.0 + exp(-v))));          // llama2.ts:285
-      a.out[(size_t)t * a.rows + i] = (float)((double)sl * (double)h3);  // llama2.ts:289
-    } else {   // WO / W2: residual accum (llama2.ts:273, 295)
-      float* xp = a.x + (size_t)t * a.dim + i;
-      *xp = *xp + sv;
     }
   }
 }
