@@ -161,6 +161,7 @@ struct l2_ctx {
   unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int pf_two_tiles = 0;             // L2_PF_TWO_TILES=1: prefill GEMMs take two 16-row tiles per workgroup (measured slower)
+  int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int pf_un = 4;                    // L2_PF_UN: 16-column blocks per register set in the prefill GEMMs (4 or 8)
   int cur_splits = 1;               // split count of the step being enqueued / captured
   unsigned* head_done = nullptr;    // [H] fused QKV+attention hand-off counters, zero between launches
@@ -361,6 +362,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->attn_splits_forced = env_int("L2_ATTN_SPLITS", 0);
   c->pf_two_tiles = env_int("L2_PF_TWO_TILES", 0);
   c->pf_un = env_int("L2_PF_UN", 4);
+  c->pf_lds = env_int("L2_PF_LDS", 1);
   if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;
   {
     const size_t rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;
@@ -1183,6 +1185,13 @@ static bool can_prefill(const l2_ctx* c) {
 // matrix height allows it and L2_PF_TWO_TILES=1 (opt-in: measured slower, fewer bytes in flight).
 template <int MODE>
 static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, hipStream_t st) {
+  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1)) {   // weight tile through LDS (row-shaped global loads); W13 only with L2_PF_LDS=2: its two tiles per wave measured slower (99 vs 96 us)
+    const size_t lds = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4>), dim3(a.rows / 16), dim3(256), lds, st, a);
+    return;
+  }
   const int mrows = (MODE == MODE_QKV) ? a.dim : a.rows;
   const bool two = (MODE != MODE_W13) && c->pf_two_tiles && (mrows % 32 == 0);
   const int grid = a.rows / (two ? 32 : 16);

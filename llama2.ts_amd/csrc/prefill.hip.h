@@ -70,6 +70,42 @@ __global__ void __launch_bounds__(256) pf_norm_kernel(float* xn, const float* x,
   for (int j = tid + 256 * MAXE; j < dim; j += 256) xn[(size_t)t * dim + j] = (float)((double)w[j] * (ss * (double)xr[j]));
 }
 
+// Epilogue of one 16-row tile: the lane holds tokens t = kq + 4r (r = 0..3) of output index i.
+template <int MODE>
+__device__ __forceinline__ void pf_emit(const PfArgs& a, const d4& av, const d4& acc3, int m, int i, int j, int kq) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = kq + 4 * r;
+    const float sv = (float)av[r];                                  // matmul store (llama2.ts:201)
+    if (MODE == MODE_QKV) {
+      const int pos = a.pos0 + t;
+      if (m == 2) {
+        if (t < a.nvalid) a.vc[(size_t)pos * a.dim + i] = sv;         // llama2.ts:240
+      } else {
+        // RoPE pair (i even, i+1) sits in adjacent lanes (llama2.ts:224-235)
+        const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv), 0xB1, 0xf, 0xf, false));
+        const float s0 = (j & 1) ? other : sv, s1 = (j & 1) ? sv : other;
+        const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
+        const int cidx = (t < a.nvalid) ? idx : 0;
+        const double fcr = a.fr[cidx], fci = a.fi[cidx];
+        const float o = (j & 1) ? (float)((double)s0 * fci + (double)s1 * fcr) : (float)((double)s0 * fcr - (double)s1 * fci);
+        if (t < a.nvalid) {
+          if (m == 0) a.out[(size_t)t * a.dim + i] = o;
+          else a.kc[(size_t)pos * a.dim + i] = o;                      // llama2.ts:239
+        }
+      }
+    } else if (MODE == MODE_W13) {
+      const float h1 = sv, h3 = (float)acc3[r];
+      const double v = h1;
+      const float sl = (float)(v * (1.0 / (1.0 + exp(-v))));          // llama2.ts:285
+      a.out[(size_t)t * a.rows + i] = (float)((double)sl * (double)h3);  // llama2.ts:289
+    } else {   // WO / W2: residual accum (llama2.ts:273, 295)
+      float* xp = a.x + (size_t)t * a.dim + i;
+      *xp = *xp + sv;
+    }
+  }
+}
+
 // NW waves per workgroup share one 16-row tile and split K NW ways.  Measured (7B shapes, L2_PF_NW_*): 4 waves per
 // tile is best everywhere (8.6 ms per 16-token chunk; 1-2 waves starve wo / w2, 8-16 waves lose to the combine).
 // TWO (QKV / WO / W2): the workgroup owns two adjacent 16-row tiles that share every activation fragment, the way
@@ -163,43 +199,114 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
     }
   }
 
-  // ---- epilogue: lane holds tokens t = kq + 4r (r = 0..3) of output index i = i0 + j (and i + 16 for the second tile)
+  // ---- epilogue (second tile: i + 16)
 #pragma unroll
-  for (int tile = 0; tile < ((TWO && MODE != MODE_W13) ? 2 : 1); ++tile) {
-    const int i = i0 + 16 * tile + j;
-    const d4 av = tile ? acc3 : acc;
+  for (int tile = 0; tile < ((TWO && MODE != MODE_W13) ? 2 : 1); ++tile) pf_emit<MODE>(a, tile ? acc3 : acc, acc3, m, i0 + 16 * tile + j, j, kq);
+}
+
+// The same GEMM with the weight tile taken through LDS.  pf_gemm_kernel's loads follow the MFMA operand layout: one
+// instruction = 16 rows x 64 B, and tools/microbench_pattern.hip shows that shape alone caps a pure stream at
+// 4.7 TB/s on this chip, against 6.0 TB/s for 1 KB-per-row instructions.  Here a wave requests its 16 x 128-column
+// chunk as 8 instructions of 2 rows x 512 contiguous bytes, parks it in a wave-private LDS tile (row stride 132
+// floats: both the row-shaped writes and the (row j, piece kq) reads are conflict-free) and reads the B fragments
+// back in MFMA layout.  Activations still come straight from L2 in operand layout.  Measured on 7B shapes: QKV
+// 60.6 -> 54.5 us, W2 56.5 -> 49.7, WO unchanged, W13 (two tiles per wave) 96 -> 99: the load shape was worth ~10 %,
+// the rest of the gap to the 33 us stream time is MFMA / widening time that the few resident waves do not overlap.
+template <int MODE, int NW>
+__global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
+  constexpr bool DUAL = (MODE == MODE_W13);
+  constexpr int KC = 128, KB = KC / 16, WS = KC + 4, TILE = 16 * WS;      // floats
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.n, nblk = n >> 4, nch = (n + KC - 1) / KC;
+  const int row0 = blockIdx.x * 16;
+  int m = 0, i0 = row0;
+  const float* wbase = a.w0;
+  if (MODE == MODE_QKV) { m = row0 / a.dim; i0 = row0 - m * a.dim; wbase = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2; }
+  const int j = lane & 15, kq = lane >> 4, lr = lane >> 5, lc = lane & 31;
+  const float* wl = wbase + (size_t)(i0 + lr) * n;                        // row-shaped: instruction i = rows 2i, 2i + 1
+  const float* wl3 = DUAL ? a.w1 + (size_t)(i0 + lr) * n : nullptr;
+  const float* xrow = a.xin + (size_t)j * n + 4 * kq;
+  float* tile = lds + (size_t)wave * (DUAL ? 2 : 1) * TILE;
+  float* tile3 = tile + TILE;
+
+  d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0}, acc3b = {0.0, 0.0, 0.0, 0.0};
+  struct Batch { f4 wv[KB], w3[DUAL ? KB : 1], xv[KB]; };
+  auto load = [&](Batch& b, int p) {
+    const int pc = min(p, nch - 1);
+    const int col = min(pc * KC + 4 * lc, n - 4);                         // clamped, never predicated; masked in mma()
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int t = kq + 4 * r;
-      const float sv = (float)av[r];                                  // matmul store (llama2.ts:201)
-      if (MODE == MODE_QKV) {
-        const int pos = a.pos0 + t;
-        if (m == 2) {
-          if (t < a.nvalid) a.vc[(size_t)pos * a.dim + i] = sv;         // llama2.ts:240
-        } else {
-          // RoPE pair (i even, i+1) sits in adjacent lanes (llama2.ts:224-235)
-          const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv), 0xB1, 0xf, 0xf, false));
-          const float s0 = (j & 1) ? other : sv, s1 = (j & 1) ? sv : other;
-          const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
-          const int cidx = (t < a.nvalid) ? idx : 0;
-          const double fcr = a.fr[cidx], fci = a.fi[cidx];
-          const float o = (j & 1) ? (float)((double)s0 * fci + (double)s1 * fcr) : (float)((double)s0 * fcr - (double)s1 * fci);
-          if (t < a.nvalid) {
-            if (m == 0) a.out[(size_t)t * a.dim + i] = o;
-            else a.kc[(size_t)pos * a.dim + i] = o;                      // llama2.ts:239
-          }
+    for (int i = 0; i < KB; ++i) {
+      b.wv[i] = ldg_nt(wl + (size_t)(2 * i) * n + col);
+      if (DUAL) b.w3[i] = ldg_nt(wl3 + (size_t)(2 * i) * n + col);
+    }
+#pragma unroll
+    for (int u = 0; u < KB; ++u) b.xv[u] = *reinterpret_cast<const f4*>(xrow + 16 * min(pc * KB + u, nblk - 1));
+  };
+  auto mma = [&](const Batch& b, int p) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      *reinterpret_cast<f4*>(tile + (2 * i + lr) * WS + 4 * lc) = b.wv[i];
+      if (DUAL) *reinterpret_cast<f4*>(tile3 + (2 * i + lr) * WS + 4 * lc) = b.w3[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                // the tile is written and read by one wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      if (p * KB + u < nblk) {
+        const f4 wv = *reinterpret_cast<const f4*>(tile + j * WS + 16 * u + 4 * kq);
+        const double x0 = b.xv[u].x, x1 = b.xv[u].y, x2 = b.xv[u].z, x3 = b.xv[u].w;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)wv.x, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)wv.y, accb, 0, 0, 0);
+        if (DUAL) {
+          const f4 w3 = *reinterpret_cast<const f4*>(tile3 + j * WS + 16 * u + 4 * kq);
+          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)w3.x, acc3, 0, 0, 0);
+          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)w3.y, acc3b, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)w3.z, acc3, 0, 0, 0);
+          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)w3.w, acc3b, 0, 0, 0);
         }
-      } else if (MODE == MODE_W13) {
-        const float h1 = sv, h3 = (float)acc3[r];
-        const double v = h1;
-        const float sl = (float)(v * (1.0 / (1.0 + exp(-v))));          // llama2.ts:285
-        a.out[(size_t)t * a.rows + i] = (float)((double)sl * (double)h3);  // llama2.ts:289
-      } else {   // WO / W2: residual accum (llama2.ts:273, 295)
-        float* xp = a.x + (size_t)t * a.dim + i;
-        *xp = *xp + sv;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)wv.z, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)wv.w, accb, 0, 0, 0);
       }
     }
+    __builtin_amdgcn_wave_barrier();
+  };
+  Batch A, B;
+  int p0 = wave;
+  if (p0 < nch) load(A, p0);
+  while (p0 < nch) {
+    const int p1 = p0 + NW;
+    load(B, p1 < nch ? p1 : p0);
+    mma(A, p0);
+    if (p1 >= nch) break;
+    const int p2 = p1 + NW;
+    load(A, p2 < nch ? p2 : p1);
+    mma(B, p1);
+    p0 = p2;
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r] += accb[r]; acc3[r] += acc3b[r]; }
+  __syncthreads();                                                          // tiles are dead: reuse the LDS for the split-K partials
+  double* part = reinterpret_cast<double*>(lds);                            // [stream][waves 1..NW-1][reg][lane]
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      part[((0 * (NW - 1) + wave - 1) * 4 + r) * 64 + lane] = acc[r];
+      if (DUAL) part[((1 * (NW - 1) + wave - 1) * 4 + r) * 64 + lane] = acc3[r];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+      acc[r] += part[((0 * (NW - 1) + w) * 4 + r) * 64 + lane];
+      if (DUAL) acc3[r] += part[((1 * (NW - 1) + w) * 4 + r) * 64 + lane];
+    }
+  }
+  pf_emit<MODE>(a, acc, acc3, m, i0 + j, j, kq);
 }
 
 }  // namespace l2k
