@@ -132,3 +132,39 @@ def test_tensor_parallel_group_matches_reference(name, G, steps):
         assert np.array_equal(logits, out[0][0])          # identical on every rank
         if meta["tokens_fed"][:steps] == [1] + meta["argmax"][:steps - 1]:   # the golden run was greedy from BOS
             assert toks == meta["argmax"][:steps]
+
+
+def test_tensor_parallel_group_samples_like_a_single_rank():
+    """l2_decode_sample on a 2-rank group: every rank samples from the gathered logits with the same seed, so all ranks
+    and the single-GPU context must produce the same token ids and the same advanced RNG state."""
+    import threading
+    hdr = configs.header("tiny")
+    single = runtime.Context(hdr)
+    single.synth_fill(3)
+    want, want_rng = single.decode_sample(1, 0, 20, 0.8, 0.9, 1234)
+    single.close()
+    G, gid = 2, bytes([9] * 128)
+    out, errs = [None] * G, [None] * G
+
+    def rank_main(r):
+        try:
+            ctx = runtime.Context(hdr, tp_rank=r, tp_size=G, nccl_id=gid)
+            ctx.synth_fill(3)
+            out[r] = ctx.decode_sample(1, 0, 20, 0.8, 0.9, 1234)
+            ctx.close()
+        except BaseException as e:
+            errs[r] = e
+
+    os.environ["L2_TP_LOOPBACK"] = "1"
+    try:
+        ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+        [t.start() for t in ts]
+        [t.join(120) for t in ts]
+        assert not any(t.is_alive() for t in ts)
+    finally:
+        del os.environ["L2_TP_LOOPBACK"]
+    for e in errs:
+        if e is not None:
+            raise e
+    for r in range(G):
+        assert out[r][0].tolist() == want.tolist() and out[r][1] == want_rng
