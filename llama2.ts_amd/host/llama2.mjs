@@ -361,7 +361,18 @@ function main() {
     token = next;
     if (start == 0) start = Date.now();
   }
-  console.log("\n\nachieved tok/s: %f\n", (pos - 1) / (Date.now() - start) * 1000.0);
+  const elapsed_ms = Date.now() - start;
+  console.log("\n\nachieved tok/s: %f\n", (pos - 1) / elapsed_ms * 1000.0);
+  if (process.env.L2_STATS == "1") {
+    // opt-in, on stderr so that stdout stays what the reference prints: the same rate against the HBM roofline,
+    // with SURVEY.md 8(d)'s algorithmic bytes per token averaged over the positions of this run
+    const d = config.dim, h = config.hidden_dim, L = config.n_layers, V = config.vocab_size, hs = d / config.n_heads;
+    let bytes = 0;
+    for (let q = 1; q < pos; q++) bytes += 4 * (L * (4 * d * d + 3 * d * h + 2 * d) + d + V * d + d + L * (2 * (q + 1) * d + 2 * d) + hs) + 4 * V;
+    const tok_s = (pos - 1) / elapsed_ms * 1000.0, bpt = pos > 1 ? bytes / (pos - 1) : 0;
+    console.error(JSON.stringify({ tokens_timed: pos - 1, tok_s, algorithmic_bytes_per_token: Math.round(bpt),
+      hbm_gbs: bpt * tok_s / 1e9, hbm_frac_of_8tbs: bpt * tok_s / 8e12 }));
+  }
   be.destroy(ctx);
 }
 

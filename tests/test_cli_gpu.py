@@ -71,6 +71,16 @@ def test_cli_device_sampler_extra_prints_the_same(workdir, name):
         assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
 
 
+def test_cli_stats_line_goes_to_stderr_only(workdir):
+    meta = json.load(open(os.path.join(GOLD, "cli_greedy.json")))
+    rc, out, err = run_cli(workdir, meta["argv"], {"L2_STATS": "1"})
+    assert rc == 0, err
+    assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])          # stdout untouched
+    stats = json.loads(err.strip().splitlines()[-1])
+    assert stats["tokens_timed"] == meta["steps_run"] - 1 and stats["algorithmic_bytes_per_token"] > 60_000_000
+    assert 0 < stats["hbm_frac_of_8tbs"] < 1
+
+
 def test_cli_usage_and_errors(workdir):
     r = subprocess.run(["node", HOST], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and r.stderr.decode().startswith("Usage: ... llama2.ts <checkpoint> [options]")
