@@ -1356,6 +1356,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   for (int s = 0; s < steps; ++s) {
     const int lvl = split_level(c, pos0 + s);
     c->cur_splits = splits_of(c, lvl);
+    if (can_chain(c)) { rc = build_chain(c, lvl, 0); if (rc) return rc; }   // experimental chain launch: allocations before any enqueue
     if (graph) {
       hipGraphExec_t& g = c->g_sample[lvl][c->samp_mode];
       if (!g) { rc = capture(c, enqueue_sample, &g); if (rc) return rc; }

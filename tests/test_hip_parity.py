@@ -467,3 +467,16 @@ def test_sampler_serial_and_parallel_forms_agree(monkeypatch):
         runs[serial] = [ctx.decode_sample(1, 0, 24, t, p, 9)[0].tolist() for t, p in ((0.9, 1.0), (1.3, 0.8))]
         ctx.close()
     assert runs["0"] == runs["1"]
+
+
+def test_device_sampler_with_the_experimental_chain_launch():
+    """l2_decode_sample must give the same ids whichever launch form produces the logits (L2_OPT_MEGAKERNEL)."""
+    hdr = configs.header("stories15M")
+    a = runtime.Context(hdr); a.synth_fill(1)
+    want, _ = a.decode_sample(1, 0, 12, 0.9, 0.9, 5)
+    a.close()
+    b = runtime.Context(hdr); b.synth_fill(1)
+    b.set_option(3, 1)
+    got, _ = b.decode_sample(1, 0, 12, 0.9, 0.9, 5)
+    b.close()
+    assert got.tolist() == want.tolist()
