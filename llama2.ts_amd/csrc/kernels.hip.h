@@ -584,6 +584,7 @@ struct AttnArgs {
   int exact;             // 1: fp32-rounded t-sequential value accumulate (llama2.ts:263)
   int pos_plus1;         // prefill: position of this query + 1 (0: read it from tokpos)
   int lpr;               // lanes per timestep row (power of two >= ceil(head_size / vecw))
+  int xb_sc1;            // 1: publish xb write-through (consumed by other workgroups of the same launch: attn_wo_kernel)
 };
 
 __device__ __forceinline__ unsigned ld_sc1(const unsigned* p) {
@@ -745,7 +746,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
         for (int j = 0; j < W; ++j) o[j] = (float)((double)o[j] + at * (double)vn[e0 + j]);
       }
 #pragma unroll
-      for (int j = 0; j < W; ++j) { if (a.fused == 2) st_sc1(a.xb + (size_t)h * hs + e0 + j, o[j]); else a.xb[(size_t)h * hs + e0 + j] = o[j]; }
+      for (int j = 0; j < W; ++j) { if (a.fused == 2 || a.xb_sc1) st_sc1(a.xb + (size_t)h * hs + e0 + j, o[j]); else a.xb[(size_t)h * hs + e0 + j] = o[j]; }
     }
   } else {
     double o[W];
@@ -779,7 +780,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
     for (int i = tid; i < hs; i += 256) {
       double sacc = 0.0;
       for (int g2 = 0; g2 < G; ++g2) sacc += pacc[(size_t)g2 * hs + i];
-      if (a.fused == 2) st_sc1(a.xb + (size_t)h * hs + i, (float)sacc); else a.xb[(size_t)h * hs + i] = (float)sacc;
+      if (a.fused == 2 || a.xb_sc1) st_sc1(a.xb + (size_t)h * hs + i, (float)sacc); else a.xb[(size_t)h * hs + i] = (float)sacc;
     }
     STAMP(5);
   }
@@ -789,6 +790,234 @@ template <bool VEC>
 __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   attn_body<VEC>(a, smem, blockIdx.x);
+}
+
+// Attention with every load up front (pos < 256, head_size = 4 NQ in {64, 128}; the default for those shapes, and the
+// attention half of the fused attention + wo launch): EVERY cache byte the head needs is requested in the first few
+// hundred cycles of the launch -- threads 0..255 their timestep's K row,
+// threads 256..511 up to NQ V rows per NQ-lane group, then q / k / v of this position -- because a moment later the
+// other workgroups flood HBM with wo and any load issued after that waits behind 67 MB (measured: the ordinary
+// body takes 12 us instead of 6 inside the fused launch).  After the requests the head runs from registers and LDS.
+// Same per-thread score order as attn_body (bit-identical scores); value sums are fp64 partials as there.
+template <int NQ>
+__device__ __forceinline__ void attn_pre_body(const AttnArgs& a, char* smem, const int h) {
+  constexpr int hs = 4 * NQ, G = 256 / NQ;                    // V side: G groups of NQ lanes, rows t = grp + G b
+  const int S = a.seq_len, dim = a.dim;
+  float* att = reinterpret_cast<float*>(smem);               // S floats (same layout as attn_body: attn_lds sizes it)
+  float* kn = att + ((S + 3) & ~3);
+  float* vn = kn + hs;
+  double* qs = reinterpret_cast<double*>(vn + hs);
+  double* red = qs + hs;
+  double* pacc = red + 8;                                    // G * hs doubles
+  const int tid = threadIdx.x;
+  const int pos = a.tokpos[1];
+  const bool kside = tid < 256;
+  const int vt = tid - 256, sub = vt & (NQ - 1), grp = vt / NQ;
+  const int last = max(pos - 1, 0);
+  STAMP(0);
+  f4 r[NQ];                                                   // K side: the timestep's row; V side: rows grp + G b, column sub
+  if (kside) {
+    const float* kp = a.kc + (size_t)min(tid, last) * dim + (size_t)h * hs;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) r[i] = reinterpret_cast<const f4*>(kp)[i];
+  } else {
+    const float* vp = a.vc + (size_t)h * hs + 4 * sub;
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) r[b] = *reinterpret_cast<const f4*>(vp + (size_t)min(grp + G * b, last) * dim);
+  }
+  for (int i = tid; i < hs; i += 512) {
+    qs[i] = (double)a.q[(size_t)h * hs + i];
+    kn[i] = a.knew[(size_t)h * hs + i];
+    vn[i] = a.vnew[(size_t)h * hs + i];
+  }
+  __syncthreads();
+  STAMP(1);
+  const double rsq = sqrt((double)hs);
+  if (kside) {                                                // scores (llama2.ts:249-254), same chains as head_dot
+    const d2* q2 = reinterpret_cast<const d2*>(qs);
+    if (tid < pos) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const d2 qa = q2[2 * i], qb = q2[2 * i + 1];
+        s0 += qa.x * (double)r[i].x; s1 += qa.y * (double)r[i].y; s2 += qb.x * (double)r[i].z; s3 += qb.y * (double)r[i].w;
+      }
+      att[tid] = (float)(((s0 + s1) + (s2 + s3)) / rsq);
+    }
+    if (tid == pos) att[pos] = (float)(head_dot<true>(qs, kn, hs) / rsq);
+  }
+  __syncthreads();
+  STAMP(2);
+  // softmax (llama2.ts:181-194) by the K side; the V side only keeps the barriers
+  float mx = -INFINITY;
+  if (kside && tid <= pos) mx = att[tid];
+  mx = wave_max(mx);
+  float* redf = reinterpret_cast<float*>(red);
+  if (kside && (tid & 63) == 0) redf[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+  double lsum = 0.0;
+  if (kside && tid <= pos) {
+    const float e = (float)exp((double)att[tid] - (double)mx);    // stored to fp32 (llama2.ts:187)
+    att[tid] = e;
+    lsum = (double)e;
+  }
+  __syncthreads();                                            // red is reused below
+  lsum = wave_sum(lsum);
+  if (kside && (tid & 63) == 0) red[tid >> 6] = lsum;
+  __syncthreads();
+  const double sum = ((red[0] + red[1]) + red[2]) + red[3];
+  if (kside && tid <= pos) {
+    const float pr = (float)((double)att[tid] / sum);          // llama2.ts:192
+    att[tid] = pr;
+    if (a.att) a.att[(size_t)h * S + tid] = pr;
+  }
+  __syncthreads();
+  STAMP(3);
+  if (!kside) {                                                // weighted sum of values (llama2.ts:257-265), fp64 partial per group
+    double o[4] = {0.0, 0.0, 0.0, 0.0}, e[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+      const int t = grp + G * b;
+      const double at = (t < pos) ? (double)att[t] : 0.0;
+      if (b & 1) { e[0] += at * (double)r[b].x; e[1] += at * (double)r[b].y; e[2] += at * (double)r[b].z; e[3] += at * (double)r[b].w; }
+      else { o[0] += at * (double)r[b].x; o[1] += at * (double)r[b].y; o[2] += at * (double)r[b].z; o[3] += at * (double)r[b].w; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += e[j];
+    if (grp == (pos % G)) {
+      const double at = att[pos];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += at * (double)vn[4 * sub + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pacc[(size_t)grp * hs + 4 * sub + j] = o[j];
+  }
+  STAMP(4);
+  __syncthreads();
+  for (int i = tid; i < hs; i += 512) {
+    double sacc = 0.0;
+    for (int g2 = 0; g2 < G; ++g2) sacc += pacc[(size_t)g2 * hs + i];
+    if (a.xb_sc1) st_sc1(a.xb + (size_t)h * hs + i, (float)sacc); else a.xb[(size_t)h * hs + i] = (float)sacc;
+  }
+  STAMP(5);
+}
+
+// The same body as its own launch: one 512-thread workgroup per head.
+template <int NQ>
+__global__ void __launch_bounds__(512) attn_pre_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_pre_body<NQ>(a, smem, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention + wo in ONE launch, with wo resident on chip.
+//
+// Attention keeps one workgroup per head busy (32 CUs on 7B) for ~7 us and reads almost nothing, then the wo GEMV
+// needs ~12 us to stream its 67 MB -- HBM idles through the first and the CUs through the second.  The register
+// files of the other CUs (512 KB each) hold far more than wo: here workgroups H .. grid-1 each REQUEST their
+// ~18 rows of wo into registers (16 float4 per lane per row) the moment the launch starts, while workgroups
+// 0 .. H-1 run the attention; when every head has published its slice of xb (write-through stores, drained, then one
+// agent-scope add per head on `ready`), the wo workgroups pull xb into LDS with L1-bypassing loads and finish
+// their rows from registers in ~1 us.  Waiters only wait on LOWER block ids (dispatched first), so nothing
+// depends on co-residency.  The last wo workgroup through the wait zeroes both counters for the next launch.
+struct WoRegArgs {
+  const float* w;       // wo[l] (rows, n) row-major
+  const float* xb;      // attention output (n floats), written by workgroups 0 .. n_attn-1 of this launch
+  const float* res;     // x: residual in (llama2.ts:273)
+  const float* emb;     // token embedding table when the residual is still the embedding row (layer 0), else null
+  float* out;           // x
+  float* aux;           // xb2 as the reference stores it (parity reads), or null
+  const int* tokpos;
+  unsigned* ready;      // attention workgroups done (own 128-B line)
+  unsigned* done;       // wo workgroups past the wait (own line)
+  int* err;
+  int rows, n, dim, n_attn;
+  int delay;            // 1024-cycle sleeps before the weight requests (experiments; 0)
+  unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
+};
+
+template <int NF4, int MAXR, int NQ>
+__global__ void __launch_bounds__(512) attn_wo_kernel(const AttnArgs aa, const WoRegArgs wa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < wa.n_attn) {
+    attn_pre_body<NQ>(aa, smem, blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's write-through stores are out
+    __syncthreads();
+    // relaxed: the data went out write-through and is drained; a release here would write back the whole L2
+    if (tid == 0) __hip_atomic_fetch_add(wa.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int b = (int)blockIdx.x - wa.n_attn, nb = (int)gridDim.x - wa.n_attn;
+#ifdef L2_STAMPS
+#define WSTAMP(k) do { if (wa.dbg && tid == 0 && (b == 0 || b == nb / 2 || b == nb - 1)) { unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); wa.dbg[((b == 0) ? 0 : (b == nb - 1) ? 2 : 1) * L2_NSTAMP + (k)] = t_; } } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
+  WSTAMP(0);
+  const int lane = tid & 63, wave = tid >> 6;                // 8 waves: wave w owns rows r0 + w, r0 + w + 8, ...
+  const int r0 = (int)(((long long)b * wa.rows) / nb), r1 = (int)(((long long)(b + 1) * wa.rows) / nb);
+  const int n4 = wa.n >> 2;
+  for (int d_ = 0; d_ < wa.delay; ++d_) __builtin_amdgcn_s_sleep(16);      // 16 * 64 = 1024 cycles per step
+  f4 w[MAXR][NF4];
+#pragma unroll
+  for (int q = 0; q < MAXR; ++q) {
+    const float* wr = wa.w + (size_t)min(r0 + wave + 8 * q, wa.rows - 1) * wa.n;      // clamped, never predicated
+#pragma unroll
+    for (int k = 0; k < NF4; ++k) w[q][k] = ldg_nt(wr + 4 * min(lane + 64 * k, n4 - 1));
+  }
+  const int token = wa.tokpos[0];
+  WSTAMP(1);
+#ifdef L2_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic only: when did this wave's weights land
+  WSTAMP(2);
+#endif
+  if (tid == 0) {
+    unsigned spins = 0;
+    // relaxed L1-bypassing polls (an acquire per poll would invalidate this XCD's L2 every iteration); xb is read with
+    // L1-bypassing loads afterwards and was never touched by this launch before
+    while (ld_sc1(wa.ready) < (unsigned)wa.n_attn) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) { *wa.err = 1; break; }      // never hang the GPU: give up, the host reports it
+    }
+  }
+  __syncthreads();
+  WSTAMP(3);
+  f4* xs = reinterpret_cast<f4*>(smem);                      // xb, zero padded to NF4 * 64 float4
+  const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = tid; i < NF4 * 64; i += 512) xs[i] = (i < n4) ? ld16_sc1(wa.xb, i, n4) : zero;
+  __syncthreads();
+  WSTAMP(4);
+#pragma unroll
+  for (int q = 0; q < MAXR; ++q) {
+    const int row = r0 + wave + 8 * q;
+    if (row < r1) {                                          // wave-uniform
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NF4; ++k) {
+        const f4 xv = xs[lane + 64 * k];                     // zero beyond n: the clamped duplicate weights drop out
+        s0 += (double)w[q][k].x * (double)xv.x; s1 += (double)w[q][k].y * (double)xv.y;
+        s2 += (double)w[q][k].z * (double)xv.z; s3 += (double)w[q][k].w * (double)xv.w;
+      }
+      const double acc = wave_sum((s0 + s1) + (s2 + s3));
+      if (lane == 0) {
+        const float xr = wa.emb ? wa.emb[(size_t)token * wa.dim + row] : wa.res[row];
+        const float mv = (float)acc;                         // xb2 as the reference stores it (llama2.ts:270)
+        wa.out[row] = xr + mv;                               // llama2.ts:273
+        if (wa.aux) wa.aux[row] = mv;
+      }
+    }
+  }
+  WSTAMP(5);
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(wa.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)nb - 1u) {                          // everyone is past the wait: re-arm for the next launch
+      __hip_atomic_store(wa.ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(wa.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // Prefill: grid (head, query).  Query p of the chunk sits at position pos0 + p and sees cache rows 0..pos0+p,

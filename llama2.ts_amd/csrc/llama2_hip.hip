@@ -165,6 +165,10 @@ struct l2_ctx {
   int pf_un = 4;                    // L2_PF_UN: 16-column blocks per register set in the prefill GEMMs (4 or 8)
   int cur_splits = 1;               // split count of the step being enqueued / captured
   unsigned* head_done = nullptr;    // [H] fused QKV+attention hand-off counters, zero between launches
+  unsigned* wo_sync = nullptr;      // attn_wo_kernel: {ready, done} counters on separate lines, zero between launches
+  int opt_fuse_wo = 0;              // L2_FUSE_WO=1: attention + register-resident wo in one launch (experimental, measured: no gain)
+  int attn_pre = 1;                 // L2_ATTN_PRE: 0 never, 1 (default) 64-wide heads, 2 also 128-wide: attention with every load up front
+  int n_cus = 256;
   int* h_err = nullptr;             // pinned + mapped: set by a kernel whose bounded wait gave up
   int* h_err_dev = nullptr;
   int opt_fuse = 0;                 // L2_FUSE_ATTN: attention inside the QKV launch (experimental)
@@ -269,6 +273,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->attn_counter) hipFree(c->attn_counter);
   for (hipEvent_t e : c->probe) hipEventDestroy(e);
   if (c->head_done) hipFree(c->head_done);
+  if (c->wo_sync) hipFree(c->wo_sync);
   if (c->chain_ctr) hipFree(c->chain_ctr);
   if (c->chain_act) hipFree(c->chain_act);
   { float* pb[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_xb, c->pf_hb}; for (float* b : pb) if (b) hipFree(b); if (c->pf_tok) hipFree(c->pf_tok); }
@@ -360,6 +365,9 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMemsetAsync(c->logits, 0, (size_t)V * 4, c->stream));
   // split attention scratch (sized for the largest split count)
   c->attn_splits_forced = env_int("L2_ATTN_SPLITS", 0);
+  c->opt_fuse_wo = env_int("L2_FUSE_WO", 0);
+  c->attn_pre = env_int("L2_ATTN_PRE", 1);
+  c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->pf_two_tiles = env_int("L2_PF_TWO_TILES", 0);
   c->pf_un = env_int("L2_PF_UN", 4);
   c->pf_lds = env_int("L2_PF_LDS", 1);
@@ -370,6 +378,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     CK(hipMalloc(&c->attn_part, (size_t)c->H_loc * maxs * rec * 8));
     CK(hipMalloc(&c->attn_counter, (size_t)c->H_loc * CTR_STRIDE * 4));
     CK(hipMemsetAsync(c->attn_counter, 0, (size_t)c->H_loc * CTR_STRIDE * 4, c->stream));
+    CK(hipMalloc(&c->wo_sync, 2 * CTR_STRIDE * 4));
+    CK(hipMemsetAsync(c->wo_sync, 0, 2 * CTR_STRIDE * 4, c->stream));
     CK(hipMalloc(&c->head_done, (size_t)c->H_loc * CTR_STRIDE * 4));
     CK(hipMemsetAsync(c->head_done, 0, (size_t)c->H_loc * CTR_STRIDE * 4, c->stream));
     CK(hipHostMalloc(&c->h_err, sizeof(int), hipHostMallocMapped));
@@ -770,7 +780,14 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
     if (vec) hipLaunchKernelGGL((attn_split_kernel<true>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((attn_split_kernel<false>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
   } else {
-    if (vec) hipLaunchKernelGGL((attn_kernel<true>), dim3(c->H_loc), dim3(256), lds, st, a);
+    // every load up front, 512 threads per head (kernels.hip.h: attn_pre_body): contexts below 256, 64- / 128-wide heads
+    // measured (same box): stories110M 3127 -> 3186 tok/s, Llama-2-7B 209.5 -> 207.5 (its 128-wide rows make the up-front
+    // request phase texture-bound), so by default only 64-wide heads take it (L2_ATTN_PRE=2: 128-wide too, 0: never)
+    const bool pre = vec && !c->opt_exact && c->attn_splits_forced == 0 && c->cur_splits <= 1 &&
+                     ((c->hs == 64 && c->attn_pre >= 1) || (c->hs == 128 && c->attn_pre >= 2));
+    if (pre && c->hs == 128) hipLaunchKernelGGL((attn_pre_kernel<32>), dim3(c->H_loc), dim3(512), lds, st, a);
+    else if (pre) hipLaunchKernelGGL((attn_pre_kernel<16>), dim3(c->H_loc), dim3(512), lds, st, a);
+    else if (vec) hipLaunchKernelGGL((attn_kernel<true>), dim3(c->H_loc), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((attn_kernel<false>), dim3(c->H_loc), dim3(256), lds, st, a);
   }
   return hipGetLastError();
@@ -778,6 +795,47 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
 
 // rmsnorm + QKV + RoPE + KV store + attention of layer l in one launch (qkv_attn_kernel).
 static bool can_fuse_attn(const l2_ctx* c) { return c->opt_fuse && attn_vec(c) && (c->d % 4 == 0); }
+
+// attention + register-resident wo in one launch (kernels.hip.h: attn_wo_kernel).  One workgroup per CU: H of them
+// run the attention, the rest hold wo.  Shapes map onto the instantiated (float4 per lane per row, rows per wave).
+static int fuse_wo_shape(const l2_ctx* c, int* nf4, int* maxr) {
+  const int nwo = c->n_cus - c->H_loc;
+  if (nwo < 8 || c->d % 4) return 0;
+  *nf4 = (c->d / 4 + 63) / 64;
+  const int rows_wg = (c->d + nwo - 1) / nwo;
+  *maxr = (rows_wg + 7) / 8;
+  return (*nf4 == 16 && *maxr == 3 && c->hs == 128) || (*nf4 == 3 && *maxr == 1 && c->hs == 64);   // the instantiated shapes: 7B, stories110M
+}
+static bool can_fuse_wo(const l2_ctx* c) {
+  int nf4, maxr;
+  return c->opt_fuse_wo && !c->tp_path && !c->opt_exact && c->cur_splits <= 1 && c->attn_splits_forced == 0 && attn_vec(c) && c->wo_sync && fuse_wo_shape(c, &nf4, &maxr);
+}
+
+static hipError_t launch_attn_wo(const l2_ctx* c, int l, hipStream_t st) {
+  AttnArgs a;
+  int G;
+  fill_attn_args(c, l, a, &G);
+  if (a.lpr > 64) return hipErrorInvalidValue;
+  a.xb_sc1 = 1;
+  WoRegArgs wa;
+  memset(&wa, 0, sizeof(wa));
+  wa.w = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l;
+  wa.xb = c->xb; wa.res = c->x; wa.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; wa.out = c->x; wa.aux = c->xb2;
+  wa.tokpos = c->tokpos; wa.ready = c->wo_sync; wa.done = c->wo_sync + CTR_STRIDE; wa.err = c->h_err_dev;
+  wa.rows = c->d; wa.n = c->d; wa.dim = c->d; wa.n_attn = c->H_loc;
+  wa.delay = env_int("L2_FUSE_WO_DELAY", 0);
+#ifdef L2_STAMPS
+  wa.dbg = c->dbg + 64 * 36 + 36;   // behind the attention stamps
+#endif
+  int nf4 = 0, maxr = 0;
+  fuse_wo_shape(c, &nf4, &maxr);
+  size_t lds = attn_lds(c, a, G, false);
+  if (lds < (size_t)nf4 * 64 * 16) lds = (size_t)nf4 * 64 * 16;
+  const dim3 grid(c->n_cus), block(512);
+  if (nf4 == 16) hipLaunchKernelGGL((attn_wo_kernel<16, 3, 32>), grid, block, lds, st, a, wa);
+  else hipLaunchKernelGGL((attn_wo_kernel<3, 1, 16>), grid, block, lds, st, a, wa);
+  return hipGetLastError();
+}
 
 static hipError_t launch_qkv_attn(const l2_ctx* c, int l, const PhaseArgs& pa_in, hipStream_t st) {
   PhaseArgs pa = pa_in;
@@ -1071,14 +1129,18 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
   if (can_chain(c)) return enqueue_chain(c, st, to_host, false);
   for (int l = 0; l < c->L; ++l) {
     PhaseArgs a = qkv_args(c, l);
+    bool fused_wo = false;
     if (can_fuse_attn(c)) {   // 1+2 in one launch: attention waits per head on the q/k/v rows of this position
       LCHK(launch_qkv_attn(c, l, a, st));
     } else {
       LCHK(launch_phase<MODE_QKV>(c, a, st));
-      LCHK(launch_attn(c, l, st));   // attention (llama2.ts:244-267)
+      if (can_fuse_wo(c)) { LCHK(launch_attn_wo(c, l, st)); fused_wo = true; }
+      else LCHK(launch_attn(c, l, st));   // attention (llama2.ts:244-267)
     }
-    a = wo_args(c, l);
-    LCHK(launch_phase<MODE_WO>(c, a, st));
+    if (!fused_wo) {
+      a = wo_args(c, l);
+      LCHK(launch_phase<MODE_WO>(c, a, st));
+    }
     if (c->tp_path) {
       { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->partial, c->xb2, c->tokpos, c->d);

@@ -480,3 +480,25 @@ def test_device_sampler_with_the_experimental_chain_launch():
     got, _ = b.decode_sample(1, 0, 12, 0.9, 0.9, 5)
     b.close()
     assert got.tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_FUSE_WO": "1"}), ("llama2_7b_L2", {"L2_ATTN_PRE": "2"}),
+                                      ("stories110M", {"L2_FUSE_WO": "1"}), ("stories110M", {"L2_ATTN_PRE": "0"})])
+def test_attention_launch_variants_match_reference(monkeypatch, name, env):
+    """Opt-in attention launch forms (attention with every load up front; attention + register-resident wo in one
+    launch) and the plain form for 64-wide heads: same goldens, same tolerance, tokens exact."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    meta, g = load_gold(name)
+    ctx = runtime.Context(meta["header"])
+    ctx.synth_fill(meta["seed"])
+    kept = meta.get("logit_positions") or list(range(len(g["logits"])))
+    for pos, tok in enumerate(meta["tokens_fed"]):
+        lg = ctx.forward(tok, pos)
+        assert runtime.argmax(lg) == meta["argmax"][pos]
+        if pos in kept:
+            assert np.abs(lg - g["logits"][kept.index(pos)]).max() <= 1e-4
+    n = len(meta["tokens_fed"])
+    if meta["tokens_fed"] == [1] + meta["argmax"][:n - 1]:
+        assert ctx.decode_greedy(1, 0, n).tolist() == meta["argmax"][:n]       # graph replay path too
+    ctx.close()
