@@ -799,7 +799,9 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 // other workgroups flood HBM with wo and any load issued after that waits behind 67 MB (measured: the ordinary
 // body takes 12 us instead of 6 inside the fused launch).  After the requests the head runs from registers and LDS.
 // Same per-thread score order as attn_body (bit-identical scores); value sums are fp64 partials as there.
-template <int NQ>
+// KPRE = false: the K side keeps attn_body's way (row loads where the dot uses them, overlapping the arithmetic) and only
+// the V rows are requested up front -- for 128-wide heads, whose up-front K request phase is texture-bound.
+template <int NQ, bool KPRE = true>
 __device__ __forceinline__ void attn_pre_body(const AttnArgs& a, char* smem, const int h) {
   constexpr int hs = 4 * NQ, G = 256 / NQ;                    // V side: G groups of NQ lanes, rows t = grp + G b
   const int S = a.seq_len, dim = a.dim;
@@ -817,9 +819,11 @@ __device__ __forceinline__ void attn_pre_body(const AttnArgs& a, char* smem, con
   STAMP(0);
   f4 r[NQ];                                                   // K side: the timestep's row; V side: rows grp + G b, column sub
   if (kside) {
-    const float* kp = a.kc + (size_t)min(tid, last) * dim + (size_t)h * hs;
+    if (KPRE) {
+      const float* kp = a.kc + (size_t)min(tid, last) * dim + (size_t)h * hs;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) r[i] = reinterpret_cast<const f4*>(kp)[i];
+      for (int i = 0; i < NQ; ++i) r[i] = reinterpret_cast<const f4*>(kp)[i];
+    }
   } else {
     const float* vp = a.vc + (size_t)h * hs + 4 * sub;
 #pragma unroll
@@ -836,13 +840,17 @@ __device__ __forceinline__ void attn_pre_body(const AttnArgs& a, char* smem, con
   if (kside) {                                                // scores (llama2.ts:249-254), same chains as head_dot
     const d2* q2 = reinterpret_cast<const d2*>(qs);
     if (tid < pos) {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      if (KPRE) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        const d2 qa = q2[2 * i], qb = q2[2 * i + 1];
-        s0 += qa.x * (double)r[i].x; s1 += qa.y * (double)r[i].y; s2 += qb.x * (double)r[i].z; s3 += qb.y * (double)r[i].w;
+        for (int i = 0; i < NQ; ++i) {
+          const d2 qa = q2[2 * i], qb = q2[2 * i + 1];
+          s0 += qa.x * (double)r[i].x; s1 += qa.y * (double)r[i].y; s2 += qb.x * (double)r[i].z; s3 += qb.y * (double)r[i].w;
+        }
+        att[tid] = (float)(((s0 + s1) + (s2 + s3)) / rsq);
+      } else {
+        att[tid] = (float)(head_dot<true>(qs, a.kc + (size_t)tid * dim + (size_t)h * hs, hs) / rsq);
       }
-      att[tid] = (float)(((s0 + s1) + (s2 + s3)) / rsq);
     }
     if (tid == pos) att[pos] = (float)(head_dot<true>(qs, kn, hs) / rsq);
   }
@@ -904,10 +912,10 @@ __device__ __forceinline__ void attn_pre_body(const AttnArgs& a, char* smem, con
 }
 
 // The same body as its own launch: one 512-thread workgroup per head.
-template <int NQ>
+template <int NQ, bool KPRE>
 __global__ void __launch_bounds__(512) attn_pre_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_pre_body<NQ>(a, smem, blockIdx.x);
+  attn_pre_body<NQ, KPRE>(a, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

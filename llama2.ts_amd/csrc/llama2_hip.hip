@@ -167,7 +167,7 @@ struct l2_ctx {
   unsigned* head_done = nullptr;    // [H] fused QKV+attention hand-off counters, zero between launches
   unsigned* wo_sync = nullptr;      // attn_wo_kernel: {ready, done} counters on separate lines, zero between launches
   int opt_fuse_wo = 0;              // L2_FUSE_WO=1: attention + register-resident wo in one launch (experimental, measured: no gain)
-  int attn_pre = 1;                 // L2_ATTN_PRE: 0 never, 1 (default) 64-wide heads, 2 also 128-wide: attention with every load up front
+  int attn_pre = 1;                 // L2_ATTN_PRE: attention with loads up front (launch_attn): 0 never, 1 (default) 64-wide heads, 2 also 128-wide, 3 V rows only
   int n_cus = 256;
   int* h_err = nullptr;             // pinned + mapped: set by a kernel whose bounded wait gave up
   int* h_err_dev = nullptr;
@@ -781,12 +781,17 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
     else hipLaunchKernelGGL((attn_split_kernel<false>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
   } else {
     // every load up front, 512 threads per head (kernels.hip.h: attn_pre_body): contexts below 256, 64- / 128-wide heads
-    // measured (same box): stories110M 3127 -> 3186 tok/s, Llama-2-7B 209.5 -> 207.5 (its 128-wide rows make the up-front
-    // request phase texture-bound), so by default only 64-wide heads take it (L2_ATTN_PRE=2: 128-wide too, 0: never)
-    const bool pre = vec && !c->opt_exact && c->attn_splits_forced == 0 && c->cur_splits <= 1 &&
-                     ((c->hs == 64 && c->attn_pre >= 1) || (c->hs == 128 && c->attn_pre >= 2));
-    if (pre && c->hs == 128) hipLaunchKernelGGL((attn_pre_kernel<32>), dim3(c->H_loc), dim3(512), lds, st, a);
-    else if (pre) hipLaunchKernelGGL((attn_pre_kernel<16>), dim3(c->H_loc), dim3(512), lds, st, a);
+    // L2_ATTN_PRE: 0 never; 1 (default) 64-wide heads, K and V rows up front; 2 128-wide heads too; 3 V rows up front only
+    // (K rows where the dot uses them).  Same box: stories110M 3130 / 3188 / - / 3195 tok/s, Llama-2-7B 209.7 / - / 207.5 / 204.8.
+    const bool ok = vec && !c->opt_exact && c->attn_splits_forced == 0 && c->cur_splits <= 1 && (c->hs == 64 || c->hs == 128);
+    const int mode = !ok ? 0 : (c->attn_pre >= 3 ? 3 : (c->hs == 64 && c->attn_pre >= 1) || (c->hs == 128 && c->attn_pre >= 2) ? 1 : 0);
+    if (mode && c->hs == 128) {
+      if (mode == 3) hipLaunchKernelGGL((attn_pre_kernel<32, false>), dim3(c->H_loc), dim3(512), lds, st, a);
+      else hipLaunchKernelGGL((attn_pre_kernel<32, true>), dim3(c->H_loc), dim3(512), lds, st, a);
+    } else if (mode && c->hs == 64) {
+      if (mode == 3) hipLaunchKernelGGL((attn_pre_kernel<16, false>), dim3(c->H_loc), dim3(512), lds, st, a);
+      else hipLaunchKernelGGL((attn_pre_kernel<16, true>), dim3(c->H_loc), dim3(512), lds, st, a);
+    }
     else if (vec) hipLaunchKernelGGL((attn_kernel<true>), dim3(c->H_loc), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((attn_kernel<false>), dim3(c->H_loc), dim3(256), lds, st, a);
   }

@@ -482,7 +482,7 @@ def test_device_sampler_with_the_experimental_chain_launch():
     assert got.tolist() == want.tolist()
 
 
-@pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_FUSE_WO": "1"}), ("llama2_7b_L2", {"L2_ATTN_PRE": "2"}),
+@pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_FUSE_WO": "1"}), ("llama2_7b_L2", {"L2_ATTN_PRE": "2"}), ("llama2_7b_L2", {"L2_ATTN_PRE": "3"}), ("stories110M", {"L2_ATTN_PRE": "3"}),
                                       ("stories110M", {"L2_FUSE_WO": "1"}), ("stories110M", {"L2_ATTN_PRE": "0"})])
 def test_attention_launch_variants_match_reference(monkeypatch, name, env):
     """Opt-in attention launch forms (attention with every load up front; attention + register-resident wo in one
