@@ -51,13 +51,13 @@ __global__ void __launch_bounds__(256) pf_norm_kernel(float* xn, const float* x,
   float v[MAXE], g[MAXE];
   double ss = 0.0;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
-    const int j = tid + 256 * e;
-    v[e] = (j < dim) ? xr[j] : 0.0f;
-    g[e] = (j < dim) ? w[j] : 0.0f;
+  for (int e = 0; e < MAXE; ++e) {                 // clamped, never predicated: a predicated load serialises the batch
+    const int j = min(tid + 256 * e, dim - 1);
+    v[e] = xr[j];
+    g[e] = w[j];
   }
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) ss += (double)v[e] * (double)v[e];
+  for (int e = 0; e < MAXE; ++e) ss += (tid + 256 * e < dim) ? (double)v[e] * (double)v[e] : 0.0;
   for (int j = tid + 256 * MAXE; j < dim; j += 256) { const double u = xr[j]; ss += u * u; }
   ss = block_sum(ss, red, tid, 256);
   ss /= (double)dim;
