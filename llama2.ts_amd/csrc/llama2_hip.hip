@@ -160,9 +160,7 @@ struct l2_ctx {
   double* attn_part = nullptr;      // split attention partials [H][NS][rec]
   unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
-  int pf_two_tiles = 0;             // L2_PF_TWO_TILES=1: prefill GEMMs take two 16-row tiles per workgroup (measured slower)
   int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
-  int pf_un = 4;                    // L2_PF_UN: 16-column blocks per register set in the prefill GEMMs (4 or 8)
   int cur_splits = 1;               // split count of the step being enqueued / captured
   unsigned* head_done = nullptr;    // [H] fused QKV+attention hand-off counters, zero between launches
   unsigned* wo_sync = nullptr;      // attn_wo_kernel: {ready, done} counters on separate lines, zero between launches
@@ -368,8 +366,6 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->opt_fuse_wo = env_int("L2_FUSE_WO", 0);
   c->attn_pre = env_int("L2_ATTN_PRE", 1);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->pf_two_tiles = env_int("L2_PF_TWO_TILES", 0);
-  c->pf_un = env_int("L2_PF_UN", 4);
   c->pf_lds = env_int("L2_PF_LDS", 1);
   if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;
   {
@@ -1248,25 +1244,28 @@ static bool can_prefill(const l2_ctx* c) {
   return !c->tp_path && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
 }
 
-// One prefill GEMM: NW waves per workgroup split K; QKV / WO / W2 take two 16-row tiles per workgroup when the
-// matrix height allows it and L2_PF_TWO_TILES=1 (opt-in: measured slower, fewer bytes in flight).
+// One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1 or 2).  QKV / WO / W2 take their weights through an LDS
+// tile by default (L2_PF_LDS: 0 never, 1 default, 2 W13 too -- its two tiles per wave measured slower).
 template <int MODE>
-static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, hipStream_t st) {
-  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1)) {   // weight tile through LDS (row-shaped global loads); W13 only with L2_PF_LDS=2: its two tiles per wave measured slower (99 vs 96 us)
-    const size_t lds = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
+static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, hipStream_t st) {
+  const dim3 grid(a.rows / 16);
+  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1)) {
+    const size_t tiles = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
+    const size_t parts = (size_t)2 * 2 * 3 * 4 * 64 * 8;
+    const size_t lds = tiles > parts ? tiles : parts;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4>), dim3(a.rows / 16), dim3(256), lds, st, a);
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    if (tt == 2) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 2>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 1>), grid, dim3(256), lds, st, a);
     return;
   }
-  const int mrows = (MODE == MODE_QKV) ? a.dim : a.rows;
-  const bool two = (MODE != MODE_W13) && c->pf_two_tiles && (mrows % 32 == 0);
-  const int grid = a.rows / (two ? 32 : 16);
-#define L2_PFG2(NW, UNN) do { if (two) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, true, UNN>), dim3(grid), dim3(64 * NW), 0, st, a); \
-                              else hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, false, UNN>), dim3(grid), dim3(64 * NW), 0, st, a); } while (0)
-#define L2_PFG(NW) do { if (c->pf_un == 8) L2_PFG2(NW, 8); else L2_PFG2(NW, 4); } while (0)
+#define L2_PFG(NW) do { if (tt == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 2>), grid, dim3(64 * NW), 0, st, a); \
+                        else hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 1>), grid, dim3(64 * NW), 0, st, a); } while (0)
   if (nw <= 4) L2_PFG(4); else L2_PFG(8);
-#undef L2_PFG2
 #undef L2_PFG
 }
 
@@ -1279,11 +1278,12 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     HIPCHK(hipMalloc(&c->pf_tok, PF_T * sizeof(int)));
     HIPCHK(hipMemset(c->pf_xb, 0, PF_T * d * 4)); HIPCHK(hipMemset(c->pf_q, 0, PF_T * d * 4));
   }
+  const int tt = (n > 16) ? 2 : 1, nt = 16 * tt;        // 16-token MFMA tiles in this chunk
   int32_t tk[PF_T] = {0};
   for (int i = 0; i < n; ++i) tk[i] = tokens[i];
   HIPCHK(hipMemcpyAsync(c->pf_tok, tk, sizeof(tk), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));   // tk is on the stack
-  hipLaunchKernelGGL(pf_embed_kernel, dim3(PF_T), dim3(256), 0, st, c->pf_x, c->w[L2_T_TOKEN_EMBEDDING], c->pf_tok, c->d, n);
+  hipLaunchKernelGGL(pf_embed_kernel, dim3(nt), dim3(256), 0, st, c->pf_x, c->w[L2_T_TOKEN_EMBEDDING], c->pf_tok, c->d, n);
   LCHK(hipGetLastError());
   for (int l = 0; l < c->L; ++l) {
     const size_t loff = (size_t)l * c->S * c->d;
@@ -1292,11 +1292,11 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG]; a.head_size = c->hs; a.dim = c->d; a.pos0 = pos0; a.nvalid = n;
     a.x = c->pf_x;
     // rmsnorm + q,k,v + RoPE + cache rows (llama2.ts:216-240)
-    hipLaunchKernelGGL(pf_norm_kernel, dim3(PF_T), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_ATT] + d * l, c->d);
+    hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_ATT] + d * l, c->d);
     a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
     a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
     a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
-    launch_pf_gemm<MODE_QKV>(c, a, env_int("L2_PF_NW_QKV", 4), st);
+    launch_pf_gemm<MODE_QKV>(c, a, env_int("L2_PF_NW_QKV", 4), tt, st);
     LCHK(hipGetLastError());
     // attention, one workgroup per (head, query) (llama2.ts:244-267)
     {
@@ -1311,15 +1311,15 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     }
     // wo + residual (llama2.ts:270-273)
     a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
-    launch_pf_gemm<MODE_WO>(c, a, env_int("L2_PF_NW_WO", 4), st);
+    launch_pf_gemm<MODE_WO>(c, a, env_int("L2_PF_NW_WO", 4), tt, st);
     // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
-    hipLaunchKernelGGL(pf_norm_kernel, dim3(PF_T), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
+    hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
     a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
     a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
-    launch_pf_gemm<MODE_W13>(c, a, env_int("L2_PF_NW_W13", 4), st);
+    launch_pf_gemm<MODE_W13>(c, a, env_int("L2_PF_NW_W13", 4), tt, st);
     // w2 + residual (llama2.ts:292-295)
     a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
-    launch_pf_gemm<MODE_W2>(c, a, env_int("L2_PF_NW_W2", 4), st);
+    launch_pf_gemm<MODE_W2>(c, a, env_int("L2_PF_NW_W2", 4), tt, st);
     LCHK(hipGetLastError());
   }
   return L2_OK;

@@ -22,7 +22,7 @@ namespace l2k {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-enum { PF_T = 16 };   // tokens per chunk
+enum { PF_T = 32 };   // tokens per chunk: one or two MFMA tiles of 16
 
 struct PfArgs {
   const float* w0;     // QKV: wq  W13: w1  else the matrix
@@ -34,7 +34,7 @@ struct PfArgs {
   float* kc; float* vc;        // QKV: cache slabs of this layer
   const float* fr; const float* fi;
   int n, rows, dim, head_size;
-  int pos0, nvalid;    // first position of the chunk, tokens in it (<= 16)
+  int pos0, nvalid;    // first position of the chunk, tokens in it (<= PF_T)
 };
 
 __global__ void __launch_bounds__(256) pf_embed_kernel(float* x, const float* emb, const int* tokens, int dim, int nvalid) {
@@ -70,12 +70,12 @@ __global__ void __launch_bounds__(256) pf_norm_kernel(float* xn, const float* x,
   for (int j = tid + 256 * MAXE; j < dim; j += 256) xn[(size_t)t * dim + j] = (float)((double)w[j] * (ss * (double)xr[j]));
 }
 
-// Epilogue of one 16-row tile: the lane holds tokens t = kq + 4r (r = 0..3) of output index i.
+// Epilogue of one 16-row x 16-token tile: the lane holds tokens t = toff + kq + 4r (r = 0..3) of output index i.
 template <int MODE>
-__device__ __forceinline__ void pf_emit(const PfArgs& a, const d4& av, const d4& acc3, int m, int i, int j, int kq) {
+__device__ __forceinline__ void pf_emit(const PfArgs& a, const d4& av, const d4& acc3, int m, int i, int j, int kq, int toff) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int t = kq + 4 * r;
+    const int t = toff + kq + 4 * r;
     const float sv = (float)av[r];                                  // matmul store (llama2.ts:201)
     if (MODE == MODE_QKV) {
       const int pos = a.pos0 + t;
@@ -106,102 +106,126 @@ __device__ __forceinline__ void pf_emit(const PfArgs& a, const d4& av, const d4&
   }
 }
 
-// NW waves per workgroup share one 16-row tile and split K NW ways.  Measured (7B shapes, L2_PF_NW_*): 4 waves per
-// tile is best everywhere (8.6 ms per 16-token chunk; 1-2 waves starve wo / w2, 8-16 waves lose to the combine).
-// TWO (QKV / WO / W2): the workgroup owns two adjacent 16-row tiles that share every activation fragment, the way
-// W13 always shares it between w1 and w3 -- half the activation-panel reads from L2 and 1.5 instead of 2
-// v_cvt_f64_f32 per MFMA.  Needs the matrix height to be a multiple of 32 (the host falls back to one tile).
-template <int MODE, int NW, bool TWO, int UN>
+// Accumulators of one workgroup: TT token tiles x (1 or 2 weight streams) x two chains (even / odd k steps: a
+// dependent MFMA cannot issue back to back).
+template <int TT, bool DUAL>
+struct PfAcc {
+  d4 a[TT][2], c[TT][2];                               // a: first stream (w0 / w1), c: second stream (w3)
+  __device__ __forceinline__ void clear() {
+    const d4 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { a[t][0] = z; a[t][1] = z; c[t][0] = z; c[t][1] = z; }
+  }
+  // one 16-column block: weight fragment w (and w3), activation fragments x[t] of the TT token tiles
+  __device__ __forceinline__ void block(const f4& w, const f4& w3, const f4 (&x)[TT]) {
+    const double w0 = w.x, w1 = w.y, w2 = w.z, w3d = w.w;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    if (DUAL) { v0 = w3.x; v1 = w3.y; v2 = w3.z; v3 = w3.w; }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      const double x0 = x[t].x, x1 = x[t].y, x2 = x[t].z, x3 = x[t].w;
+      a[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, w0, a[t][0], 0, 0, 0);
+      a[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, w1, a[t][1], 0, 0, 0);
+      if (DUAL) {
+        c[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, v0, c[t][0], 0, 0, 0);
+        c[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, v1, c[t][1], 0, 0, 0);
+      }
+      a[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, w2, a[t][0], 0, 0, 0);
+      a[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, w3d, a[t][1], 0, 0, 0);
+      if (DUAL) {
+        c[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, v2, c[t][0], 0, 0, 0);
+        c[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, v3, c[t][1], 0, 0, 0);
+      }
+    }
+  }
+  // chains folded, split-K partials of waves 1..NW-1 added in wave order into wave 0 (part: LDS, [TT][2][NW-1][4][64])
+  template <int NW>
+  __device__ __forceinline__ bool combine(double* part, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[t][0][r] += a[t][1][r]; c[t][0][r] += c[t][1][r]; }
+    if (NW == 1) return true;
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          part[(((t * 2 + 0) * (NW - 1) + wave - 1) * 4 + r) * 64 + lane] = a[t][0][r];
+          if (DUAL) part[(((t * 2 + 1) * (NW - 1) + wave - 1) * 4 + r) * 64 + lane] = c[t][0][r];
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return false;
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) {
+          a[t][0][r] += part[(((t * 2 + 0) * (NW - 1) + w) * 4 + r) * 64 + lane];
+          if (DUAL) c[t][0][r] += part[(((t * 2 + 1) * (NW - 1) + w) * 4 + r) * 64 + lane];
+        }
+    return true;
+  }
+};
+
+// One 16-row weight tile per workgroup, NW waves split K, TT tiles of 16 tokens share every weight fragment (the
+// chunk is 16 or 32 tokens: with 32 each streamed weight byte feeds two MFMAs and is widened once).  Weight loads in
+// MFMA operand layout.  Measured (7B shapes): NW = 4 is best everywhere (1-2 waves starve wo / w2, 8-16 lose to the
+// combine); two 16-row tiles per workgroup and 8-block register sets were slower (fewer workgroups / occupancy).
+template <int MODE, int NW, int TT>
 __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
-  constexpr bool DUAL = (MODE == MODE_W13) || TWO;   // a second weight stream on the same activations
-  __shared__ double part[DUAL ? 2 : 1][NW > 1 ? NW - 1 : 1][4][64];   // [stream][waves 1..NW-1][reg][lane]
+  constexpr bool DUAL = (MODE == MODE_W13);          // w1 and w3 on the same activations
+  constexpr int UN = 4;                              // 16-column blocks per batch (two register sets of them)
+  __shared__ double part[TT * 2 * (NW > 1 ? NW - 1 : 1) * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = a.n, nblk = n >> 4;                 // 16-column blocks
-  const int row0 = blockIdx.x * ((TWO && MODE != MODE_W13) ? 32 : 16);   // first output row of this workgroup
+  const int row0 = blockIdx.x * 16;
   int m = 0, i0 = row0;
   const float* wbase = a.w0;
   if (MODE == MODE_QKV) { m = row0 / a.dim; i0 = row0 - m * a.dim; wbase = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2; }
   const int j = lane & 15, kq = lane >> 4;
   const float* wrow = wbase + (size_t)(i0 + j) * n + 4 * kq;
-  const float* wrow3 = (MODE == MODE_W13) ? a.w1 + (size_t)(i0 + j) * n + 4 * kq          // w3, same rows
-                       : (TWO ? wbase + (size_t)(i0 + 16 + j) * n + 4 * kq : nullptr);   // the tile below
-  const float* xrow = a.xin + (size_t)j * n + 4 * kq;       // token j as the A row
-
-  // two independent accumulator chains per tile (even / odd k steps): a dependent MFMA cannot issue back to back
-  d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0}, acc3b = {0.0, 0.0, 0.0, 0.0};
-  // UN = 16-column blocks per batch (two register sets of them)
-  // a wave takes UN ADJACENT 16-column blocks per batch (256 contiguous bytes of every weight row: DRAM pages see
-  // runs, not 64-byte pieces), batches round-robin over the NW waves; batch b+1 loads while batch b is on the matrix pipe
-  const int npair = (nblk + UN - 1) / UN;            // batches of UN blocks
-  struct Batch { f4 wv[UN], xv[UN], w3[UN]; };
-  auto blk = [&](int p0, int u) { return p0 * UN + u; };
+  const float* wrow3 = DUAL ? a.w1 + (size_t)(i0 + j) * n + 4 * kq : nullptr;
+  const float* xrow = a.xin + (size_t)j * n + 4 * kq;       // token j (and 16 + j) as the A row
+  PfAcc<TT, DUAL> acc;
+  acc.clear();
+  // a wave takes UN ADJACENT 16-column blocks per batch (256 contiguous bytes of every weight row), batches round-robin
+  // over the NW waves; batch b+1 loads while batch b is on the matrix pipe
+  const int npair = (nblk + UN - 1) / UN;
+  struct Batch { f4 wv[UN], w3[DUAL ? UN : 1], xv[UN][TT]; };
   auto load = [&](Batch& b, int p0) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int sb = min(blk(p0, u), nblk - 1);     // clamped (never predicated) loads; masked in mma()
+      const int sb = min(p0 * UN + u, nblk - 1);     // clamped (never predicated) loads; masked in mma()
       b.wv[u] = ldg_nt(wrow + 16 * sb);
       if (DUAL) b.w3[u] = ldg_nt(wrow3 + 16 * sb);
-      b.xv[u] = *reinterpret_cast<const f4*>(xrow + 16 * sb);
+#pragma unroll
+      for (int t = 0; t < TT; ++t) b.xv[u][t] = *reinterpret_cast<const f4*>(xrow + (size_t)16 * t * n + 16 * sb);
     }
   };
   auto mma = [&](const Batch& b, int p0) {
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      if (blk(p0, u) < nblk) {
-        const double x0 = b.xv[u].x, x1 = b.xv[u].y, x2 = b.xv[u].z, x3 = b.xv[u].w;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)b.wv[u].x, acc, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)b.wv[u].y, accb, 0, 0, 0);
-        if (DUAL) {
-          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)b.w3[u].x, acc3, 0, 0, 0);
-          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)b.w3[u].y, acc3b, 0, 0, 0);
-        }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)b.wv[u].z, acc, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)b.wv[u].w, accb, 0, 0, 0);
-        if (DUAL) {
-          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)b.w3[u].z, acc3, 0, 0, 0);
-          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)b.w3[u].w, acc3b, 0, 0, 0);
-        }
-      }
-    }
+    for (int u = 0; u < UN; ++u)
+      if (p0 * UN + u < nblk) acc.block(b.wv[u], b.w3[DUAL ? u : 0], b.xv[u]);
   };
-  constexpr int PSTEP = NW;                          // batches advance by the wave count
   Batch A, B;
   int p0 = wave;
   if (p0 < npair) load(A, p0);
   while (p0 < npair) {
-    const int p1 = p0 + PSTEP;
+    const int p1 = p0 + NW;
     load(B, p1 < npair ? p1 : p0);                   // unconditional (clamped) prefetch keeps the waits counted
     mma(A, p0);
     if (p1 >= npair) break;
-    const int p2 = p1 + PSTEP;
+    const int p2 = p1 + NW;
     load(A, p2 < npair ? p2 : p1);
     mma(B, p1);
     p0 = p2;
   }
+  if (!acc.template combine<NW>(part, wave, lane)) return;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { acc[r] += accb[r]; acc3[r] += acc3b[r]; }
-  // split-K partials of waves 1..NW-1 -> wave 0, added in wave order
-  if (wave > 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      part[0][wave - 1][r][lane] = acc[r];
-      if (DUAL) part[DUAL ? 1 : 0][wave - 1][r][lane] = acc3[r];
-    }
-  }
-  __syncthreads();
-  if (wave != 0) return;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int w = 0; w < NW - 1; ++w) {
-      acc[r] += part[0][w][r][lane];
-      if (DUAL) acc3[r] += part[DUAL ? 1 : 0][w][r][lane];
-    }
-  }
-
-  // ---- epilogue (second tile: i + 16)
-#pragma unroll
-  for (int tile = 0; tile < ((TWO && MODE != MODE_W13) ? 2 : 1); ++tile) pf_emit<MODE>(a, tile ? acc3 : acc, acc3, m, i0 + 16 * tile + j, j, kq);
+  for (int t = 0; t < TT; ++t) pf_emit<MODE>(a, acc.a[t][0], acc.c[t][0], m, i0 + j, j, kq, 16 * t);
 }
 
 // The same GEMM with the weight tile taken through LDS.  pf_gemm_kernel's loads follow the MFMA operand layout: one
@@ -212,7 +236,7 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
 // back in MFMA layout.  Activations still come straight from L2 in operand layout.  Measured on 7B shapes: QKV
 // 60.6 -> 54.5 us, W2 56.5 -> 49.7, WO unchanged, W13 (two tiles per wave) 96 -> 99: the load shape was worth ~10 %,
 // the rest of the gap to the 33 us stream time is MFMA / widening time that the few resident waves do not overlap.
-template <int MODE, int NW>
+template <int MODE, int NW, int TT>
 __global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
   constexpr bool DUAL = (MODE == MODE_W13);
   constexpr int KC = 128, KB = KC / 16, WS = KC + 4, TILE = 16 * WS;      // floats
@@ -229,9 +253,9 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
   const float* xrow = a.xin + (size_t)j * n + 4 * kq;
   float* tile = lds + (size_t)wave * (DUAL ? 2 : 1) * TILE;
   float* tile3 = tile + TILE;
-
-  d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0}, acc3b = {0.0, 0.0, 0.0, 0.0};
-  struct Batch { f4 wv[KB], w3[DUAL ? KB : 1], xv[KB]; };
+  PfAcc<TT, DUAL> acc;
+  acc.clear();
+  struct Batch { f4 wv[KB], w3[DUAL ? KB : 1], xv[KB][TT]; };
   auto load = [&](Batch& b, int p) {
     const int pc = min(p, nch - 1);
     const int col = min(pc * KC + 4 * lc, n - 4);                         // clamped, never predicated; masked in mma()
@@ -241,7 +265,9 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
       if (DUAL) b.w3[i] = ldg_nt(wl3 + (size_t)(2 * i) * n + col);
     }
 #pragma unroll
-    for (int u = 0; u < KB; ++u) b.xv[u] = *reinterpret_cast<const f4*>(xrow + 16 * min(pc * KB + u, nblk - 1));
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) b.xv[u][t] = *reinterpret_cast<const f4*>(xrow + (size_t)16 * t * n + 16 * min(pc * KB + u, nblk - 1));
   };
   auto mma = [&](const Batch& b, int p) {
 #pragma unroll
@@ -256,18 +282,9 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
     for (int u = 0; u < KB; ++u) {
       if (p * KB + u < nblk) {
         const f4 wv = *reinterpret_cast<const f4*>(tile + j * WS + 16 * u + 4 * kq);
-        const double x0 = b.xv[u].x, x1 = b.xv[u].y, x2 = b.xv[u].z, x3 = b.xv[u].w;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)wv.x, acc, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)wv.y, accb, 0, 0, 0);
-        if (DUAL) {
-          const f4 w3 = *reinterpret_cast<const f4*>(tile3 + j * WS + 16 * u + 4 * kq);
-          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, (double)w3.x, acc3, 0, 0, 0);
-          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, (double)w3.y, acc3b, 0, 0, 0);
-          acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)w3.z, acc3, 0, 0, 0);
-          acc3b = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)w3.w, acc3b, 0, 0, 0);
-        }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, (double)wv.z, acc, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, (double)wv.w, accb, 0, 0, 0);
+        f4 w3 = wv;
+        if (DUAL) w3 = *reinterpret_cast<const f4*>(tile3 + j * WS + 16 * u + 4 * kq);
+        acc.block(wv, w3, b.xv[u]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -285,28 +302,10 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
     mma(B, p1);
     p0 = p2;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { acc[r] += accb[r]; acc3[r] += acc3b[r]; }
   __syncthreads();                                                          // tiles are dead: reuse the LDS for the split-K partials
-  double* part = reinterpret_cast<double*>(lds);                            // [stream][waves 1..NW-1][reg][lane]
-  if (wave > 0) {
+  if (!acc.template combine<NW>(reinterpret_cast<double*>(lds), wave, lane)) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      part[((0 * (NW - 1) + wave - 1) * 4 + r) * 64 + lane] = acc[r];
-      if (DUAL) part[((1 * (NW - 1) + wave - 1) * 4 + r) * 64 + lane] = acc3[r];
-    }
-  }
-  __syncthreads();
-  if (wave != 0) return;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int w = 0; w < NW - 1; ++w) {
-      acc[r] += part[((0 * (NW - 1) + w) * 4 + r) * 64 + lane];
-      if (DUAL) acc3[r] += part[((1 * (NW - 1) + w) * 4 + r) * 64 + lane];
-    }
-  }
-  pf_emit<MODE>(a, acc, acc3, m, i0 + j, j, kq);
+  for (int t = 0; t < TT; ++t) pf_emit<MODE>(a, acc.a[t][0], acc.c[t][0], m, i0 + j, j, kq, 16 * t);
 }
 
 }  // namespace l2k
