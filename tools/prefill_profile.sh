@@ -13,8 +13,7 @@ for r in csv.DictReader(open("gpurun_out/pf_$tag/p_kernel_stats.csv")):
     if "pf_gemm" in n and "lds" in n or "pf_gemm" in n: print("  %-48s %8.2f us" % (n.replace("l2k::", "").replace("(PfArgs)", "")[:48], float(r["AverageNs"]) / 1e3))
 PY
 }
-run base L2_PF_LDS=0 L2_PF_UN=4
+run base L2_PF_LDS=0
 run nw8 L2_PF_LDS=0 L2_PF_NW_QKV=8 L2_PF_NW_WO=8 L2_PF_NW_W13=8 L2_PF_NW_W2=8
-run two L2_PF_LDS=0 L2_PF_TWO_TILES=1
 run lds L2_PF_LDS=1
 run nolds L2_PF_LDS=0
