@@ -221,10 +221,10 @@ def main():
                 ctx.decode_sample(1, 0, n_s, t, p, 42)
                 samp[nm] = round(n_s / (time.perf_counter() - t0), 3)
             out["sampled_decode_tok_s"] = samp
-            # prompt ingestion (l2_prefill: chunks of 32 tokens on the fp64 MFMA path) next to the token-by-token loop it replaces
-            n_p = min(64, hdr[6])
+            # prompt ingestion (l2_prefill: chunks of up to 64 tokens on the fp64 MFMA path) next to the token-by-token loop it replaces
+            n_p = min(128, hdr[6])
             ptoks = (np.arange(n_p, dtype=np.int32) * 7919 + 2) % cfg.vocab_size
-            ctx.prefill(ptoks[:32], 0)
+            ctx.prefill(ptoks[:64], 0)
             t0 = time.perf_counter()
             ctx.prefill(ptoks, 0)
             out["prefill_tok_s"] = round(n_p / (time.perf_counter() - t0), 1)

@@ -140,7 +140,7 @@ int l2_debug_running_sums(int device, const float* values, size_t n, double* sum
 
 /* Next row of SURVEY.md 8(f3): prompt ingestion.  The reference runs one transformer() per prompt token and
  * ignores the logits (llama2.ts:471-473); this feeds `n_tokens` tokens at positions pos0 .. pos0+n_tokens-1 in
- * chunks of up to 32 (one or two 16-token MFMA tiles) that share every weight read (fp64 MFMA GEMMs), leaves the KV cache exactly as the n_tokens
+ * chunks of up to 64 (one, two or four 16-token MFMA tiles) that share every weight read (fp64 MFMA GEMMs), leaves the KV cache exactly as the n_tokens
  * separate calls would, and returns the logits of the LAST position in logits_out (may be NULL).  Shapes whose
  * dim / hidden_dim are not multiples of 16 fall back to n_tokens l2_forward calls. */
 int l2_prefill(l2_ctx* ctx, const int32_t* tokens, int n_tokens, int pos0, float* logits_out);

@@ -1244,26 +1244,30 @@ static bool can_prefill(const l2_ctx* c) {
   return !c->tp_path && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
 }
 
-// One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1 or 2).  QKV / WO / W2 take their weights through an LDS
+// One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1, 2 or 4).  QKV / WO / W2 take their weights through an LDS
 // tile by default (L2_PF_LDS: 0 never, 1 default, 2 W13 too -- its two tiles per wave measured slower).
 template <int MODE>
 static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, hipStream_t st) {
   const dim3 grid(a.rows / 16);
-  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1)) {
+  // four token tiles: the LDS form's 8-block register sets (32 activation fragments) leave one spilled wave per SIMD: 3200 vs 3490 tok/s
+  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && (tt < 4 || c->pf_lds >= 3)) {
     const size_t tiles = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
-    const size_t parts = (size_t)2 * 2 * 3 * 4 * 64 * 8;
+    const size_t parts = (size_t)4 * 2 * 3 * 4 * 64 * 8;
     const size_t lds = tiles > parts ? tiles : parts;
     static bool attr = false;
     if (!attr) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
-    if (tt == 2) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 2>), grid, dim3(256), lds, st, a);
+    if (tt == 4) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 4>), grid, dim3(256), lds, st, a);
+    else if (tt == 2) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 2>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 1>), grid, dim3(256), lds, st, a);
     return;
   }
-#define L2_PFG(NW) do { if (tt == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 2>), grid, dim3(64 * NW), 0, st, a); \
+#define L2_PFG(NW) do { if (tt == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 4>), grid, dim3(64 * NW), 0, st, a); \
+                        else if (tt == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 2>), grid, dim3(64 * NW), 0, st, a); \
                         else hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 1>), grid, dim3(64 * NW), 0, st, a); } while (0)
   if (nw <= 4) L2_PFG(4); else L2_PFG(8);
 #undef L2_PFG
@@ -1278,7 +1282,7 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     HIPCHK(hipMalloc(&c->pf_tok, PF_T * sizeof(int)));
     HIPCHK(hipMemset(c->pf_xb, 0, PF_T * d * 4)); HIPCHK(hipMemset(c->pf_q, 0, PF_T * d * 4));
   }
-  const int tt = (n > 16) ? 2 : 1, nt = 16 * tt;        // 16-token MFMA tiles in this chunk
+  const int tt = (n > 32) ? 4 : (n > 16) ? 2 : 1, nt = 16 * tt;        // 16-token MFMA tiles in this chunk
   int32_t tk[PF_T] = {0};
   for (int i = 0; i < n; ++i) tk[i] = tokens[i];
   HIPCHK(hipMemcpyAsync(c->pf_tok, tk, sizeof(tk), hipMemcpyHostToDevice, st));

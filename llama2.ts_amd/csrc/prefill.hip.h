@@ -22,7 +22,7 @@ namespace l2k {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-enum { PF_T = 32 };   // tokens per chunk: one or two MFMA tiles of 16
+enum { PF_T = 64 };   // tokens per chunk: one, two or four MFMA tiles of 16
 
 struct PfArgs {
   const float* w0;     // QKV: wq  W13: w1  else the matrix

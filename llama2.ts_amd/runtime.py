@@ -177,7 +177,7 @@ class Context:
         return out
 
     def prefill(self, tokens, pos0=0):
-        """Feed a run of (prompt) tokens at pos0.. in chunks of up to 32 tokens; returns the logits of the last position."""
+        """Feed a run of (prompt) tokens at pos0.. in chunks of up to 64 tokens; returns the logits of the last position."""
         t = np.ascontiguousarray(tokens, dtype=np.int32)
         _check(lib().l2_prefill(self._h, t.ctypes.data, t.size, int(pos0), None))
         return self.logits_host()

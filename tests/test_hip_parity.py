@@ -305,10 +305,10 @@ def test_full_size_7b_properties(built):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,n", [("tiny", 1), ("tiny", 5), ("tiny", 16), ("tiny", 17), ("tiny", 32), ("tiny", 33), ("tiny", 40), ("tiny", 64),
+@pytest.mark.parametrize("name,n", [("tiny", 1), ("tiny", 5), ("tiny", 16), ("tiny", 17), ("tiny", 32), ("tiny", 33), ("tiny", 40), ("tiny", 64), ("tinylong", 65), ("tinylong", 150),
                                     ("ragged", 7), ("stories15M", 21), ("stories15M", 70)])
 def test_prefill_equals_token_by_token(built, name, n):
-    """l2_prefill (chunks of 16 or 32 tokens on fp64 MFMA) must leave the KV cache and the last logits exactly
+    """l2_prefill (chunks of 16, 32 or 64 tokens on fp64 MFMA) must leave the KV cache and the last logits exactly
     where n separate transformer() calls -- what the reference does with a prompt, llama2.ts:471-473 -- leave them,
     and decoding must continue identically.  `ragged` (dims not multiples of 16) takes the fallback path."""
     meta, g = load_gold(name)
