@@ -244,12 +244,16 @@ static void destroy_graphs(l2_ctx* c) {
   }
 }
 
-// Attention split level by context length (measured on 7B, tools/longctx.py): one workgroup per head is
-// fastest below ~256 cached timesteps, 4 splits up to ~1024, 8 beyond (pos 1900: 7.4 -> 5.6 ms per token).
+// Attention split level by context length (measured on 7B, tools/ctx_curve.py with L2_ATTN_SPLITS=2/4/8/16): one
+// workgroup per head is fastest below ~256 cached timesteps, 4 splits up to ~512, 8 beyond (ms per token at pos 768:
+// 5.16 with 4 splits, 5.11 with 8; pos 1920: 6.26 / 5.60 / 5.39 / 5.58 with 2 / 4 / 8 / 16).
 static const int kSplitLevels[3] = {1, 4, 8};
+// 64-wide heads (stories110M, same tool): 8 splits never pay below 1024 positions (pos 768: 0.412 ms with 4, 0.439 with 8),
+// so the second threshold scales with the bytes of a head's cache rows: 65536 / head_size positions.
 static int split_level(const l2_ctx* c, int pos) {
   if (c->attn_splits_forced > 0) return 0;
-  return pos < 256 ? 0 : (pos < 1024 ? 1 : 2);
+  const int t8 = (c->hs > 0 && 65536 / c->hs > 512) ? 65536 / c->hs : 512;
+  return pos < 256 ? 0 : (pos < t8 ? 1 : 2);
 }
 static int splits_of(const l2_ctx* c, int level) { return c->attn_splits_forced > 0 ? c->attn_splits_forced : kSplitLevels[level]; }
 

@@ -205,7 +205,7 @@ def test_split_attention_matches_reference(built, name, splits):
 
 
 def test_long_context_crosses_every_split_level_token_exact(built):
-    """1280 greedy steps at tiny width: attention runs unsplit (pos < 256), 4-way (< 1024) and 8-way split;
+    """1280 greedy steps at tiny width: attention runs unsplit (pos < 256) and split (thresholds scale with head size; forced 8-way below);
     the token stream and the logits at the level boundaries must still equal the TRUE reference's."""
     meta, g = load_gold("tinylong")
     ctx = runtime.Context(meta["header"])
