@@ -5,7 +5,9 @@
  * the per-token `transformer()` forward (/root/reference/llama2.ts:205-303) and the
  * helpers it calls (accum :168, rmsnorm :172, softmax :181, matmul :196), plus the
  * llama2.c-v0 checkpoint layout (readConfig :80-93, readWeights :112-129) and the
- * RunState buffers (newRunState :147-163).
+ * RunState buffers (newRunState :147-163); and, for the rows next to the path, the RNG and
+ * samplers downstream of it (random_u32 / random_f32 :348-360, sample :368-376, sample_topp :378-394,
+ * the temperature branch :476-493).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link, load or
  * call this.  The product (llama2.ts_amd/) never does: it fails loudly without the HIP library.
@@ -13,7 +15,8 @@
  * Parity pin: the reference ships no tests and no golden vectors for this path (SURVEY.md
  * section 4), so this restatement is pinned against outputs of the reference itself, executed
  * in the build container under Node 12 (recipe: oracle/make_goldens.py, fixtures:
- * tests/golden/).  tests/test_oracle_golden.py checks every fixture bit-for-bit.
+ * tests/golden/).  tests/test_oracle_golden.py checks every fixture bit-for-bit (logits of every position of
+ * every run; sampled token ids of the reference's -t / -p / -s runs).
  */
 #ifndef LLAMA2_ORACLE_H
 #define LLAMA2_ORACLE_H
