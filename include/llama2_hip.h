@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define L2_ABI_VERSION 1
+#define L2_ABI_VERSION 2
 
 enum {
   L2_OK = 0,
@@ -63,8 +63,7 @@ enum {
 enum {
   L2_OPT_EXACT_ATTENTION = 1, /* 1: value-accumulate rounds to fp32 at every timestep in t order, exactly as
                                  llama2.ts:260-265 does (bit-faithful, slower); 0 (default): fp64 partial sums */
-  L2_OPT_USE_GRAPH = 2,       /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
-  L2_OPT_MEGAKERNEL = 3       /* experimental: one "chain" launch per token instead of one launch per phase */
+  L2_OPT_USE_GRAPH = 2        /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
 };
 
 typedef struct l2_ctx l2_ctx;

@@ -1,0 +1,348 @@
+// attention.hip.h -- multi-head attention over the KV cache for one position (llama2.ts:244-267), gfx950.
+//
+// One workgroup per (head, split).  The cache rows of a head are `head_size` contiguous floats every `dim`
+// floats (cache layout [L][S][d], llama2.ts:160-161), so a row is read by LR = head_size/4 (rounded up to a
+// power of two) adjacent lanes, 16 bytes each: one wave instruction covers 64/LR whole rows and touches each
+// 128-byte line once.  (The round-1 kernel gave every thread its own row: 64 lines per instruction, and the
+// address path, not HBM, set the time -- 11 500 cycles per head at 100 cached positions on stories110M.)
+//
+//   scores   (:249-254)  every lane multiplies its float4 of the row with its float4 of q in fp64; the LR partial
+//                        sums of a row are added through a wave-private LDS transpose (16 tiles at a time), one
+//                        rounding to fp32 after the fp64 divide by sqrt(head_size);
+//   softmax  (:181-194)  block-wide, with the reference's three roundings (exp stored fp32, sum of the rounded
+//                        values in fp64, quotient stored fp32);
+//   values   (:257-265)  same tiles, fp64 partial per (row slot, wave), summed through LDS, ONE rounding --
+//                        or, with `exact`, the reference's own t-sequential fp32-rounded accumulate.
+//
+// Every K and V tile of the first 16 x NW x (64/LR) rows is requested before anything is waited for; nothing in
+// the kernel depends on q until the first multiply.  Splits (flash-decode) publish {acc, l, m} write-through and
+// the last arriver of a head merges, as the MI355X guide's hand-off recipe prescribes (sc1 stores, every storing
+// wave drains, barrier, one agent-scope ticket; the merger reads with sc1 loads).
+#pragma once
+#include "kernels.hip.h"
+
+namespace l2k {
+
+struct AttnArgs {
+  const float* q;        // (dim) rotated q of this position
+  const float* kc;       // key_cache   + l*S*d   (row `pos` was written by the QKV launch before this one)
+  const float* vc;       // value_cache + l*S*d
+  float* att;            // (H, S) probabilities (RunState.att, parity reads)
+  float* xb;             // (dim) out
+  const int* tokpos;
+  double* part;          // split form: [H][nsplit][rec] doubles, rec = round_up(hs + 2, 16)
+  unsigned* counter;     // split form: [H] merge tickets (one per 128-byte line), zero between launches
+  int dim, head_size, seq_len, n_heads, nsplit;
+  double inv_sqrt_hs;    // 1 / sqrt(head_size)
+  int exact;             // 1: fp32-rounded t-sequential value accumulate (llama2.ts:263); never with nsplit > 1
+  int pos_plus1;         // scalar fallback kernel, prefill: non-zero = the queries are pos0 + blockIdx.y (else tokpos)
+  unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
+};
+
+constexpr int ATT_PS = 65;       // doubles per tile slot in the transpose buffer (odd: conflict-free reads)
+
+__host__ __device__ inline int attn_rec(int hs) { return (hs + 2 + 15) & ~15; }
+
+// NT = tiles (wave instructions) per wave per round.  LDS bytes: sc[cmax] floats | red[32] doubles | P[NW][NT][65] doubles (reused as the value partials
+// [NW * 64/LR][hs], never larger) -- the host sizes the launch with the same function.
+__host__ __device__ inline size_t attn_tile_lds(int S, int nsplit, int NW, int NT) {
+  const int cmax = (S + nsplit - 1) / nsplit;
+  return (size_t)((cmax + 3) & ~3) * 4 + 32 * 8 + (size_t)NW * NT * ATT_PS * 8;
+}
+
+template <int LR, int NW, int NT>
+__device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, const int h, const int sp, const int pos) {
+  constexpr int RPT = 64 / LR;             // rows per tile
+  constexpr int RG = NT * RPT;         // rows per wave per round
+  constexpr int RR = NW * RG;              // rows per workgroup per round
+  constexpr int NTH = 64 * NW;
+  const int S = a.seq_len, hs = a.head_size, dim = a.dim, NS = a.nsplit;
+  const int cmax = (S + NS - 1) / NS;
+  float* sc = reinterpret_cast<float*>(smem);
+  double* red = reinterpret_cast<double*>(smem + (size_t)((cmax + 3) & ~3) * 4);
+  double* P = red + 32;
+  unsigned* ticket = reinterpret_cast<unsigned*>(red + 31);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = pos + 1;
+  const int chunk = (T + NS - 1) / NS;
+  const int t0 = sp * chunk, t1 = min(T, t0 + chunk);
+  const int n = max(t1 - t0, 0);                       // rows of this workgroup
+  const int rounds = (n + RR - 1) / RR;
+  const int r = lane / LR, c = lane % LR;
+  const bool cl = 4 * c < hs;                           // lanes past the head's width carry zeros
+  const int cc4 = cl ? 4 * c : 0;
+
+  STAMP_INIT(a.dbg);
+  STAMP(0);
+  // ---- requests first: K tiles of round 0, then q, then (single round) the V tiles of round 0.
+  // Buffer loads: ONE 32-bit lane offset for all 16 tiles of a set (the tile stride goes in the scalar offset), and
+  // the descriptor ends at row t1, so rows past this workgroup's slice read as zeros -- no clamps, no predicates.
+  f4 ra[NT], rb[NT];
+  auto row_of = [&](int rd, int j) { return ((rd * NT + j) * NW + wave) * RPT + r; };   // relative to t0
+  const unsigned slab = (unsigned)max(t1, 0) * (unsigned)dim * 4u;
+  const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.kc), 0, slab, 0x00020000);
+  const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vc), 0, slab, 0x00020000);
+  const unsigned voff = (unsigned)(((size_t)(t0 + wave * RPT + r) * dim + (size_t)h * hs + cc4) * 4);
+  const unsigned tstride = (unsigned)(NW * RPT) * (unsigned)dim * 4u;                            // bytes between a wave's tiles
+  auto issue = [&](f4 (&buf)[NT], bool values, int rd) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      buf[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(values ? vrs : krs, voff, (unsigned)(rd * NT + j) * tstride, 0));
+  };
+  issue(ra, false, 0);
+  const f4 q4 = *reinterpret_cast<const f4*>(a.q + (size_t)h * hs + cc4);
+  if (rounds <= 1) issue(rb, true, 0);
+  const double q0 = cl ? (double)q4.x : 0.0, q1 = cl ? (double)q4.y : 0.0, q2 = cl ? (double)q4.z : 0.0, q3 = cl ? (double)q4.w : 0.0;
+  const double rsq = a.inv_sqrt_hs;             // 1 / sqrt(head_size), rounded once by the host (llama2.ts:253 divides)
+  double* Pw = P + (size_t)wave * NT * ATT_PS;
+  STAMP(1);
+
+  // ---- scores (llama2.ts:249-254)
+  auto score_round = [&](const f4 (&buf)[NT], int rd) {
+    // every tile, live or not (rows past the slice read as zeros): straight-line code, so the NT independent chains
+    // interleave -- a branch per tile left each chain's fp64 latency (~30 cycles an instruction) exposed
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const double s = (q0 * (double)buf[j].x + q1 * (double)buf[j].y) + (q2 * (double)buf[j].z + q3 * (double)buf[j].w);
+      Pw[j * ATT_PS + lane] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // wave-private transpose: dot (tile j, row slot rr) = sum over the row's LR lanes (four interleaved chains)
+#pragma unroll
+    for (int dd = lane; dd < NT * RPT; dd += 64) {
+      const int rr = dd / NT, j = dd % NT;
+      const int tr = ((rd * NT + j) * NW + wave) * RPT + rr;
+      const double* pp = Pw + j * ATT_PS + rr * LR;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < LR; k += 4) { s0 += pp[k]; s1 += pp[k + 1]; s2 += pp[k + 2]; s3 += pp[k + 3]; }
+      if (tr < n) sc[tr] = (float)(((s0 + s1) + (s2 + s3)) * rsq);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (rounds <= 1) {
+    score_round(ra, 0);
+  } else {
+    for (int rd = 0; rd < rounds; rd += 2) {        // A / B register sets: the next round is in flight while this one is used
+      if (rd + 1 < rounds) issue(rb, false, rd + 1);
+      score_round(ra, rd);
+      if (rd + 1 < rounds) {
+        if (rd + 2 < rounds) issue(ra, false, rd + 2);
+        score_round(rb, rd + 1);
+      }
+    }
+    issue(ra, true, 0);
+    if (rounds > 1) issue(rb, true, 1);
+  }
+  __syncthreads();
+  STAMP(2);
+
+  // ---- softmax (llama2.ts:181-194); a split keeps its own max / sum, rescaled at the merge.
+  // Every wave finds the maximum of all n scores itself (one LDS read per 64 rows): no barrier for it.
+  float mx = -INFINITY;
+  for (int t = lane; t < n; t += 64) mx = fmaxf(mx, sc[t]);
+  mx = wave_max(mx);
+  double lsum = 0.0;
+  float e_own = 0.0f;                                           // n <= NTH (the usual case): the thread's one element stays in a register
+  for (int t = tid; t < n; t += NTH) {
+    const float e = (float)exp_fast((double)sc[t] - (double)mx);    // stored to fp32 (llama2.ts:187)
+    if (n > NTH || NS != 1) sc[t] = e;
+    e_own = e;
+    lsum += (double)e;                                          // sum of the ROUNDED values (:190)
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[8 + wave] = lsum;
+  __syncthreads();
+  double sum = red[8];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) sum += red[8 + w];
+  if (NS == 1) {
+    const double rs = rcp_fast(sum);                            // llama2.ts:192 divides; the quotient is rounded to fp32
+    for (int t = tid; t < n; t += NTH) {
+      const float pr = (float)((double)(n > NTH ? sc[t] : e_own) * rs);
+      sc[t] = pr;
+      if (a.att) a.att[(size_t)h * S + t] = pr;
+    }
+  } else if (a.att) {
+    for (int t = tid; t < n; t += NTH) st_sc1(a.att + (size_t)h * S + t0 + t, sc[t]);   // rescaled by the merging workgroup
+  }
+  __syncthreads();
+  STAMP(3);
+
+  // ---- weighted sum of values (llama2.ts:257-265)
+  if (a.exact && NS == 1) {
+    // bit-faithful: the accumulator is a Float32Array element, rounded at every timestep, t ascending
+    for (int i = tid; i < hs; i += NTH) {
+      const float* vp = a.vc + (size_t)h * hs + i;
+      float o = 0.0f;
+      for (int t = 0; t < n; ++t) o = (float)((double)o + (double)sc[t] * (double)vp[(size_t)t * dim]);
+      a.xb[(size_t)h * hs + i] = o;
+    }
+    return;
+  }
+  double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;   // two sets of chains
+  auto value_round = [&](const f4 (&buf)[NT], int rd) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int tr = row_of(rd, j);
+      const double at = (tr < n) ? (double)sc[tr] : 0.0;
+      if (j & 1) { e0 += at * (double)buf[j].x; e1 += at * (double)buf[j].y; e2 += at * (double)buf[j].z; e3 += at * (double)buf[j].w; }
+      else { o0 += at * (double)buf[j].x; o1 += at * (double)buf[j].y; o2 += at * (double)buf[j].z; o3 += at * (double)buf[j].w; }
+    }
+  };
+  if (rounds <= 1) {
+    value_round(rb, 0);
+  } else {
+    for (int rd = 0; rd < rounds; rd += 2) {
+      value_round(ra, rd);
+      if (rd + 2 < rounds) issue(ra, true, rd + 2);
+      if (rd + 1 < rounds) {
+        value_round(rb, rd + 1);
+        if (rd + 3 < rounds) issue(rb, true, rd + 3);
+      }
+    }
+  }
+  o0 += e0; o1 += e1; o2 += e2; o3 += e3;
+  double* pacc = P;                                              // [NW * RPT][hs]: the transpose buffer is free now
+  if (cl) {
+    double* dst = pacc + (size_t)(wave * RPT + r) * hs + 4 * c;
+    dst[0] = o0; dst[1] = o1; dst[2] = o2; dst[3] = o3;
+  }
+  STAMP(4);
+  __syncthreads();
+  if (NS == 1) {
+    for (int i = tid; i < hs; i += NTH) {
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+      for (int g = 0; g < NW * RPT; g += 4) {
+        c0 += pacc[(size_t)g * hs + i]; c1 += pacc[(size_t)(g + 1) * hs + i];
+        c2 += pacc[(size_t)(g + 2) * hs + i]; c3 += pacc[(size_t)(g + 3) * hs + i];
+      }
+      a.xb[(size_t)h * hs + i] = (float)((c0 + c1) + (c2 + c3));   // ONE rounding of the fp64 sum
+    }
+    STAMP(5);
+    return;
+  }
+
+  // ---- split form: publish {acc, l, m}, last arriver of the head merges
+  const int rec = attn_rec(hs);
+  double* mypart = a.part + ((size_t)h * NS + sp) * rec;
+  for (int i = tid; i < hs; i += NTH) {
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+    for (int g = 0; g < NW * RPT; g += 4) {
+      c0 += pacc[(size_t)g * hs + i]; c1 += pacc[(size_t)(g + 1) * hs + i];
+      c2 += pacc[(size_t)(g + 2) * hs + i]; c3 += pacc[(size_t)(g + 3) * hs + i];
+    }
+    st_sc1(mypart + i, (c0 + c1) + (c2 + c3));
+  }
+  if (tid == 0) { st_sc1(mypart + hs, sum); st_sc1(mypart + hs + 1, (double)mx); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
+  __syncthreads();
+  if (tid == 0) *ticket = __hip_atomic_fetch_add(a.counter + (size_t)h * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*ticket != (unsigned)(NS - 1)) return;
+
+  const double* hp = a.part + (size_t)h * NS * rec;     // sc1 loads: they bypass this CU's L1
+  double M = -INFINITY;
+  for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, ld_sc1(hp + (size_t)s2 * rec + hs + 1));
+  double Lsum = 0.0;
+  for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + hs);
+  for (int i = tid; i < hs; i += NTH) {
+    double num = 0.0;
+    for (int s2 = 0; s2 < NS; ++s2) num += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + i);
+    a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
+  }
+  if (a.att) {
+    for (int t = tid; t < T; t += NTH) {                 // probabilities for parity reads of RunState.att
+      const double ws = exp(ld_sc1(hp + (size_t)(t / chunk) * rec + hs + 1) - M);
+      a.att[(size_t)h * S + t] = (float)((double)ld_sc1(a.att + (size_t)h * S + t) * ws / Lsum);
+    }
+  }
+  if (tid == 0) __hip_atomic_store(a.counter + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every split has its ticket: re-arm
+}
+
+// Tiles per wave per round by the rows this workgroup has: a short context requests (and pays address-path cycles
+// for) only the tiles it has -- NT / 4, NT / 2 or NT (one round covers NW * NT * 64 / LR rows).
+template <int LR, int NW, int NT>
+__device__ __forceinline__ void attn_tile_dispatch(const AttnArgs& a, char* smem, const int h, const int sp, const int pos) {
+  const int T = pos + 1, NS = a.nsplit;
+  const int chunk = (T + NS - 1) / NS;
+  const int n = min(T, sp * chunk + chunk) - sp * chunk;
+  constexpr int RQ = NW * (NT / 4) * (64 / LR);
+  if (n <= RQ) attn_tile_body<LR, NW, NT / 4>(a, smem, h, sp, pos);
+  else if (n <= 2 * RQ) attn_tile_body<LR, NW, NT / 2>(a, smem, h, sp, pos);
+  else attn_tile_body<LR, NW, NT>(a, smem, h, sp, pos);
+}
+
+template <int LR, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_tile_dispatch<LR, NW, NT>(a, smem, blockIdx.x, blockIdx.y, a.tokpos[1]);
+}
+
+// Prefill: grid (head, query).  Query p of the chunk sits at position pos0 + p and sees cache rows 0..pos0+p,
+// all written by the chunk's QKV GEMM in an earlier launch.
+template <int LR, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW) pf_attn_tile_kernel(const AttnArgs a, int pos0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  AttnArgs b = a;
+  const int p = blockIdx.y;
+  b.q = a.q + (size_t)p * a.dim;
+  b.xb = a.xb + (size_t)p * a.dim;
+  b.att = nullptr;
+  b.nsplit = 1;
+  attn_tile_dispatch<LR, NW, NT>(b, smem, blockIdx.x, 0, pos0 + p);
+}
+
+// Shapes whose head_size or dim is not a multiple of 4 (rows are not 16-byte aligned): one workgroup per head,
+// one thread per timestep, scalar loads.  Correctness only; keeps every rounding of the reference.
+__global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int pos0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = a.seq_len, hs = a.head_size, dim = a.dim, h = blockIdx.x, tid = threadIdx.x;
+  float* att = reinterpret_cast<float*>(smem);                    // S floats
+  double* red = reinterpret_cast<double*>(att + ((S + 3) & ~3));  // 8 doubles
+  const int pos = a.pos_plus1 ? pos0 + (int)blockIdx.y : a.tokpos[1];
+  const float* q = a.q + (a.pos_plus1 ? (size_t)blockIdx.y * dim : 0) + (size_t)h * hs;
+  float* xb = a.xb + (a.pos_plus1 ? (size_t)blockIdx.y * dim : 0) + (size_t)h * hs;
+  const double rsq = sqrt((double)hs);
+  for (int t = tid; t <= pos; t += 256) {
+    const float* kp = a.kc + (size_t)t * dim + (size_t)h * hs;
+    double s = 0.0;
+    for (int i = 0; i < hs; ++i) s += (double)q[i] * (double)kp[i];
+    att[t] = (float)(s / rsq);
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = tid; t <= pos; t += 256) mx = fmaxf(mx, att[t]);
+  mx = wave_max(mx);
+  float* redf = reinterpret_cast<float*>(red);
+  if ((tid & 63) == 0) redf[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+  __syncthreads();
+  double lsum = 0.0;
+  for (int t = tid; t <= pos; t += 256) { const float e = (float)exp((double)att[t] - (double)mx); att[t] = e; lsum += (double)e; }
+  const double sum = block_sum(lsum, red, tid, 256);
+  for (int t = tid; t <= pos; t += 256) {
+    const float pr = (float)((double)att[t] / sum);
+    att[t] = pr;
+    if (a.att && !a.pos_plus1) a.att[(size_t)h * S + t] = pr;
+  }
+  __syncthreads();
+  for (int i = tid; i < hs; i += 256) {
+    const float* vp = a.vc + (size_t)h * hs + i;
+    if (a.exact) {
+      float o = 0.0f;
+      for (int t = 0; t <= pos; ++t) o = (float)((double)o + (double)att[t] * (double)vp[(size_t)t * dim]);
+      xb[i] = o;
+    } else {
+      double o = 0.0;
+      for (int t = 0; t <= pos; ++t) o += (double)att[t] * (double)vp[(size_t)t * dim];
+      xb[i] = (float)o;
+    }
+  }
+}
+
+}  // namespace l2k

@@ -27,10 +27,13 @@
 #include <vector>
 
 #include "kernels.hip.h"
+#include "attention.hip.h"
 #include "prefill.hip.h"
 #include "sampler.h"
 
 using namespace l2k;
+
+enum { NLEV = 4 };   // attention split levels: 1, 2, 4, 8 workgroups per head
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -143,7 +146,7 @@ struct l2_ctx {
   int d_loc, h_loc, H_loc, V_loc;
   nccl_comm comm = nullptr;
   l2s::Sampler samp;                 // device sampler (l2_decode_sample), created on first use
-  hipGraphExec_t g_sample[3][2] = {};  // [attention split level][plain sample / top-p]
+  hipGraphExec_t g_sample[NLEV][2] = {};  // [attention split level][plain sample / top-p]
   int samp_mode = 0;
   std::shared_ptr<LoopGroup> loop;   // L2_TP_LOOPBACK test hook (see LoopGroup)
   double* loop_tmp = nullptr;
@@ -162,29 +165,16 @@ struct l2_ctx {
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int cur_splits = 1;               // split count of the step being enqueued / captured
-  unsigned* head_done = nullptr;    // [H] fused QKV+attention hand-off counters, zero between launches
-  unsigned* wo_sync = nullptr;      // attn_wo_kernel: {ready, done} counters on separate lines, zero between launches
-  int opt_fuse_wo = 0;              // L2_FUSE_WO=1: attention + register-resident wo in one launch (experimental, measured: no gain)
-  int attn_pre = 1;                 // L2_ATTN_PRE: attention with loads up front (launch_attn): 0 never, 1 (default) 64-wide heads, 2 also 128-wide, 3 V rows only
+  int split_bytes = 128 << 10;      // L2_ATTN_SPLIT_BYTES: K + V bytes of a head per attention workgroup before it is split further
+  int attn_nw = 0;                  // L2_ATTN_NW: waves per attention workgroup (0: by head size)
+  int small_max = 0;                // L2_SMALL_MAX: largest matrix (floats) that takes the latency-form GEMV
   int n_cus = 256;
-  int* h_err = nullptr;             // pinned + mapped: set by a kernel whose bounded wait gave up
-  int* h_err_dev = nullptr;
-  int opt_fuse = 0;                 // L2_FUSE_ATTN: attention inside the QKV launch (experimental)
   std::vector<hipEvent_t> probe;    // in-situ probe: event pairs around every launch of the dominant kernel
   size_t probe_used = 0;
   bool probe_on = false;
-  // chain launch: one kernel per token (kernels.hip.h chain_kernel)
-  int opt_chain = 0;
-  int chain_cap = 768;              // workgroups per GEMV phase
-  unsigned* chain_ctr = nullptr;    // per phase: 16 shard lines, 1 top line, 8 flag lines
-  size_t chain_ctr_bytes = 0;
-  float* chain_act = nullptr;       // per-layer activations: no buffer is rewritten inside one launch (see build_chain)
-  size_t chain_act_stride = 0;      // floats per layer
-  double* chain_part = nullptr;     // per-layer split-attention partials
   // prefill (prefill.hip.h): 16-token chunk buffers
   float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_xb = nullptr, *pf_hb = nullptr;
   int* pf_tok = nullptr;
-  struct ChainSet { ChainPhase* d_phases = nullptr; ChainLaunch cl; size_t lds = 0; int blocks = 0; bool built = false; } chain[3][2];
   int* tokpos = nullptr;    // device {token,pos,step,0}
   int* h_tokpos = nullptr;  // pinned
   int* d_tokens = nullptr;  // device, S ints
@@ -194,7 +184,7 @@ struct l2_ctx {
   int profile_sync = 0;
   unsigned long long* dbg = nullptr;  // L2_STAMPS builds
 
-  hipGraphExec_t g_step[3] = {}, g_greedy[3] = {};   // one captured graph per attention split level
+  hipGraphExec_t g_step[NLEV] = {}, g_greedy[NLEV] = {};   // one captured graph per attention split level
   int opt_exact = 0, opt_graph = 1;
   int next_pos = 0;
   bool ran_forward = false;
@@ -237,23 +227,24 @@ extern "C" int l2_device_count(void) {
 }
 
 static void destroy_graphs(l2_ctx* c) {
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NLEV; ++i) {
     if (c->g_step[i]) { hipGraphExecDestroy(c->g_step[i]); c->g_step[i] = nullptr; }
     if (c->g_greedy[i]) { hipGraphExecDestroy(c->g_greedy[i]); c->g_greedy[i] = nullptr; }
     for (int m = 0; m < 2; ++m) if (c->g_sample[i][m]) { hipGraphExecDestroy(c->g_sample[i][m]); c->g_sample[i][m] = nullptr; }
   }
 }
 
-// Attention split level by context length (measured on 7B, tools/ctx_curve.py with L2_ATTN_SPLITS=2/4/8/16): one
-// workgroup per head is fastest below ~256 cached timesteps, 4 splits up to ~512, 8 beyond (ms per token at pos 768:
-// 5.16 with 4 splits, 5.11 with 8; pos 1920: 6.26 / 5.60 / 5.39 / 5.58 with 2 / 4 / 8 / 16).
-static const int kSplitLevels[3] = {1, 4, 8};
-// 64-wide heads (stories110M, same tool): 8 splits never pay below 1024 positions (pos 768: 0.412 ms with 4, 0.439 with 8),
-// so the second threshold scales with the bytes of a head's cache rows: 65536 / head_size positions.
+// Attention split level by context length.  A head's cache rows are read by ONE workgroup per split, and one CU pulls
+// ~50-100 GB/s however many loads it keeps in flight, so a head is split over more workgroups (flash-decode merge by
+// the last arriver, attention.hip.h) once its K + V rows exceed `split_bytes` per workgroup: 2, 4, then 8 splits.
+// The merge costs ~1.5 us, which sets the threshold (tools/ctx_curve.py).
+static const int kSplitLevels[NLEV] = {1, 2, 4, 8};
 static int split_level(const l2_ctx* c, int pos) {
-  if (c->attn_splits_forced > 0) return 0;
-  const int t8 = (c->hs > 0 && 65536 / c->hs > 512) ? 65536 / c->hs : 512;
-  return pos < 256 ? 0 : (pos < t8 ? 1 : 2);
+  if (c->attn_splits_forced > 0 || c->opt_exact) return 0;
+  const long long bytes = (long long)(pos + 1) * c->hs * 8;
+  int lvl = 0;
+  while (lvl < NLEV - 1 && bytes > ((long long)c->split_bytes << lvl)) ++lvl;
+  return lvl;
 }
 static int splits_of(const l2_ctx* c, int level) { return c->attn_splits_forced > 0 ? c->attn_splits_forced : kSplitLevels[level]; }
 
@@ -274,14 +265,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->attn_part) hipFree(c->attn_part);
   if (c->attn_counter) hipFree(c->attn_counter);
   for (hipEvent_t e : c->probe) hipEventDestroy(e);
-  if (c->head_done) hipFree(c->head_done);
-  if (c->wo_sync) hipFree(c->wo_sync);
-  if (c->chain_ctr) hipFree(c->chain_ctr);
-  if (c->chain_act) hipFree(c->chain_act);
   { float* pb[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_xb, c->pf_hb}; for (float* b : pb) if (b) hipFree(b); if (c->pf_tok) hipFree(c->pf_tok); }
-  if (c->chain_part) hipFree(c->chain_part);
-  for (auto& lv : c->chain) for (auto& cs : lv) if (cs.d_phases) hipFree(cs.d_phases);
-  if (c->h_err) hipHostFree(c->h_err);
   if (c->tokpos) hipFree(c->tokpos);
   if (c->d_tokens) hipFree(c->d_tokens);
   if (c->h_tokpos) hipHostFree(c->h_tokpos);
@@ -367,8 +351,9 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMemsetAsync(c->logits, 0, (size_t)V * 4, c->stream));
   // split attention scratch (sized for the largest split count)
   c->attn_splits_forced = env_int("L2_ATTN_SPLITS", 0);
-  c->opt_fuse_wo = env_int("L2_FUSE_WO", 0);
-  c->attn_pre = env_int("L2_ATTN_PRE", 1);
+  c->attn_nw = env_int("L2_ATTN_NW", 0);
+  c->split_bytes = env_int("L2_ATTN_SPLIT_BYTES", 128 << 10);
+  c->small_max = env_int("L2_SMALL_MAX", 8 << 20);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->pf_lds = env_int("L2_PF_LDS", 1);
   if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;
@@ -378,16 +363,6 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     CK(hipMalloc(&c->attn_part, (size_t)c->H_loc * maxs * rec * 8));
     CK(hipMalloc(&c->attn_counter, (size_t)c->H_loc * CTR_STRIDE * 4));
     CK(hipMemsetAsync(c->attn_counter, 0, (size_t)c->H_loc * CTR_STRIDE * 4, c->stream));
-    CK(hipMalloc(&c->wo_sync, 2 * CTR_STRIDE * 4));
-    CK(hipMemsetAsync(c->wo_sync, 0, 2 * CTR_STRIDE * 4, c->stream));
-    CK(hipMalloc(&c->head_done, (size_t)c->H_loc * CTR_STRIDE * 4));
-    CK(hipMemsetAsync(c->head_done, 0, (size_t)c->H_loc * CTR_STRIDE * 4, c->stream));
-    CK(hipHostMalloc(&c->h_err, sizeof(int), hipHostMallocMapped));
-    *c->h_err = 0;
-    CK(hipHostGetDevicePointer((void**)&c->h_err_dev, c->h_err, 0));
-    c->opt_chain = env_int("L2_CHAIN", 0);
-    c->chain_cap = env_int("L2_CHAIN_CAP", 768);
-    c->opt_fuse = env_int("L2_FUSE_ATTN", 0);   // measured: no gain (the last head's attention latency stays exposed), off by default
   }
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
@@ -398,8 +373,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipHostGetDevicePointer((void**)&c->h_logits_dev, c->h_logits, 0));
   c->opt_zero_copy = env_int("L2_ZERO_COPY_LOGITS", G == 1 ? 1 : 0);
 #ifdef L2_STAMPS
-  CK(hipMalloc(&c->dbg, 8 * 64 * 64));
-  CK(hipMemset(c->dbg, 0, 8 * 64 * 64));
+  CK(hipMalloc(&c->dbg, 8 * 66 * 108));
+  CK(hipMemset(c->dbg, 0, 8 * 66 * 108));
 #endif
   CK(hipStreamSynchronize(c->stream));
 #undef CK
@@ -709,16 +684,66 @@ extern "C" int l2_debug_stamps(l2_ctx* c, unsigned long long* out, size_t n) {
 }
 #endif
 
+
+// LDS a launch may ask for: 160 KiB per CU on gfx950, opted into per kernel (the default cap is 64 KiB).
+template <class K>
+static hipError_t lds_opt_in(K kernel, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// Latency form (kernels.hip.h: phase_small_kernel) for matrices of at most `small_max` floats whose input vector fits
+// 8 float4 per lane; everything else (Llama-2-7B's phases, every classifier) streams through phase_kernel.
+static bool use_small(const l2_ctx* c, int mode, int rows, int n) {
+  if (n % 4 || n > 2048 || mode == MODE_CLS) return false;
+  const long long elems = (long long)rows * n * (mode == MODE_W13 ? 2 : 1);
+  return elems <= (long long)c->small_max;
+}
+
+template <int MODE, int XV>
+static hipError_t launch_small_xv(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
+  constexpr bool pair = (MODE == MODE_QKV || MODE == MODE_W13);       // row pairs: RoPE neighbours / (w1, w3)
+  const size_t lds = (size_t)XV * 64 * 16;
+  const int waves = c->n_cus * 7;     // seven compute waves per workgroup (kernels.hip.h)
+  // one row per wave while that still leaves waves idle, else two
+  const bool r1 = !pair && a.rows <= waves;
+  const int rpg = (MODE == MODE_W13) ? 1 : (r1 ? 1 : 2);
+  const int groups = (a.rows + rpg - 1) / rpg;
+  int grid = (groups + 6) / 7;
+  if (grid > c->n_cus) grid = c->n_cus;
+  if (grid < 1) grid = 1;
+  if (!pair && r1) hipLaunchKernelGGL((phase_small_kernel<MODE, XV, pair ? 2 : 1>), dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((phase_small_kernel<MODE, XV, 2>), dim3(grid), dim3(512), lds, st, a);
+  return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_small(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
+  const int xv = (a.n / 4 + 63) / 64;
+  switch (xv) {
+    case 1: return launch_small_xv<MODE, 1>(c, a, st);
+    case 2: return launch_small_xv<MODE, 2>(c, a, st);
+    case 3: return launch_small_xv<MODE, 3>(c, a, st);
+    case 4: return launch_small_xv<MODE, 4>(c, a, st);
+    case 5: case 6: return launch_small_xv<MODE, 6>(c, a, st);
+    default: return launch_small_xv<MODE, 8>(c, a, st);
+  }
+}
+
 template <int MODE>
 static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream_t st) {
   PhaseArgs a = a_in;
 #ifdef L2_STAMPS
-  a.dbg = c->dbg + (size_t)(g_stamp_slot++ % 64) * 36;
+  a.dbg = c->dbg + (size_t)(g_stamp_slot++ % 64) * 108;
 #endif
+  if (use_small(c, MODE, a.rows, a.n)) return launch_small<MODE>(c, a, st);
   const Geo g = pick_geo(c, MODE, a.rows, a.n, a.dim);
   const dim3 grid(g.grid), block(64 * g.nwaves);
   if (!g.vec) {
     const size_t lds = (((size_t)a.n * 4 + 15) & ~(size_t)15) + 64;
+    hipError_t e = lds_opt_in(&phase_kernel_scalar<MODE>, lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((phase_kernel_scalar<MODE>), grid, block, lds, st, a);
     return hipGetLastError();
   }
@@ -728,7 +753,8 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   const int round4 = g.pre * 64 * g.nwaves;                   // PRE * nthreads (kernels.hip.h)
   const int nstage4 = ((npad4 + round4 - 1) / round4) * round4;
   const size_t lds = (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
-#define L2_LAUNCH(UU, PP) hipLaunchKernelGGL((phase_kernel<MODE, 2, UU, PP>), grid, block, lds, st, a)
+#define L2_LAUNCH(UU, PP) do { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \
+                               hipLaunchKernelGGL((phase_kernel<MODE, 2, UU, PP>), grid, block, lds, st, a); } while (0)
 #define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else L2_LAUNCH(UU, 4); } while (0)
   if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
 #undef L2_LAUNCH_U
@@ -736,146 +762,61 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   return hipGetLastError();
 }
 
-static int attn_lpr(int hs, bool vec) {
-  const int need = vec ? (hs + 3) / 4 : hs;
-  int l = 1;
-  while (l < need) l <<= 1;
-  return l;
-}
+static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4 == 0) && c->hs <= 256; }
 
-static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4 == 0); }
-
-static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a, int* G_out) {
+static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
   const size_t loff = (size_t)l * c->S * c->d_loc;
   memset(&a, 0, sizeof(a));
-  a.q = c->q; a.knew = c->k; a.vnew = c->v; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb;
-  a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter; a.head_done = c->head_done; a.err = c->h_err_dev;
+  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb;
+  a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter;
   a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
   a.exact = c->opt_exact;
-  a.lpr = attn_lpr(c->hs, attn_vec(c));
-  *G_out = 256 / a.lpr;
+  a.inv_sqrt_hs = 1.0 / sqrt((double)c->hs);
 #ifdef L2_STAMPS
-  a.dbg = c->dbg + 64 * 36;   // attention stamps live behind the phase-kernel slots (last launch wins)
+  a.dbg = c->dbg + 64 * 108;   // attention stamps live behind the phase-kernel slots (last launch wins)
 #endif
 }
 
-static size_t attn_lds(const l2_ctx* c, const AttnArgs& a, int G, bool split) {
-  const size_t hs4 = (size_t)((c->hs + 3) & ~3);
-  if (split) {
-    const int cmax = (c->S + a.nsplit - 1) / a.nsplit;
-    return (size_t)((cmax + 3) & ~3) * 4 + 4 * hs4 * 4 + 128 + (size_t)G * c->hs * 8;
+// Lanes per cache row: head_size / 4 rounded up to a power of two (attention.hip.h); waves per workgroup: 8 from
+// 128-wide heads (a round is then 256 rows), else 4.
+static int attn_lr(int hs) { int l = 4; while (l * 4 < hs) l <<= 1; return l; }
+static int attn_nw(const l2_ctx* c) { return (c->attn_nw == 4 || c->attn_nw == 8) ? c->attn_nw : (c->hs > 64 ? 8 : 4); }
+
+// One launch of the tile kernel; ny = splits (decode) or queries of the chunk (prefill, pos0 >= 0).
+static hipError_t launch_attn_tile(const l2_ctx* c, const AttnArgs& a, int ny, int pos0, hipStream_t st) {
+  const int lr = attn_lr(c->hs), nw = attn_nw(c);
+  const size_t lds = attn_tile_lds(c->S, pos0 >= 0 ? 1 : a.nsplit, nw, nw == 8 ? 8 : 16);
+  const dim3 grid(c->H_loc, ny), block(64 * nw);
+  // 4 waves x 16 tiles (one wave per SIMD, ~290 registers) or 8 waves x 8 tiles (two per SIMD, <= 256 registers)
+#define L2_AT(LR, NW, NT) do { if (pos0 >= 0) { hipError_t e_ = lds_opt_in(&pf_attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
+                                            hipLaunchKernelGGL((pf_attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a, pos0); } \
+                           else { hipError_t e_ = lds_opt_in(&attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
+                                  hipLaunchKernelGGL((attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a); } } while (0)
+#define L2_AT_NW(LR) do { if (nw == 8) L2_AT(LR, 8, 8); else L2_AT(LR, 4, 16); } while (0)
+  switch (lr) {
+    case 4: L2_AT_NW(4); break;
+    case 8: L2_AT_NW(8); break;
+    case 16: L2_AT_NW(16); break;
+    case 32: L2_AT_NW(32); break;
+    default: L2_AT_NW(64); break;
   }
-  return (size_t)((c->S + 3) & ~3) * 4 + 4 * hs4 * 4 + 64 + (size_t)G * c->hs * 8;
+#undef L2_AT_NW
+#undef L2_AT
+  return hipGetLastError();
 }
 
-static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {
+static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // attention (llama2.ts:244-267)
   AttnArgs a;
-  int G;
-  fill_attn_args(c, l, a, &G);
-  if (a.lpr > 64) return hipErrorInvalidValue;
-  const bool vec = attn_vec(c);
-  const bool split = c->cur_splits > 1 && !c->opt_exact;
-  const size_t lds = attn_lds(c, a, G, split);
-  if (split) {
-    if (vec) hipLaunchKernelGGL((attn_split_kernel<true>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((attn_split_kernel<false>), dim3(c->H_loc, a.nsplit), dim3(256), lds, st, a);
-  } else {
-    // every load up front, 512 threads per head (kernels.hip.h: attn_pre_body): contexts below 256, 64- / 128-wide heads
-    // L2_ATTN_PRE: 0 never; 1 (default) 64-wide heads, K and V rows up front; 2 128-wide heads too; 3 V rows up front only
-    // (K rows where the dot uses them).  Same box: stories110M 3130 / 3188 / - / 3195 tok/s, Llama-2-7B 209.7 / - / 207.5 / 204.8.
-    const bool ok = vec && !c->opt_exact && c->attn_splits_forced == 0 && c->cur_splits <= 1 && (c->hs == 64 || c->hs == 128);
-    const int mode = !ok ? 0 : (c->attn_pre >= 3 ? 3 : (c->hs == 64 && c->attn_pre >= 1) || (c->hs == 128 && c->attn_pre >= 2) ? 1 : 0);
-    if (mode && c->hs == 128) {
-      if (mode == 3) hipLaunchKernelGGL((attn_pre_kernel<32, false>), dim3(c->H_loc), dim3(512), lds, st, a);
-      else hipLaunchKernelGGL((attn_pre_kernel<32, true>), dim3(c->H_loc), dim3(512), lds, st, a);
-    } else if (mode && c->hs == 64) {
-      if (mode == 3) hipLaunchKernelGGL((attn_pre_kernel<16, false>), dim3(c->H_loc), dim3(512), lds, st, a);
-      else hipLaunchKernelGGL((attn_pre_kernel<16, true>), dim3(c->H_loc), dim3(512), lds, st, a);
-    }
-    else if (vec) hipLaunchKernelGGL((attn_kernel<true>), dim3(c->H_loc), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((attn_kernel<false>), dim3(c->H_loc), dim3(256), lds, st, a);
+  fill_attn_args(c, l, a);
+  if (!attn_vec(c)) {
+    const size_t lds = (size_t)((c->S + 3) & ~3) * 4 + 64;
+    hipError_t e = lds_opt_in(&attn_scalar_kernel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_scalar_kernel, dim3(c->H_loc, 1), dim3(256), lds, st, a, 0);
+    return hipGetLastError();
   }
-  return hipGetLastError();
-}
-
-// rmsnorm + QKV + RoPE + KV store + attention of layer l in one launch (qkv_attn_kernel).
-static bool can_fuse_attn(const l2_ctx* c) { return c->opt_fuse && attn_vec(c) && (c->d % 4 == 0); }
-
-// attention + register-resident wo in one launch (kernels.hip.h: attn_wo_kernel).  One workgroup per CU: H of them
-// run the attention, the rest hold wo.  Shapes map onto the instantiated (float4 per lane per row, rows per wave).
-static int fuse_wo_shape(const l2_ctx* c, int* nf4, int* maxr) {
-  const int nwo = c->n_cus - c->H_loc;
-  if (nwo < 8 || c->d % 4) return 0;
-  *nf4 = (c->d / 4 + 63) / 64;
-  const int rows_wg = (c->d + nwo - 1) / nwo;
-  *maxr = (rows_wg + 7) / 8;
-  return (*nf4 == 16 && *maxr == 3 && c->hs == 128) || (*nf4 == 3 && *maxr == 1 && c->hs == 64);   // the instantiated shapes: 7B, stories110M
-}
-static bool can_fuse_wo(const l2_ctx* c) {
-  int nf4, maxr;
-  return c->opt_fuse_wo && !c->tp_path && !c->opt_exact && c->cur_splits <= 1 && c->attn_splits_forced == 0 && attn_vec(c) && c->wo_sync && fuse_wo_shape(c, &nf4, &maxr);
-}
-
-static hipError_t launch_attn_wo(const l2_ctx* c, int l, hipStream_t st) {
-  AttnArgs a;
-  int G;
-  fill_attn_args(c, l, a, &G);
-  if (a.lpr > 64) return hipErrorInvalidValue;
-  a.xb_sc1 = 1;
-  WoRegArgs wa;
-  memset(&wa, 0, sizeof(wa));
-  wa.w = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l;
-  wa.xb = c->xb; wa.res = c->x; wa.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; wa.out = c->x; wa.aux = c->xb2;
-  wa.tokpos = c->tokpos; wa.ready = c->wo_sync; wa.done = c->wo_sync + CTR_STRIDE; wa.err = c->h_err_dev;
-  wa.rows = c->d; wa.n = c->d; wa.dim = c->d; wa.n_attn = c->H_loc;
-  wa.delay = env_int("L2_FUSE_WO_DELAY", 0);
-#ifdef L2_STAMPS
-  wa.dbg = c->dbg + 64 * 36 + 36;   // behind the attention stamps
-#endif
-  int nf4 = 0, maxr = 0;
-  fuse_wo_shape(c, &nf4, &maxr);
-  size_t lds = attn_lds(c, a, G, false);
-  if (lds < (size_t)nf4 * 64 * 16) lds = (size_t)nf4 * 64 * 16;
-  const dim3 grid(c->n_cus), block(512);
-  if (nf4 == 16) hipLaunchKernelGGL((attn_wo_kernel<16, 3, 32>), grid, block, lds, st, a, wa);
-  else hipLaunchKernelGGL((attn_wo_kernel<3, 1, 16>), grid, block, lds, st, a, wa);
-  return hipGetLastError();
-}
-
-static hipError_t launch_qkv_attn(const l2_ctx* c, int l, const PhaseArgs& pa_in, hipStream_t st) {
-  PhaseArgs pa = pa_in;
-  pa.head_done = c->head_done;
-  AttnArgs a;
-  int G;
-  fill_attn_args(c, l, a, &G);
-  if (a.lpr > 64) return hipErrorInvalidValue;
-  a.fused = 1;
-  a.expect = (unsigned)(3 * c->hs / 2);                      // row groups per head at R = 2
-  const bool split = c->cur_splits > 1 && !c->opt_exact;
-  const int nattn = c->H_loc * (split ? a.nsplit : 1);
-  // GEMV geometry at 4 waves per workgroup (one block size for the whole launch)
-  const int n4 = pa.n / 4;
-  int U = (n4 <= 64) ? 1 : 2;
-  if (n4 > 128 && n4 <= 256) U = 4;
-  if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4) U = c->tune_U;
-  const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 256;
-  const int pre = (npad4 <= nth) ? 1 : (npad4 <= 2 * nth ? 2 : 4);
-  const int groups = (pa.rows + 1) / 2;
-  int ggrid = (groups + 3) / 4;
-  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : 256 * 6;
-  if (ggrid > cap) ggrid = cap;
-  const int round4 = pre * nth, nstage4 = ((npad4 + round4 - 1) / round4) * round4;
-  size_t lds = (size_t)nstage4 * 2 * 16 + 64;
-  const size_t alds = attn_lds(c, a, G, split);
-  if (alds > lds) lds = alds;
-  const dim3 grid(nattn + ggrid), block(256);
-#define L2_QA(UU, PP) do { if (split) hipLaunchKernelGGL((qkv_attn_kernel<UU, PP, true>), grid, block, lds, st, pa, a); \
-                           else hipLaunchKernelGGL((qkv_attn_kernel<UU, PP, false>), grid, block, lds, st, pa, a); } while (0)
-#define L2_QA_U(UU) do { if (pre == 1) L2_QA(UU, 1); else if (pre == 2) L2_QA(UU, 2); else L2_QA(UU, 4); } while (0)
-  if (U == 1) L2_QA_U(1); else if (U == 2) L2_QA_U(2); else L2_QA_U(4);
-#undef L2_QA_U
-#undef L2_QA
-  return hipGetLastError();
+  if (c->opt_exact) a.nsplit = 1;
+  return launch_attn_tile(c, a, a.nsplit, -1, st);
 }
 
 __global__ void tp_residual_kernel(float* x, const float* res_emb, const double* sum, float* mv_out, const int* tokpos, int d) {
@@ -890,12 +831,12 @@ __global__ void tp_residual_kernel(float* x, const float* res_emb, const double*
 #define LCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(L2_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 // Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
-// PhaseArgs of each phase of layer l (shared by the per-phase launches and the chain launch)
+// PhaseArgs of each phase of layer l
 static PhaseArgs base_args(const l2_ctx* c) {
   PhaseArgs a;
   memset(&a, 0, sizeof(a));
   a.tokpos = c->tokpos; a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG];
-  a.head_size = c->hs; a.dim = c->d; a.err = c->h_err_dev;
+  a.head_size = c->hs; a.dim = c->d; a.inv_n = 1.0 / (double)c->d;   // every normed phase has n == dim
   return a;
 }
 static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs + RoPE + KV-cache store (llama2.ts:216-240)
@@ -944,162 +885,6 @@ static PhaseArgs cls_args(const l2_ctx* c, bool to_host) {   // final rmsnorm + 
   return a;
 }
 
-// ---- chain launch -----------------------------------------------------------------------------
-#ifdef L2_STAMPS
-static unsigned long long* g_chain_tl = nullptr; static int g_chain_blocks = 0; static ChainLaunch g_chain_off;
-extern "C" int l2_debug_chain_timeline(unsigned long long* out, int* nblocks, int* off6, int* L, int* cls) {
-  hipDeviceSynchronize();
-  if (out) hipMemcpy(out, g_chain_tl, (size_t)g_chain_blocks * 16, hipMemcpyDeviceToHost);
-  *nblocks = g_chain_blocks; for (int i = 0; i < 6; ++i) off6[i] = g_chain_off.off[i]; *L = g_chain_off.L; cls[0] = g_chain_off.cls_first; cls[1] = g_chain_off.cls_blocks;
-  return 0;
-}
-#endif
-static bool can_chain(const l2_ctx* c) {
-  return c->opt_chain && !c->tp_path && (c->d % 4 == 0) && (c->h % 4 == 0) && attn_vec(c);
-}
-
-static unsigned* chain_line(const l2_ctx* c, int phase, int line) { return c->chain_ctr + ((size_t)phase * 16 + line) * CTR_STRIDE; }
-
-static void chain_wire(const l2_ctx* c, PhaseArgs& a, int q, int prev_blocks) {   // counters of phase q, wait on phase q-1
-  a.done_shard = chain_line(c, q, 0);
-  const bool wait = q > 0 && !env_int("L2_CHAIN_NOWAIT", 0);   // NOWAIT: timing experiment only (wrong results)
-  a.wait_shard = wait ? chain_line(c, q - 1, 0) : nullptr;
-  a.wait_blocks = prev_blocks;
-  a.err = c->h_err_dev;
-}
-
-static int chain_blocks(const l2_ctx* c, int mode, int rows) {
-  const int groups = (rows * (mode == MODE_W13 ? 2 : 1) + 1) / 2;
-  int b = (groups + 3) / 4;
-  if (b > c->chain_cap) b = c->chain_cap;
-  return b < 1 ? 1 : b;
-}
-
-static size_t chain_phase_lds(int mode, int n, int U) {
-  const int n4 = n / 4, cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi;
-  const int round4 = 4 * 256, nstage4 = ((npad4 + round4 - 1) / round4) * round4;
-  const bool norm = (mode == MODE_QKV || mode == MODE_W13 || mode == MODE_CLS);
-  return (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
-}
-
-static int chain_U(int n) { const int n4 = n / 4; return (n4 > 128 && n4 <= 256) ? 4 : 2; }
-
-static int build_chain(l2_ctx* c, int level, int greedy) {
-  l2_ctx::ChainSet& cs = c->chain[level][greedy];
-  if (cs.built) return L2_OK;
-  const int nph = 5 * c->L + 1 + (greedy ? 1 : 0);
-  if (!c->chain_ctr) {
-    c->chain_ctr_bytes = (size_t)(5 * c->L + 2) * 16 * CTR_STRIDE * 4;
-    // uncached (fine-grained) memory: a polled flag must never be served from a stale line of the poller's L2
-    HIPCHK(hipExtMallocWithFlags((void**)&c->chain_ctr, c->chain_ctr_bytes, hipDeviceMallocUncached));
-    HIPCHK(hipMemset(c->chain_ctr, 0, c->chain_ctr_bytes));
-  }
-  // Per-XCD L2s are not coherent: a buffer that one XCD rewrites inside a launch can be served stale from
-  // another XCD's L2 even to an L1-bypassing load (observed: xb of layer 1 read as layer 0's).  So inside one
-  // chain launch every activation buffer is written exactly once: each layer has its own q/k/v/xb/x/hb/att
-  // (kernel boundaries between tokens make the reuse across launches safe, as for the per-phase launches).
-  const size_t dl = c->d_loc, rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;
-  const size_t o_q = 0, o_k = dl, o_v = 2 * dl, o_xb = 3 * dl, o_xm = 4 * dl, o_hb = o_xm + c->d, o_xo = o_hb + c->h_loc,
-               o_att = o_xo + c->d, stride = (o_att + (size_t)c->H_loc * c->S + 63) & ~(size_t)63;
-  if (!c->chain_act) {
-    c->chain_act_stride = stride;
-    HIPCHK(hipMalloc(&c->chain_act, stride * c->L * sizeof(float)));
-    HIPCHK(hipMemset(c->chain_act, 0, stride * c->L * sizeof(float)));
-    HIPCHK(hipMalloc(&c->chain_part, (size_t)c->L * c->H_loc * 8 * rec * sizeof(double)));
-  }
-  auto act = [&](int l, size_t off) { return c->chain_act + (size_t)l * stride + off; };
-  std::vector<ChainPhase> ph(nph);
-  memset(ph.data(), 0, sizeof(ChainPhase) * nph);
-  const int splits = splits_of(c, level);
-  const bool split = splits > 1 && !c->opt_exact;
-  size_t lds = 0;
-  int off[6] = {0, 0, 0, 0, 0, 0};
-  int prev_blocks = 0;
-  for (int l = 0; l < c->L; ++l) {
-    PhaseArgs pa[5] = {qkv_args(c, l), base_args(c), wo_args(c, l), w13_args(c, l), w2_args(c, l)};
-    const int modes[5] = {MODE_QKV, CHAIN_ATTN, MODE_WO, MODE_W13, MODE_W2};
-    int run = 0;
-    for (int r = 0; r < 5; ++r) {
-      ChainPhase& p = ph[l * 5 + r];
-      p.mode = modes[r];
-      p.pa = pa[r];
-      // per-layer buffers: x_in(l) = x_out(l-1) (the embedding row in layer 0)
-      const float* x_in = l > 0 ? act(l - 1, o_xo) : nullptr;
-      if (r == 0) { p.pa.in = x_in; p.pa.out = act(l, o_q); p.pa.aux = act(l, o_k); p.pa.aux2 = act(l, o_v); }
-      if (r == 2) { p.pa.in = act(l, o_xb); p.pa.res = x_in; p.pa.out = act(l, o_xm); }
-      if (r == 3) { p.pa.in = act(l, o_xm); p.pa.out = act(l, o_hb); }
-      if (r == 4) { p.pa.in = act(l, o_hb); p.pa.res = act(l, o_xm); p.pa.out = act(l, o_xo); }
-      if (r == 1) {
-        int G;
-        c->cur_splits = splits;
-        fill_attn_args(c, l, p.aa, &G);
-        p.split = split ? 1 : 0;
-        p.nblocks = c->H_loc * (split ? splits : 1);
-        const size_t al = attn_lds(c, p.aa, G, split);
-        if (al > lds) lds = al;
-      } else {
-        p.U = chain_U(p.pa.n);
-        p.nblocks = chain_blocks(c, p.mode, p.pa.rows);
-        const size_t pl = chain_phase_lds(p.mode, p.pa.n, p.U);
-        if (pl > lds) lds = pl;
-      }
-      chain_wire(c, p.pa, l * 5 + r, prev_blocks);
-      prev_blocks = p.nblocks;
-      if (r == 1) {
-        p.aa.fused = 2; p.aa.wait_shard = p.pa.wait_shard; p.aa.wait_blocks = p.pa.wait_blocks; p.aa.err = c->h_err_dev;
-        p.aa.q = act(l, o_q); p.aa.knew = act(l, o_k); p.aa.vnew = act(l, o_v); p.aa.xb = act(l, o_xb);
-        p.aa.att = act(l, o_att); p.aa.part = c->chain_part + (size_t)l * c->H_loc * 8 * rec;
-      }
-      if (l == 0) { off[r] = run; }
-      run += p.nblocks;
-    }
-    if (l == 0) off[5] = run;
-  }
-  ChainPhase& pc = ph[5 * c->L];
-  pc.mode = MODE_CLS;
-  pc.pa = cls_args(c, !greedy);
-  pc.pa.in = act(c->L - 1, o_xo);
-  pc.U = chain_U(pc.pa.n);
-  pc.nblocks = chain_blocks(c, MODE_CLS, pc.pa.rows);
-  chain_wire(c, pc.pa, 5 * c->L, prev_blocks);
-  { const size_t pl = chain_phase_lds(MODE_CLS, pc.pa.n, pc.U); if (pl > lds) lds = pl; }
-  if (greedy) {
-    ChainPhase& pg = ph[5 * c->L + 1];
-    pg.mode = CHAIN_ARGMAX;
-    pg.pa = base_args(c);
-    chain_wire(c, pg.pa, 5 * c->L + 1, pc.nblocks);
-    pg.nblocks = 1;
-  }
-  HIPCHK(hipMalloc(&cs.d_phases, sizeof(ChainPhase) * nph));
-  HIPCHK(hipMemcpy(cs.d_phases, ph.data(), sizeof(ChainPhase) * nph, hipMemcpyHostToDevice));
-  ChainLaunch& cl = cs.cl;
-  memset(&cl, 0, sizeof(cl));
-  cl.phases = cs.d_phases; cl.L = c->L;
-  for (int i = 0; i < 6; ++i) cl.off[i] = off[i];
-  cl.cls_first = c->L * off[5]; cl.cls_blocks = pc.nblocks; cl.has_argmax = greedy;
-  cl.logits = c->logits; cl.V = c->V; cl.tokpos = c->tokpos; cl.tokens_out = c->d_tokens;
-  cs.blocks = cl.cls_first + cl.cls_blocks + (greedy ? 1 : 0);
-#ifdef L2_STAMPS
-  { unsigned long long* tl = nullptr; HIPCHK(hipMalloc(&tl, (size_t)cs.blocks * 16)); HIPCHK(hipMemset(tl, 0, (size_t)cs.blocks * 16)); cl.tl = tl; g_chain_tl = tl; g_chain_blocks = cs.blocks; g_chain_off = cl; }
-#endif
-  cs.lds = lds;
-  cs.built = true;
-  return L2_OK;
-}
-
-static int enqueue_chain(l2_ctx* c, hipStream_t st, bool to_host, bool greedy) {
-  int level = 0;
-  for (int i = 0; i < 3; ++i) if (splits_of(c, i) == c->cur_splits) level = i;
-  (void)to_host;
-  int rc = build_chain(c, level, greedy ? 1 : 0);
-  if (rc) return rc;
-  const l2_ctx::ChainSet& cs = c->chain[level][greedy ? 1 : 0];
-  LCHK(hipMemsetAsync(c->chain_ctr, 0, c->chain_ctr_bytes, st));     // re-arm every counter and flag
-  hipLaunchKernelGGL(chain_kernel, dim3(cs.blocks), dim3(256), cs.lds, st, cs.cl);
-  LCHK(hipGetLastError());
-  return L2_OK;
-}
-
 // Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
 // The two collectives of the tensor-parallel step: RCCL, or the loopback test hook.
 static int tp_all_reduce(l2_ctx* c, hipStream_t st) {
@@ -1131,21 +916,12 @@ static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
 }
 
 static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
-  if (can_chain(c)) return enqueue_chain(c, st, to_host, false);
   for (int l = 0; l < c->L; ++l) {
     PhaseArgs a = qkv_args(c, l);
-    bool fused_wo = false;
-    if (can_fuse_attn(c)) {   // 1+2 in one launch: attention waits per head on the q/k/v rows of this position
-      LCHK(launch_qkv_attn(c, l, a, st));
-    } else {
-      LCHK(launch_phase<MODE_QKV>(c, a, st));
-      if (can_fuse_wo(c)) { LCHK(launch_attn_wo(c, l, st)); fused_wo = true; }
-      else LCHK(launch_attn(c, l, st));   // attention (llama2.ts:244-267)
-    }
-    if (!fused_wo) {
-      a = wo_args(c, l);
-      LCHK(launch_phase<MODE_WO>(c, a, st));
-    }
+    LCHK(launch_phase<MODE_QKV>(c, a, st));
+    LCHK(launch_attn(c, l, st));
+    a = wo_args(c, l);
+    LCHK(launch_phase<MODE_WO>(c, a, st));
     if (c->tp_path) {
       { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->partial, c->xb2, c->tokpos, c->d);
@@ -1183,7 +959,6 @@ static int ensure_ready(l2_ctx* c) {
 }
 
 static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step: forward, argmax, advance
-  if (can_chain(c)) return enqueue_chain(c, st, false, true);
   int rc = enqueue_forward(c, st);
   if (rc) return rc;
   hipLaunchKernelGGL(argmax_advance_kernel, dim3(1), dim3(1024), 0, st, c->logits, c->V, c->tokpos, c->d_tokens);
@@ -1224,7 +999,6 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   const int lvl = split_level(c, pos);
   c->cur_splits = splits_of(c, lvl);
-  if (can_chain(c)) { rc = build_chain(c, lvl, 0); if (rc) return rc; }   // allocations must precede any capture
   if (c->opt_graph) {
     if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc) return rc; }
     HIPCHK(hipGraphLaunch(c->g_step[lvl], c->stream));
@@ -1236,7 +1010,6 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
     HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
-  if (*c->h_err) { *c->h_err = 0; return fail(L2_E_HIP, "in-kernel hand-off wait timed out (attention never saw its head's q/k/v rows)"); }
   if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
   return L2_OK;
 }
@@ -1309,13 +1082,10 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     // attention, one workgroup per (head, query) (llama2.ts:244-267)
     {
       AttnArgs aa;
-      int G;
       c->cur_splits = 1;
-      fill_attn_args(c, l, aa, &G);
-      aa.q = c->pf_q; aa.xb = c->pf_xb; aa.att = nullptr;
-      const size_t lds = attn_lds(c, aa, G, false);
-      hipLaunchKernelGGL((pf_attn_kernel<true>), dim3(c->H, n), dim3(256), lds, st, aa, pos0);
-      LCHK(hipGetLastError());
+      fill_attn_args(c, l, aa);
+      aa.q = c->pf_q; aa.xb = c->pf_xb; aa.att = nullptr; aa.pos_plus1 = 1;
+      LCHK(launch_attn_tile(c, aa, n, pos0, st));
     }
     // wo + residual (llama2.ts:270-273)
     a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
@@ -1377,7 +1147,6 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   HIPCHK(hipSetDevice(c->device));
   c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  if (can_chain(c)) for (int s = 0; s < steps; ++s) { rc = build_chain(c, split_level(c, pos0 + s), 1); if (rc) return rc; }
   if (c->opt_graph) {   // capture what this run needs before the timed region
     for (int s = 0; s < steps; ++s) {
       const int lvl = split_level(c, pos0 + s);
@@ -1401,7 +1170,6 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
-  if (*c->h_err) { *c->h_err = 0; return fail(L2_E_HIP, "in-kernel hand-off wait timed out (attention never saw its head's q/k/v rows)"); }
   return L2_OK;
 }
 
@@ -1427,11 +1195,10 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   HIPCHK(hipMemcpyAsync(c->samp.params, params, sizeof(params), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->samp.rng, rng_state, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));                 // the host sources above are stack / caller memory
-  const bool graph = c->opt_graph && !c->opt_chain && !c->loop;
+  const bool graph = c->opt_graph && !c->loop;
   for (int s = 0; s < steps; ++s) {
     const int lvl = split_level(c, pos0 + s);
     c->cur_splits = splits_of(c, lvl);
-    if (can_chain(c)) { rc = build_chain(c, lvl, 0); if (rc) return rc; }   // experimental chain launch: allocations before any enqueue
     if (graph) {
       hipGraphExec_t& g = c->g_sample[lvl][c->samp_mode];
       if (!g) { rc = capture(c, enqueue_sample, &g); if (rc) return rc; }
@@ -1445,7 +1212,6 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   HIPCHK(hipMemcpyAsync(tokens_out, c->d_tokens, (size_t)steps * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
-  if (*c->h_err) { *c->h_err = 0; return fail(L2_E_HIP, "in-kernel hand-off wait timed out"); }
   return L2_OK;
 }
 
@@ -1484,11 +1250,11 @@ extern "C" int l2_bench_dominant_in_situ(l2_ctx* c, int first_token, int pos0, i
   HIPCHK(hipSetDevice(c->device));
   const size_t need = (size_t)2 * c->L * steps;
   while (c->probe.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->probe.push_back(e); }
-  const int saved_graph = c->opt_graph, saved_chain = c->opt_chain;
-  c->opt_graph = 0; c->opt_chain = 0;
+  const int saved_graph = c->opt_graph;
+  c->opt_graph = 0;
   c->probe_used = 0; c->probe_on = true;
   int rc = run_greedy(c, first_token, pos0, steps, false, nullptr);
-  c->probe_on = false; c->opt_graph = saved_graph; c->opt_chain = saved_chain;
+  c->probe_on = false; c->opt_graph = saved_graph;
   if (rc) return rc;
   double total = 0.0;
   size_t n = 0;
@@ -1541,11 +1307,9 @@ extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
       if (c->opt_exact != !!value) {
         c->opt_exact = !!value;
         destroy_graphs(c);
-        for (auto& lv : c->chain) for (auto& cs : lv) { if (cs.d_phases) hipFree(cs.d_phases); cs.d_phases = nullptr; cs.built = false; }
       }
       return L2_OK;
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
-    case L2_OPT_MEGAKERNEL: if (c->opt_chain != !!value) { c->opt_chain = !!value; destroy_graphs(c); } return L2_OK;
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }
@@ -1555,7 +1319,6 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
   switch (key) {
     case L2_OPT_EXACT_ATTENTION: *value = c->opt_exact; return L2_OK;
     case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
-    case L2_OPT_MEGAKERNEL: *value = c->opt_chain; return L2_OK;
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }
@@ -1582,9 +1345,13 @@ extern "C" int l2_bench_gemv(l2_ctx* c, int kind, int layer, int iters, float* a
   int rc = ensure_ready(c);
   if (rc) return rc;
   HIPCHK(hipSetDevice(c->device));
+  // the phases read {token, pos} from device memory: whatever a previous decode left there may be pos == seq_len
+  memset(c->h_tokpos, 0, 4 * sizeof(int));
+  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   PhaseArgs a;
   memset(&a, 0, sizeof(a));
   a.tokpos = c->tokpos; a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG]; a.head_size = c->hs; a.dim = c->d;
+  a.inv_n = 1.0 / (double)c->d;
   const size_t loff = (size_t)layer * c->S * c->d_loc;
   int mode;
   switch (kind) {

@@ -42,8 +42,12 @@ PLAN = {
     "tinylong": (1280, [0, 255, 256, 257, 1023, 1024, 1279], False, None),
     "stories15M": (256, [0, 1, 2, 127, 255], False, None),
     "stories15M_prompt": (24, [3, 4, 23], False, "Once upon a time"),
-    "stories110M": (40, [0, 39], False, None),
-    "llama2_7b_L2": (6, [0, 5], False, None),
+    # the whole context window: every attention split threshold of the HIP path at head_size 64 ...
+    "stories110M": (1024, [0, 39, 127, 128, 129, 255, 256, 257, 299, 511, 512, 513, 1023], False, None),
+    # ... and at head_size 128 (7B width, 2 layers; ~1 tok/s in the reference: about an hour)
+    "llama2_7b_L2": (2048, [0, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 559, 1023, 1024, 1919, 1920, 1984, 2047], False, None),
+    # the real thing: all 32 layers, 3 steps (27 GB synthetic checkpoint in /tmp, ~6 s per token in the reference)
+    "llama2_7b": (3, [0, 2], False, None),
     # whole-CLI goldens (stdout text): the reference runs with the repo's SYNTHETIC tokenizer.bin in its cwd
     "cli_greedy": (48, [], False, None, ["-t", "0", "-s", "1"], True),
     "cli_prompt": (40, [], False, "wetds oyn fra uynia", ["-t", "0", "-s", "1"], True),

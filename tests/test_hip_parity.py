@@ -223,27 +223,6 @@ def test_long_context_crosses_every_split_level_token_exact(built):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,steps", [("tiny", 64), ("stories15M", 48)])
-def test_chain_launch_matches_reference(built, name, steps):
-    """Experimental one-kernel-per-token chain launch (L2_OPT_MEGAKERNEL): phases ordered by block id, in-launch
-    hand-offs through write-through stores and completion counters.  Must give the reference's tokens and logits;
-    a bounded wait that gives up surfaces as an L2Error, never as a hang."""
-    meta, g = load_gold(name)
-    ctx = runtime.Context(meta["header"])
-    ctx.synth_fill(meta["seed"])
-    ctx.set_option(runtime.OPT_MEGAKERNEL, 1)
-    assert ctx.get_option(runtime.OPT_MEGAKERNEL) == 1
-    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
-    for pos, tok in enumerate(meta["tokens_fed"][:steps]):
-        got = np.array(ctx.forward(tok, pos), copy=True)
-        assert runtime.argmax(got) == meta["argmax"][pos], (name, pos)
-        if pos in keep:
-            assert np.abs(got - g["logits"][keep[pos]]).max() <= TOL
-    toks = ctx.decode_greedy(1, 0, steps)
-    assert toks.tolist() == meta["argmax"][:steps]
-    ctx.close()
-
-
 def test_native_checkpoint_loader_equals_per_array_upload(built, tmp_path):
     """l2_load_checkpoint vs readWeights + l2_upload: same bytes in HBM, same logits."""
     import time
@@ -270,7 +249,7 @@ def test_native_checkpoint_loader_equals_per_array_upload(built, tmp_path):
 def test_full_size_7b_properties(built):
     """BASELINE.json's full Llama-2-7B shape (27 GB of synthetic weights generated on the device): properties that
     do not need a CPU pass over 27 GB -- the captured-graph and eager paths agree bit for bit, the bit-faithful and
-    default attention agree within the gate, the split-attention and chain launches give the same tokens, the
+    default attention agree within the gate, the split-attention launch gives the same tokens, the
     greedy stream is reproducible, and logits are finite with softmax rows summing to one."""
     hdr = configs.header("llama2_7b")
     ctx = runtime.Context(hdr)
@@ -290,9 +269,6 @@ def test_full_size_7b_properties(built):
     t1 = ctx.decode_greedy(1, 0, 12)
     t2 = ctx.decode_greedy(1, 0, 12)
     assert t1.tolist() == t2.tolist()
-    ctx.set_option(runtime.OPT_MEGAKERNEL, 1)
-    t3 = ctx.decode_greedy(1, 0, 12)
-    assert t3.tolist() == t1.tolist()
     ctx.close()
     os.environ["L2_ATTN_SPLITS"] = "8"
     try:
@@ -470,24 +446,12 @@ def test_sampler_serial_and_parallel_forms_agree(monkeypatch):
     assert runs["0"] == runs["1"]
 
 
-def test_device_sampler_with_the_experimental_chain_launch():
-    """l2_decode_sample must give the same ids whichever launch form produces the logits (L2_OPT_MEGAKERNEL)."""
-    hdr = configs.header("stories15M")
-    a = runtime.Context(hdr); a.synth_fill(1)
-    want, _ = a.decode_sample(1, 0, 12, 0.9, 0.9, 5)
-    a.close()
-    b = runtime.Context(hdr); b.synth_fill(1)
-    b.set_option(3, 1)
-    got, _ = b.decode_sample(1, 0, 12, 0.9, 0.9, 5)
-    b.close()
-    assert got.tolist() == want.tolist()
-
-
-@pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_FUSE_WO": "1"}), ("llama2_7b_L2", {"L2_ATTN_PRE": "2"}), ("llama2_7b_L2", {"L2_ATTN_PRE": "3"}), ("stories110M", {"L2_ATTN_PRE": "3"}),
-                                      ("stories110M", {"L2_FUSE_WO": "1"}), ("stories110M", {"L2_ATTN_PRE": "0"})])
-def test_attention_launch_variants_match_reference(monkeypatch, name, env):
-    """Opt-in attention launch forms (attention with every load up front; attention + register-resident wo in one
-    launch) and the plain form for 64-wide heads: same goldens, same tolerance, tokens exact."""
+@pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_ATTN_NW": "4"}), ("stories110M", {"L2_ATTN_NW": "8"}), ("stories15M", {"L2_ATTN_NW": "8"}),
+                                      ("stories110M", {"L2_SMALL_MAX": "0"}), ("stories15M", {"L2_SMALL_MAX": "0"})])
+def test_launch_geometry_variants_match_reference(monkeypatch, name, env):
+    """The other geometry of the attention tile kernel (4 waves x 16 tiles / 8 waves x 8 tiles per round) and the
+    streaming form of the GEMV phases on shapes that default to the latency form: same goldens, same tolerance,
+    tokens exact."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     meta, g = load_gold(name)

@@ -1,5 +1,11 @@
-"""Latency anatomy of the phase kernels from the diagnostic (L2_STAMPS) build: shader-clock deltas between
-stages for wave 0 of the first / middle / last workgroup of every launch of one token."""
+"""Latency anatomy of the GEMV phase kernels from the diagnostic (L2_STAMPS) build: shader-clock stamps of wave 0
+of the first / middle / last workgroup of every launch of one token, printed as cycles since the wave's first stamp.
+
+  python tools/stamps.py [config] [position]
+
+Stamp ids (kernels.hip.h): streaming form 0 start, 1 x + first weights requested, 2 x in LDS, 3 sum(x^2) reduced,
+4 normalised + barrier, 5 first batch consumed, 6 rows reduced, 7 epilogue; latency form 0 start, 1 everything
+requested, 2 sum(x^2) reduced (wave 0), 3 barrier passed, 5 dot products done, 6 rows reduced, 7 epilogue."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,26 +20,22 @@ ctx = runtime.Context(hdr); ctx.synth_fill(1)
 tok = 1
 for pos in range(F):
     tok = int(np.argmax(ctx.forward(tok, pos)))
-per_tok = 4 * cfg.n_layers + 1            # phase-kernel launches per token (attention has no stamps)
-buf = np.zeros(64 * 36, dtype=np.uint64)
+per_tok = 4 * cfg.n_layers + 1            # phase-kernel launches per token (attention stamps: stamps_attn.py)
+buf = np.zeros(66 * 108, dtype=np.uint64)
 L = runtime.lib()
 L.l2_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert L.l2_debug_stamps(ctx._h, buf.ctypes.data, buf.size) == 0
-buf = buf.reshape(64, 3, 12).astype(np.int64)
+buf = buf[:64 * 108].reshape(64, 3, 3, 12).astype(np.int64)
 names = ["qkv", "wo", "w13", "w2"]
-labels = ["x+w issued", "x landed", "x in LDS", "ss reduced", "norm+barrier", "weights consumed", "rows reduced", "epilogue"]
 first = per_tok * (F - 1)
-print("config", name, "pos", F - 1, "(cycles; ~2.1-2.4 GHz => 1000 cycles ~ 0.45 us)")
-print("%-10s %-5s " % ("kernel", "wg") + " ".join("%16s" % l for l in labels) + "   total")
+print("config", name, "pos", F - 1, "(cycles since the wave's stamp 0; 1000 cycles ~ 0.42-0.48 us; w0 = wave 0 (the x wave of the latency form), w1 = wave 1)")
+print("%-10s %-8s " % ("kernel", "wg/wave") + " ".join("%7s" % ("s%d" % k) for k in range(1, 12)))
 for j in list(range(0, 8)) + [per_tok - 1]:
     slot = (first + j) % 64
     nm = "cls" if j == per_tok - 1 else "%s.l%d" % (names[j % 4], j // 4)
     for w, wn in enumerate(("first", "mid", "last")):
-        t = buf[slot, w]
-        if t[0] == 0:
-            continue
-        d = [int(t[k + 1] - t[k]) if t[k + 1] and t[k] else 0 for k in range(7)]
-        has_norm = t[3] != 0
-        if not has_norm:   # copy modes have no stamp 3
-            d[2] = 0; d[3] = int(t[4] - t[2])
-        print("%-10s %-5s " % (nm, wn) + " ".join("%16d" % v for v in [0] + d)[17:] + "   %6d" % int(t[7] - t[0]))
+        for wv in range(3):
+            t = buf[slot, w, wv]
+            if t[0] == 0:
+                continue
+            print("%-10s %-8s " % (nm, "%s/%s" % (wn, ("w0", "w1", "wL")[wv])) + " ".join("%7s" % (str(int(t[k] - t[0])) if t[k] else "-") for k in range(1, 12)))

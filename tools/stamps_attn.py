@@ -1,4 +1,6 @@
-"""Latency anatomy of attn_kernel (diagnostic L2_STAMPS build): cycles between stages, wave 0 of head 0 / mid / last."""
+"""Latency anatomy of the attention tile kernel (diagnostic L2_STAMPS build): cycles since the wave's first stamp,
+wave 0 of the first / middle / last workgroup of the last layer's launch.
+Stamps (attention.hip.h): 1 K / q / V requested, 2 scores in LDS, 3 probabilities in LDS, 4 value partials in LDS, 5 xb stored."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,20 +13,12 @@ ctx = runtime.Context(configs.header(name)); ctx.synth_fill(1)
 tok = 1
 for pos in range(F):
     tok = int(np.argmax(ctx.forward(tok, pos)))
-buf = np.zeros(66 * 36, dtype=np.uint64)
+buf = np.zeros(66 * 108, dtype=np.uint64)
 L = runtime.lib(); L.l2_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert L.l2_debug_stamps(ctx._h, buf.ctypes.data, buf.size) == 0
-t = buf[64 * 36:65 * 36].reshape(3, 12).astype(np.int64)
-labels = ["stage q/k/v", "scores", "softmax", "values", "merge+store"]
-print(name, "pos", F - 1, "last layer (cycles)")
-for w, wn in enumerate(("head0", "mid", "last")):
-    print("%-6s" % wn, " ".join("%s %6d" % (l, t[w][k + 1] - t[w][k]) for k, l in enumerate(labels)), " total", t[w][5] - t[w][0])
-w = buf[65 * 36:66 * 36].reshape(3, 12).astype(np.int64)
-if w[0][0]:
-    a0 = t[0][0]
-    print("fused attention + wo launch, cycles relative to head 0's start:")
-    for k, wn in enumerate(("head0", "mid", "last")):
-        print("  attn %-5s start %6d  xb stored %6d" % (wn, t[k][0] - a0, t[k][5] - a0))
-    wl = ["start", "weights requested", "weights landed", "flag seen", "xb in LDS", "rows done"]
-    for k, wn in enumerate(("first", "mid", "last")):
-        print("  wo   %-5s " % wn + "  ".join("%s %6d" % (l, w[k][j] - a0) for j, l in enumerate(wl)))
+t = buf[64 * 108:65 * 108].reshape(3, 3, 12).astype(np.int64)[:, 0]
+labels = ["requested", "scores", "softmax", "values", "stored"]
+print(name, "pos", F - 1, "last layer (cycles since stamp 0)")
+for w, wn in enumerate(("first", "mid", "last")):
+    if t[w][0]:
+        print("%-6s" % wn, " ".join("%s %6s" % (l, str(int(t[w][k + 1] - t[w][0])) if t[w][k + 1] else "-") for k, l in enumerate(labels)))
