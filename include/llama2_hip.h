@@ -63,7 +63,9 @@ enum {
 enum {
   L2_OPT_EXACT_ATTENTION = 1, /* 1: value-accumulate rounds to fp32 at every timestep in t order, exactly as
                                  llama2.ts:260-265 does (bit-faithful, slower); 0 (default): fp64 partial sums */
-  L2_OPT_USE_GRAPH = 2        /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
+  L2_OPT_USE_GRAPH = 2,       /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
+  L2_OPT_KEEP_ATT = 3         /* 1: RunState.att (the softmax rows, llama2.ts:158) is written out for l2_read_state(L2_S_ATT);
+                                 0 (default): it stays on chip -- nothing outside transformer() reads it (llama2.ts:244-265) */
 };
 
 typedef struct l2_ctx l2_ctx;

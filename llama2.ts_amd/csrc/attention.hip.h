@@ -245,17 +245,44 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   if (*ticket != (unsigned)(NS - 1)) return;
 
   const double* hp = a.part + (size_t)h * NS * rec;     // sc1 loads: they bypass this CU's L1
-  double M = -INFINITY;
-  for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, ld_sc1(hp + (size_t)s2 * rec + hs + 1));
-  double Lsum = 0.0;
-  for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + hs);
-  for (int i = tid; i < hs; i += NTH) {
-    double num = 0.0;
-    for (int s2 = 0; s2 < NS; ++s2) num += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + i);
-    a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
+  if (NS <= 8) {
+    // ONE round of loads: every thread requests {m, l} of all splits and its element of every partial at once
+    // (three dependent rounds of L1-bypassing loads were 3 us of the merge)
+    for (int i = tid; i < hs; i += NTH) {
+      double mm[8], ll[8], aa[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double* rp = hp + (size_t)min(k, NS - 1) * rec;
+        mm[k] = ld_sc1(rp + hs + 1); ll[k] = ld_sc1(rp + hs); aa[k] = ld_sc1(rp + i);
+      }
+      double M = mm[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) M = fmax(M, mm[k]);
+      double Lsum = 0.0, num = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double w = (k < NS) ? exp_fast(mm[k] - M) : 0.0;
+        Lsum += w * ll[k]; num += w * aa[k];
+      }
+      a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
+    }
+  } else {
+    double M = -INFINITY;
+    for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, ld_sc1(hp + (size_t)s2 * rec + hs + 1));
+    double Lsum = 0.0;
+    for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + hs);
+    for (int i = tid; i < hs; i += NTH) {
+      double num = 0.0;
+      for (int s2 = 0; s2 < NS; ++s2) num += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + i);
+      a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
+    }
   }
-  if (a.att) {
-    for (int t = tid; t < T; t += NTH) {                 // probabilities for parity reads of RunState.att
+  if (a.att) {                                          // probabilities for parity reads of RunState.att (L2_OPT_KEEP_ATT)
+    double M = -INFINITY;
+    for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, ld_sc1(hp + (size_t)s2 * rec + hs + 1));
+    double Lsum = 0.0;
+    for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + hs);
+    for (int t = tid; t < T; t += NTH) {
       const double ws = exp(ld_sc1(hp + (size_t)(t / chunk) * rec + hs + 1) - M);
       a.att[(size_t)h * S + t] = (float)((double)ld_sc1(a.att + (size_t)h * S + t) * ws / Lsum);
     }

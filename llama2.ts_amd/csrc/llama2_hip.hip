@@ -33,7 +33,7 @@
 
 using namespace l2k;
 
-enum { NLEV = 4 };   // attention split levels: 1, 2, 4, 8 workgroups per head
+enum { NLEV = 2 };   // attention split levels: 1 or 8 workgroups per head
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -165,7 +165,7 @@ struct l2_ctx {
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int cur_splits = 1;               // split count of the step being enqueued / captured
-  int split_bytes = 128 << 10;      // L2_ATTN_SPLIT_BYTES: K + V bytes of a head per attention workgroup before it is split further
+  int split_rows = 144;             // L2_ATTN_SPLIT_ROWS: cached rows of a head beyond which attention runs 8 workgroups per head
   int attn_nw = 0;                  // L2_ATTN_NW: waves per attention workgroup (0: by head size)
   int small_max = 0;                // L2_SMALL_MAX: largest matrix (floats) that takes the latency-form GEMV
   int n_cus = 256;
@@ -185,7 +185,7 @@ struct l2_ctx {
   unsigned long long* dbg = nullptr;  // L2_STAMPS builds
 
   hipGraphExec_t g_step[NLEV] = {}, g_greedy[NLEV] = {};   // one captured graph per attention split level
-  int opt_exact = 0, opt_graph = 1;
+  int opt_exact = 0, opt_graph = 1, opt_keep_att = 0;
   int next_pos = 0;
   bool ran_forward = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -235,16 +235,14 @@ static void destroy_graphs(l2_ctx* c) {
 }
 
 // Attention split level by context length.  A head's cache rows are read by ONE workgroup per split, and one CU pulls
-// ~50-100 GB/s however many loads it keeps in flight, so a head is split over more workgroups (flash-decode merge by
-// the last arriver, attention.hip.h) once its K + V rows exceed `split_bytes` per workgroup: 2, 4, then 8 splits.
-// The merge costs ~1.5 us, which sets the threshold (tools/ctx_curve.py).
-static const int kSplitLevels[NLEV] = {1, 2, 4, 8};
+// ~50-100 GB/s however many loads it keeps in flight, so beyond `split_rows` cached rows a head is split over 8
+// workgroups (flash-decode merge by the last arriver, attention.hip.h).  The merge costs ~2.5 us per layer whatever
+// the split count, so intermediate counts never win (tools/ctx_curve.py, 7B and 110M: 2 / 4 splits are slower than
+// 8 at every position where they beat 1; the crossover is at 140-160 rows for 64- and 128-wide heads alike).
+static const int kSplitLevels[NLEV] = {1, 8};
 static int split_level(const l2_ctx* c, int pos) {
   if (c->attn_splits_forced > 0 || c->opt_exact) return 0;
-  const long long bytes = (long long)(pos + 1) * c->hs * 8;
-  int lvl = 0;
-  while (lvl < NLEV - 1 && bytes > ((long long)c->split_bytes << lvl)) ++lvl;
-  return lvl;
+  return pos + 1 > c->split_rows ? 1 : 0;
 }
 static int splits_of(const l2_ctx* c, int level) { return c->attn_splits_forced > 0 ? c->attn_splits_forced : kSplitLevels[level]; }
 
@@ -352,7 +350,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   // split attention scratch (sized for the largest split count)
   c->attn_splits_forced = env_int("L2_ATTN_SPLITS", 0);
   c->attn_nw = env_int("L2_ATTN_NW", 0);
-  c->split_bytes = env_int("L2_ATTN_SPLIT_BYTES", 128 << 10);
+  c->split_rows = env_int("L2_ATTN_SPLIT_ROWS", 144);
   c->small_max = env_int("L2_SMALL_MAX", 8 << 20);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->pf_lds = env_int("L2_PF_LDS", 1);
@@ -767,7 +765,7 @@ static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4
 static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
   const size_t loff = (size_t)l * c->S * c->d_loc;
   memset(&a, 0, sizeof(a));
-  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->att; a.xb = c->xb;
+  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->opt_keep_att ? c->att : nullptr; a.xb = c->xb;
   a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter;
   a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
   a.exact = c->opt_exact;
@@ -1284,7 +1282,9 @@ extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t
     case L2_S_Q: src = c->q; n = c->d_loc; break;
     case L2_S_K: src = c->k; n = c->d_loc; break;
     case L2_S_V: src = c->v; n = c->d_loc; break;
-    case L2_S_ATT: src = c->att; n = (size_t)c->H_loc * c->S; break;
+    case L2_S_ATT:
+      if (!c->opt_keep_att) return fail(L2_E_STATE, "RunState.att is not kept: set L2_OPT_KEEP_ATT before the forward");
+      src = c->att; n = (size_t)c->H_loc * c->S; break;
     case L2_S_LOGITS: src = c->logits; n = c->V; break;
     case L2_S_KEY_CACHE: case L2_S_VALUE_CACHE: {
       const float* base = which == L2_S_KEY_CACHE ? c->kc : c->vc;
@@ -1310,6 +1310,7 @@ extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
       }
       return L2_OK;
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
+    case L2_OPT_KEEP_ATT: if (c->opt_keep_att != !!value) { c->opt_keep_att = !!value; destroy_graphs(c); } return L2_OK;
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }
@@ -1319,6 +1320,7 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
   switch (key) {
     case L2_OPT_EXACT_ATTENTION: *value = c->opt_exact; return L2_OK;
     case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
+    case L2_OPT_KEEP_ATT: *value = c->opt_keep_att; return L2_OK;
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }

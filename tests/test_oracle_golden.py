@@ -26,14 +26,22 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("name", ["tiny", "ragged", "tinylong", "stories15M", "stories15M_prompt", "stories110M", "llama2_7b_L2"])
+# Steps of each fixture the default CPU suite replays (the fixtures of the two big shapes cover their whole context
+# window -- 1024 and 2048 reference steps -- which is an hour of oracle time; L2_ORACLE_FULL=1 replays everything,
+# and adds the 3-step fixture of the full 32-layer Llama-2-7B, 27 GB of host memory).  Last full replay: see DESIGN.md.
+FULL = os.environ.get("L2_ORACLE_FULL") == "1"
+STEP_CAP = {} if FULL else {"stories110M": 48, "llama2_7b_L2": 6}
+NAMES = ["tiny", "ragged", "tinylong", "stories15M", "stories15M_prompt", "stories110M", "llama2_7b_L2"] + (["llama2_7b"] if FULL else [])
+
+
+@pytest.mark.parametrize("name", NAMES)
 def test_oracle_matches_reference_bit_for_bit(name):
     meta, g = load(name)
     o = O.Oracle(meta["header"], meta["seed"])
     keep = {p: i for i, p in enumerate(meta["logit_positions"])}
     n = meta["steps_run"]
     assert n == len(meta["tokens_fed"]) == len(meta["logits_sha256"])
-    for pos, tok in enumerate(meta["tokens_fed"]):
+    for pos, tok in enumerate(meta["tokens_fed"][:STEP_CAP.get(name, n)]):
         lg = o.forward(tok, pos)
         assert hashlib.sha256(lg.tobytes()).hexdigest() == meta["logits_sha256"][pos], (name, pos)
         if pos in keep:
@@ -44,7 +52,7 @@ def test_oracle_matches_reference_bit_for_bit(name):
         if "x" in g.files:
             for nm in ("x", "xb", "xb2", "hb", "hb2", "q", "k", "v", "att"):
                 assert np.array_equal(bits(o.state(nm)), bits(g[nm][pos])), (name, pos, nm)
-    if "key_cache" in g.files:
+    if "key_cache" in g.files and name not in STEP_CAP:
         assert np.array_equal(bits(o.state("key_cache")), bits(g["key_cache"]))
         assert np.array_equal(bits(o.state("value_cache")), bits(g["value_cache"]))
     o.close()
