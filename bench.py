@@ -9,14 +9,28 @@ llama2.ts:468-478 consumes them) are reported next to it as `dropin_tok_s`.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config llama2_7b|stories110M|stories15M]
 
+Everything in the JSON line is measured by this run:
+  * `roofline`: the dominant kernel (rmsnorm + w1/w3 GEMV + SwiGLU) timed in situ with HIP events on the
+    library's stream; `traffic` = HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE,
+    gfx950 corrections of the MI355X guide) that this script runs over itself as child processes (--pmc-child)
+    BEFORE it touches the GPU; null when rocprofv3 is unavailable;
+  * `cpu_baseline`: the C restatement of the reference (oracle/, one thread like the single-threaded reference)
+    timed on this box's host cores on a bounded sample of the same workload;
+  * `stories110M`: BASELINE.json's other named shape, same fields.
+
 N > 1 (launched by torch.distributed.run, one rank per GPU): Llama-2-7B is tensor-parallel (heads / FFN
-rows sharded, RCCL all-reduce of d fp64 partials twice per layer; SURVEY.md 8(e)) => strong scaling;
+rows sharded, fp64 all-reduce of d partials twice per layer; SURVEY.md 8(e)) => strong scaling;
 shapes that do not shard run as independent replicas => weak scaling.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,10 +41,11 @@ import numpy as np  # noqa: E402
 from llama2_ts_amd import configs, runtime  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DOMINANT = "rmsnorm + w1/w3 GEMV + SwiGLU (llama2.ts:276-289)"
 
 
-def avg_bytes_per_token(hdr, steps):
-    return sum(configs.algorithmic_bytes_per_token(hdr, p) for p in range(steps)) / float(steps)
+def avg_bytes_per_token(hdr, p0, p1):
+    return sum(configs.algorithmic_bytes_per_token(hdr, p) for p in range(p0, p1)) / float(p1 - p0)
 
 
 def dominant_kernel_bytes(cfg):
@@ -40,15 +55,84 @@ def dominant_kernel_bytes(cfg):
     return 4 * (2 * h * d + 2 * d + h)
 
 
+# ---- HBM traffic of the dominant kernel: rocprofv3 --pmc over a child of this script ------------------------------
+def pmc_child(name, seed):
+    """Target of the counter passes: the model of this config, one forward, a few launches of the dominant kernel."""
+    ctx = runtime.Context(configs.header(name))
+    ctx.synth_fill(seed)
+    ctx.forward(1, 0)
+    ctx.bench_gemv(runtime.T_W1, ctx.cfg.n_layers // 2, 6)
+    ctx.close()
+
+
+def pmc_traffic(name, seed):
+    """FETCH_SIZE and WRITE_SIZE in SEPARATE passes (kernel trace only), corrected as the MI355X guide prescribes:
+    both are in KiB and FETCH_SIZE reports exactly half of a 16-byte-per-lane coalesced stream on gfx950."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    out = {}
+    work = tempfile.mkdtemp(prefix="l2_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", name, "--seed", str(seed)]
+            env = dict(os.environ, TMPDIR="/tmp", L2_USE_GRAPH="0")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (ctr, r.returncode)
+            vals = []
+            for row in csv.DictReader(open(files[0])):
+                kn = row["Kernel_Name"]
+                if row["Counter_Name"] == ctr and ("phase_kernel<2," in kn or "phase_small_kernel<2," in kn):
+                    vals.append(float(row["Counter_Value"]))
+            if len(vals) < 3:
+                return None, "no launches of the dominant kernel in the %s pass" % ctr
+            vals = vals[2:]   # the first launches follow a forward: drop them like warm-up
+            out[ctr] = sum(vals) / len(vals)
+    except Exception as e:   # noqa: BLE001 -- a missing profiler must not fail the benchmark
+        return None, "pmc pass: %r" % (e,)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    total = out["FETCH_SIZE"] * 1024.0 * 2.0 + out["WRITE_SIZE"] * 1024.0
+    return int(total), ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this run (FETCH_SIZE KiB x 1024 x 2 + "
+                        "WRITE_SIZE KiB x 1024; per launch, mean of %d)" % len(vals))
+
+
+# ---- CPU baseline ------------------------------------------------------------------------------------------------
+def mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 0.0
+
+
 def cpu_baseline(name, hdr, seed):
-    """The CPU oracle (C restatement of llama2.ts, one thread like the single-threaded reference) timed on
-    this box's host cores on a bounded sample of the same workload."""
+    """The CPU oracle (C restatement of llama2.ts, ONE thread like the single-threaded reference) timed on this box's
+    host cores on a bounded sample of the same workload.  (Its synthetic-weight generator may use every core; the
+    timed forward passes do not.)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     d, h, L, H, kv, V, S = hdr
-    if L * d * h > 4 * 768 * 2048 * 12:
-        # too big to materialise on the host in seconds: time 1-layer and 3-layer models of the same width
-        # and extrapolate linearly in the layer count (time per token is linear in bytes streamed)
+    weights_gb = configs.checkpoint_bytes(hdr) / 2.0 ** 30
+    extrapolated = False
+    if weights_gb > 2.0 and mem_available_gb() > weights_gb + 8.0 and not os.environ.get("L2_BENCH_CPU_EXTRAPOLATE"):
+        o = O.Oracle(hdr, seed)          # the full model in host memory
+        tok = O.argmax(o.forward(1, 0))
+        n = 2
+        t0 = time.perf_counter()
+        for pos in range(1, 1 + n):
+            tok = O.argmax(o.forward(tok, pos))
+        sec = (time.perf_counter() - t0) / n
+        o.close()
+        sample = "oracle, %d greedy tokens (after 1 untimed) on the full %d-layer %s shape, %.0f GB of weights in host memory" % (n, L, name, weights_gb)
+    elif weights_gb > 2.0:
+        # not enough host memory for the whole model: 1- and 3-layer models of the same width, linear in the layer count
         t = {}
         for layers in (1, 3):
             o = O.Oracle((d, h, layers, H, kv, V, S), seed)
@@ -59,30 +143,70 @@ def cpu_baseline(name, hdr, seed):
                 tok = O.argmax(o.forward(tok, pos))
             t[layers] = (time.perf_counter() - t0) / 6.0
             o.close()
-        per_layer = (t[3] - t[1]) / 2.0
-        sec = t[1] + (L - 1) * per_layer
-        sample = "oracle on 1- and 3-layer models of this width, 6 tokens each, extrapolated to %d layers" % L
+        sec = t[1] + (L - 1) * (t[3] - t[1]) / 2.0
+        extrapolated = True
+        sample = "oracle on 1- and 3-layer models of this width, 6 tokens each, extrapolated to %d layers (host memory too small for the full model)" % L
     else:
         o = O.Oracle(hdr, seed)
-        steps = 8
-        sec0, _ = o.time_forward(steps)
-        steps = int(max(8, min(S, 12.0 / (sec0 / steps))))
+        sec0, _ = o.time_forward(8)
+        steps = int(max(8, min(S, 12.0 / (sec0 / 8))))
         o2 = O.Oracle(hdr, seed)
         sec_total, _ = o2.time_forward(steps)
         sec = sec_total / steps
         sample = "oracle, %d greedy tokens from BOS on the full %s shape" % (steps, name)
         o.close(); o2.close()
-    return {"value": round(1.0 / sec, 4), "unit": "tokens/s", "cores": 1, "kind": "port", "sample": sample}
+    return {"value": round(1.0 / sec, 4), "unit": "tokens/s", "cores": 1, "kind": "port", "sample": sample, "extrapolated": extrapolated}
 
 
-def run_single(args, hdr, device, tp=None):
-    cfg = runtime.Config(hdr)
-    if tp:
-        ctx = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=tp["id"])
-    else:
-        ctx = runtime.Context(hdr, device=device)
-    ctx.synth_fill(args.seed)
-    return cfg, ctx
+# ---- one config on one GPU: decode loop + roofline + CPU baseline ------------------------------------------------
+def roofline_block(ctx, cfg, K, traffic, traffic_how):
+    iters = 200 if cfg.dim * cfg.hidden_dim < (1 << 24) else 50
+    kms_isolated = ctx.bench_gemv(runtime.T_W1, cfg.n_layers // 2, iters)
+    kus, nlaunch = ctx.bench_dominant_in_situ(1, 0, min(K, 128))    # HIP event pair around every launch, eager launches of the same kernels
+    kb = dominant_kernel_bytes(cfg)
+    ach = kb / (kus * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_how": traffic_how,
+            "kernel": DOMINANT, "bytes_per_launch": kb, "avg_launch_us": round(kus, 3), "launches_timed": nlaunch,
+            "how": "HIP event pair around every launch inside a decode run on the library's stream",
+            "isolated_back_to_back_us": round(kms_isolated * 1e3, 3)}
+
+
+def per_kernel_block(ctx, cfg):
+    iters = 200 if cfg.dim * cfg.hidden_dim < (1 << 24) else 50
+    out = {}
+    d, h, V = cfg.dim, cfg.hidden_dim, cfg.vocab_size
+    for nm, kind in (("qkv", runtime.T_WQ), ("wo", runtime.T_WO), ("w13", runtime.T_W1), ("w2", runtime.T_W2), ("wcls", runtime.T_WCLS)):
+        ms = ctx.bench_gemv(kind, 0, iters)
+        nb = {"qkv": 3 * d * d, "wo": d * d, "w13": 2 * d * h, "w2": d * h, "wcls": V * d}[nm] * 4
+        out[nm] = {"us": round(ms * 1e3, 3), "GBs": round(nb / (ms * 1e-3) / 1e9, 1)}
+    return out
+
+
+def secondary_config(name, seed, device, with_cpu, traffic):
+    """BASELINE.json's metric names stories110M next to 7B: the same measurement as a block of the same JSON line."""
+    hdr = configs.header(name)
+    ctx = runtime.Context(hdr, device=device)
+    ctx.synth_fill(seed)
+    cfg = ctx.cfg
+    K = min(256, hdr[6])
+    ctx.bench_decode(1, 0, 32)
+    t0 = time.perf_counter()
+    ctx.bench_decode(1, 0, K)
+    wall = time.perf_counter() - t0
+    bpt = avg_bytes_per_token(hdr, 0, K)
+    out = {"value": round(K / wall, 2), "unit": "tokens/s", "steps": K, "ms_per_step": round(1e3 * wall / K, 5),
+           "algorithmic_bytes_per_token": int(bpt),
+           "hbm_gbs_end_to_end": round(bpt * K / wall / 1e9, 2),
+           "hbm_frac_end_to_end": round(bpt * K / wall / 1e9 / HBM_PEAK_GBS, 4),
+           "roofline": roofline_block(ctx, cfg, K, traffic[0], traffic[1])}
+    S = hdr[6]
+    ms = ctx.bench_decode(1, 0, S)
+    out["whole_context_tok_s"] = round(S / (ms * 1e-3), 2)
+    ctx.close()
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(name, hdr, seed)
+    return out
 
 
 def main():
@@ -93,9 +217,14 @@ def main():
     ap.add_argument("--config", default="llama2_7b", choices=sorted(configs.CONFIGS))
     ap.add_argument("--seed", type=int, default=configs.DEFAULT_SEED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary stories110M line")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (stories110M block, long context, sampler, prefill)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the l2_forward (host round trip per token) loop")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args.config, args.seed)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,13 +232,22 @@ def main():
     hdr = configs.header(args.config)
     K = min(args.steps, hdr[6])
     W = min(args.warmup, hdr[6])
+    extras = rank == 0 and world == 1
+
+    # counter passes first: they are child processes, and nothing in THIS process has touched the GPU yet
+    traffic = {args.config: (None, "skipped (--no-pmc)")}
+    if extras and not args.no_pmc:
+        traffic[args.config] = pmc_traffic(args.config, args.seed)
+        if not args.no_extra and args.config == "llama2_7b":
+            traffic["stories110M"] = pmc_traffic("stories110M", args.seed)
+
     dist = None
     tp = None
     shards = world > 1 and args.config.startswith("llama2_7b")
     if world > 1:
         import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo")   # rendezvous + barriers only; the data path is RCCL inside the library
+        dist.init_process_group("gloo")   # rendezvous + barriers only; the data path is inside the library
         if shards:
             idbuf = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -121,7 +259,12 @@ def main():
             tp = {"rank": rank, "size": world, "id": bytes(idbuf.numpy().tobytes())}
 
     device = int(os.environ.get("L2_BENCH_FORCE_DEVICE", local_rank))   # test hook: several ranks on one GPU (replicas only)
-    cfg, ctx = run_single(args, hdr, device, tp)
+    cfg = runtime.Config(hdr)
+    if tp:
+        ctx = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=tp["id"])
+    else:
+        ctx = runtime.Context(hdr, device=device)
+    ctx.synth_fill(args.seed)
 
     def sync_all():
         if dist is not None:
@@ -143,7 +286,8 @@ def main():
 
     tokens_total = K if (shards or world == 1) else K * world
     value = tokens_total / wall
-    bpt = avg_bytes_per_token(hdr, K)
+    bpt = avg_bytes_per_token(hdr, 0, K)
+    per_gpu_streams = 1 if (shards or world == 1) else world
 
     out = {
         "metric": "decode tokens/sec + achieved HBM GB/s (% peak), 1 GPU" if world == 1 else "decode tokens/sec (whole job)",
@@ -153,67 +297,40 @@ def main():
         "data": "synthetic (seeded hash generator, llama2.c-v0 layout)",
         "config": {"workload": "%s batch-1 greedy decode, %d tokens from BOS (-t 0 -s 1 -n %d)" % (args.config, K, K),
                    "header": list(hdr), "parallelism": ("tp%d" % world) if shards else ("replicas%d" % world if world > 1 else "single"),
-                   "loop": ("device-resident (forward + argmax on GPU), eager launches with 2L fp64 RCCL all-reduces + 1 all-gather per token"
+                   "loop": ("device-resident (forward + argmax on GPU); tensor-parallel step: %s" % ctx.tp_mode()
                             if shards else "device-resident (forward + argmax on GPU, one hipGraph replay per token)")},
         "device_ms_per_step": round(dev_ms / K, 5),
         "algorithmic_bytes_per_token": int(bpt),
-        "hbm_gbs_end_to_end": round(bpt * value / 1e9 / (1 if shards or world == 1 else world), 2),
-        "hbm_frac_end_to_end": round(bpt * value / 1e9 / (1 if shards or world == 1 else world) / HBM_PEAK_GBS / (world if shards else 1), 4),
+        "hbm_gbs_end_to_end": round(bpt * value / 1e9 / per_gpu_streams, 2),
+        "hbm_frac_end_to_end": round(bpt * value / 1e9 / per_gpu_streams / HBM_PEAK_GBS / (world if shards else 1), 4),
     }
 
-    if rank == 0 and world == 1:
-        # the same K steps through the blocking drop-in boundary (logits to the host every token)
-        if not args.no_dropin:
+    if extras:
+        if not args.no_dropin:   # the same K steps through the blocking drop-in boundary (logits to the host every token)
             tok = 1
             ctx.forward(1, 0)
             t0 = time.perf_counter()
             for pos in range(K):
-                lg = ctx.forward(tok, pos)
-                tok = int(np.argmax(lg))
-            dt = time.perf_counter() - t0
-            out["dropin_tok_s"] = round(K / dt, 3)
-        # dominant kernel alone, HIP events on the library's stream
-        iters = 200 if cfg.dim * cfg.hidden_dim < (1 << 24) else 50
-        kms_isolated = ctx.bench_gemv(runtime.T_W1, cfg.n_layers // 2, iters)
-        # the dominant kernel timed IN SITU: HIP event pairs around each of its launches inside K decode steps
-        # (eager launches of the same kernels, on the library's stream)
-        kus, nlaunch = ctx.bench_dominant_in_situ(1, 0, min(K, 128))
-        kms = kus * 1e-3
-        kb = dominant_kernel_bytes(cfg)
-        ach = kb / (kms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "kernel": "phase_kernel<MODE_W13> (rmsnorm + w1/w3 GEMV + SwiGLU, llama2.ts:276-289)",
-                           "bytes_per_launch": kb, "avg_launch_us": round(kms * 1e3, 3), "launches_timed": nlaunch,
-                           "how": "HIP event pair around every launch inside a decode run on the library's stream",
-                           "isolated_back_to_back_us": round(kms_isolated * 1e3, 3)}
-        per_kernel = {}
-        for nm, kind in (("qkv", runtime.T_WQ), ("wo", runtime.T_WO), ("w13", runtime.T_W1), ("w2", runtime.T_W2), ("wcls", runtime.T_WCLS)):
-            ms = ctx.bench_gemv(kind, 0, iters)
-            d, h, V = cfg.dim, cfg.hidden_dim, cfg.vocab_size
-            nb = {"qkv": 3 * d * d, "wo": d * d, "w13": 2 * d * h, "w2": d * h, "wcls": V * d}[nm] * 4
-            per_kernel[nm] = {"us": round(ms * 1e3, 3), "GBs": round(nb / (ms * 1e-3) / 1e9, 1)}
-        out["per_kernel"] = per_kernel
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config, hdr, args.seed)
+                tok = int(np.argmax(ctx.forward(tok, pos, view=True)))
+            out["dropin_tok_s"] = round(K / (time.perf_counter() - t0), 3)
+        out["roofline"] = roofline_block(ctx, cfg, K, *traffic[args.config])
+        out["per_kernel"] = per_kernel_block(ctx, cfg)
+        S = hdr[6]
         if not args.no_extra:
-            # the same loop near the end of the context window (attention reads ~S rows per layer; split-attention form)
-            S = hdr[6]
-            if S >= 1024:
+            # the whole context window, position 0 .. S-1 (attention reads up to S rows per layer; split form beyond 144 rows)
+            ms = ctx.bench_decode(1, 0, S)
+            out["whole_context_tok_s"] = round(S / (ms * 1e-3), 3)
+            if S >= 1024:   # and its last 128 positions on their own
                 n_long = 128
                 p0 = S - n_long
                 ctx.bench_decode(1, p0, 8)
                 ms = ctx.bench_decode(1, p0, n_long)
-                b_long = sum(configs.algorithmic_bytes_per_token(hdr, p) for p in range(p0, S)) / n_long
+                b_long = avg_bytes_per_token(hdr, p0, S)
                 out["long_context"] = {"positions": [p0, S - 1], "value": round(n_long / (ms * 1e-3), 3), "unit": "tokens/s",
                                        "ms_per_step": round(ms / n_long, 5), "algorithmic_bytes_per_token": int(b_long),
                                        "hbm_frac_end_to_end": round(b_long * n_long / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             # the sampled branch of the loop on the device (l2_decode_sample): reference semantics, same token ids per seed
-            n_s = min(64, hdr[6])
+            n_s = min(64, S)
             samp = {}
             for nm, t, p in (("sample_t0.9", 0.9, 1.0), ("topp0.9_t0.9", 0.9, 0.9)):
                 ctx.decode_sample(1, 0, 8, t, p, 42)
@@ -222,7 +339,7 @@ def main():
                 samp[nm] = round(n_s / (time.perf_counter() - t0), 3)
             out["sampled_decode_tok_s"] = samp
             # prompt ingestion (l2_prefill: chunks of up to 64 tokens on the fp64 MFMA path) next to the token-by-token loop it replaces
-            n_p = min(128, hdr[6])
+            n_p = min(128, S)
             ptoks = (np.arange(n_p, dtype=np.int32) * 7919 + 2) % cfg.vocab_size
             ctx.prefill(ptoks[:64], 0)
             t0 = time.perf_counter()
@@ -230,21 +347,11 @@ def main():
             out["prefill_tok_s"] = round(n_p / (time.perf_counter() - t0), 1)
     ctx.close()
 
-    if rank == 0 and world == 1 and not args.no_extra and args.config == "llama2_7b":
-        # BASELINE.json's metric names stories110M too: same measurement, secondary line in the same JSON
-        h2 = configs.header("stories110M")
-        c2 = runtime.Context(h2, device=local_rank)
-        c2.synth_fill(args.seed)
-        K2 = min(256, h2[6])
-        c2.bench_decode(1, 0, 8)
-        t0 = time.perf_counter()
-        c2.bench_decode(1, 0, K2)
-        w2 = time.perf_counter() - t0
-        b2 = avg_bytes_per_token(h2, K2)
-        out["stories110M"] = {"value": round(K2 / w2, 2), "unit": "tokens/s", "steps": K2,
-                              "hbm_gbs_end_to_end": round(b2 * K2 / w2 / 1e9, 2),
-                              "hbm_frac_end_to_end": round(b2 * K2 / w2 / 1e9 / HBM_PEAK_GBS, 4)}
-        c2.close()
+    if extras and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.config, hdr, args.seed)
+    if extras and not args.no_extra and args.config == "llama2_7b":
+        out["stories110M"] = secondary_config("stories110M", args.seed, local_rank, not args.no_cpu_baseline,
+                                              traffic.get("stories110M", (None, "skipped")))
 
     if rank == 0:
         print(json.dumps(out))

@@ -83,6 +83,10 @@ void l2_destroy(l2_ctx* ctx);
  * [rank*H/G, ...).  `nccl_id` is the 128-byte ncclUniqueId produced by l2_tp_unique_id on rank 0 and
  * handed to the others by the caller (e.g. over torch.distributed).  tp_size 1 == l2_create. */
 int l2_tp_unique_id(void* id_out_128);
+/* How this context's tensor-parallel step runs: 0 not tensor parallel, 1 eager launches with RCCL collectives,
+ * 2 one hipGraph per token with the RCCL collectives captured, 3 one hipGraph per token with the one-shot
+ * peer-to-peer all-reduce, 4 loopback test group. */
+int l2_tp_mode(l2_ctx* ctx);
 int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out);
 
 /* Replaces the hand-over of one Float32Array of TransformerWeights (readWeights, llama2.ts:112-129):

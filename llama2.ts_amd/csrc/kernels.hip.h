@@ -81,6 +81,7 @@ struct PhaseArgs {
   // tensor parallel: column-sharded WO/W2 write fp64 partials instead of x
   double* partial;    // non-null (WO/W2 of a tensor-parallel rank): out[i] is not written, partial[i] = fp64 sum
   double inv_n;       // 1.0 / n, correctly rounded by the host (rmsnorm's mean, llama2.ts:174)
+  unsigned long long* amax;  // CLS of the greedy loop: 8 argmax keys (one per 128-byte line) the workgroups fold their best logit into, or null
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
 };
 
@@ -241,6 +242,35 @@ __device__ __forceinline__ void row_ptrs(const PhaseArgs& a, int g, int n, const
   }
 }
 
+// argmax (llama2.ts:364-366: first maximum, strict '>'): a logit and its index travel as ONE 64-bit key
+// (order-preserving bits of the value, then ~index), so "largest value, smallest index" is an unsigned maximum.
+__device__ __forceinline__ unsigned long long argmax_key(float v, int i) {
+  v = v + 0.0f;                                          // -0 -> +0: '>' does not tell them apart
+  const unsigned u = __float_as_uint(v);
+  const unsigned o = (v != v) ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));   // NaN never wins a '>'
+  return ((unsigned long long)o << 32) | (unsigned)(~i);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {   // lanes outside ROW_MASK keep v
+  const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+  const unsigned nlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  const unsigned nhi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  const unsigned long long o = ((unsigned long long)nhi << 32) | nlo;
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  v = dpp_max_u64<0xB1, 0xf>(v);
+  v = dpp_max_u64<0x4E, 0xf>(v);
+  v = dpp_max_u64<0x141, 0xf>(v);
+  v = dpp_max_u64<0x140, 0xf>(v);
+  v = dpp_max_u64<0x142, 0xa>(v);
+  v = dpp_max_u64<0x143, 0xc>(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+
 // Epilogue operands that do not depend on the GEMV (RoPE table entries of the row pair, residual value of the row):
 // lane p's operands for pair / row p of row group g.  The latency kernel requests them with the weights; the
 // streaming kernel loads them in the epilogue (there the extra live registers cost more than the L2 round trip).
@@ -268,7 +298,8 @@ __device__ __forceinline__ EpiPre epi_prefetch(const PhaseArgs& a, int g, int la
 
 // Epilogue of one row group; every lane holds every reduced sum, lane p finishes output / pair p.
 template <int MODE, int R, bool PREF>
-__device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const double (&acc)[R], int lane, int token, int pos, const EpiPre& pre) {
+__device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const double (&acc)[R], int lane, int token, int pos, const EpiPre& pre,
+                                             unsigned long long& best) {
   if (MODE == MODE_QKV) {
     int m, i0;
     qkv_group(a, g, R, m, i0);
@@ -318,6 +349,8 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         const float lg = (float)acc[r];                                     // llama2.ts:302
         a.out[row0 + r] = lg;
         if (a.aux2) a.aux2[row0 + r] = lg;   // straight into the host's RunState.logits (pinned, mapped)
+        const unsigned long long key = argmax_key(lg, row0 + r);
+        best = key > best ? key : best;
       }
     }
   } else {  // WO / W2: matmul store then residual accum (llama2.ts:270-273, 292-295)
@@ -478,6 +511,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   STAMP(4);
 
   const EpiPre nopre = {0.0f, 0.0f};
+  unsigned long long best = 0;      // CLS: this lane's best (logit, index) so far
   auto finish = [&](int gi) {
     if (R == 2) wave_sum2(acc[0], acc[R - 1]);
     else {
@@ -485,7 +519,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
       for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
     }
     STAMP(6);
-    finish_group<MODE, R, false>(a, gi, acc, lane, token, pos, nopre);
+    finish_group<MODE, R, false>(a, gi, acc, lane, token, pos, nopre, best);
     STAMP(7);
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
@@ -510,6 +544,19 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
     consume(bufB, ch2);
     if (ch2 == nchunks - 1) finish(g2);
     g = g3; ch = ch3; have = have3;
+  }
+  if (MODE == MODE_CLS && a.amax) {
+    // greedy loop: ONE memory-side maximum per workgroup (no value returned, nothing waits for it); the launch
+    // boundary orders it before the one-wave kernel that reads the eight keys (argmax_finish_kernel)
+    best = wave_max_u64(best);
+    unsigned long long* sk = reinterpret_cast<unsigned long long*>(red);
+    __syncthreads();
+    if (lane == 0) sk[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < nwaves; ++w) best = sk[w] > best ? sk[w] : best;
+      __hip_atomic_fetch_max(a.amax + (size_t)(vblock & 7) * 16, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -650,7 +697,8 @@ __global__ void __launch_bounds__(512) phase_small_kernel(const PhaseArgs a) {
       for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
     }
     STAMP(6);
-    finish_group<MODE, R, true>(a, gi, acc, lane, token, pos, pre);
+    unsigned long long nobest = 0;
+    finish_group<MODE, R, true>(a, gi, acc, lane, token, pos, pre, nobest);
     STAMP(7);
   };
   for (int g = g0; g < groups; g += 2 * gstride) {
@@ -691,6 +739,7 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
   __syncthreads();
   const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
   const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
+  unsigned long long best = 0;
   for (int g = blockIdx.x * nwaves + wave; g < groups; g += gridDim.x * nwaves) {
     const float* rp[R];
     row_ptrs<MODE, R>(a, g, n, rp);
@@ -705,7 +754,18 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-    { const EpiPre nopre = {0.0f, 0.0f}; finish_group<MODE, R, false>(a, g, acc, lane, token, pos, nopre); }
+    { const EpiPre nopre = {0.0f, 0.0f}; finish_group<MODE, R, false>(a, g, acc, lane, token, pos, nopre, best); }
+  }
+  if (MODE == MODE_CLS && a.amax) {   // as in phase_body
+    best = wave_max_u64(best);
+    unsigned long long* sk = reinterpret_cast<unsigned long long*>(red);
+    __syncthreads();
+    if (lane == 0) sk[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < nwaves; ++w) best = sk[w] > best ? sk[w] : best;
+      __hip_atomic_fetch_max(a.amax + (size_t)(blockIdx.x & 7) * 16, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -714,30 +774,19 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
 // loop (llama2.ts:465-508 at -t 0) on the device.  A logit and its index travel as ONE 64-bit key
 // (order-preserving bits of the value, then ~index), so "largest value, smallest index" is an unsigned maximum and
 // the cross-lane reduction runs on the DPP path; {pos, step} are requested at the top, not after the reduction.
-__device__ __forceinline__ unsigned long long argmax_key(float v, int i) {
-  v = v + 0.0f;                                          // -0 -> +0: '>' does not tell them apart
-  const unsigned u = __float_as_uint(v);
-  const unsigned o = (v != v) ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));   // NaN never wins a '>'
-  return ((unsigned long long)o << 32) | (unsigned)(~i);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {   // lanes outside ROW_MASK keep v
-  const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-  const unsigned nlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-  const unsigned nhi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-  const unsigned long long o = ((unsigned long long)nhi << 32) | nlo;
-  return o > v ? o : v;
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  v = dpp_max_u64<0xB1, 0xf>(v);
-  v = dpp_max_u64<0x4E, 0xf>(v);
-  v = dpp_max_u64<0x141, 0xf>(v);
-  v = dpp_max_u64<0x140, 0xf>(v);
-  v = dpp_max_u64<0x142, 0xa>(v);
-  v = dpp_max_u64<0x143, 0xc>(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-  return ((unsigned long long)hi << 32) | lo;
+// The greedy loop's pick when the classifier kernel has folded its logits into the eight keys of `amax`: one wave
+// takes their maximum, re-arms them, records the token and advances {token, pos, step}.
+__global__ void __launch_bounds__(64) argmax_finish_kernel(unsigned long long* amax, int* tokpos, int* tokens_out) {
+  const int lane = threadIdx.x;
+  const int p1 = tokpos[1], step = tokpos[2];
+  unsigned long long k = lane < 8 ? amax[(size_t)lane * 16] : 0ull;
+  if (lane < 8) amax[(size_t)lane * 16] = 0ull;
+  k = wave_max_u64(k);
+  if (lane == 0) {
+    const int bi = (k == 0) ? 0 : (int)~(unsigned)k;
+    tokens_out[step] = bi;
+    tokpos[0] = bi; tokpos[1] = p1 + 1; tokpos[2] = step + 1;
+  }
 }
 
 __global__ void __launch_bounds__(1024) argmax_advance_kernel(const float* logits, int V, int* tokpos, int* tokens_out) {

@@ -162,6 +162,7 @@ struct l2_ctx {
   double* partial = nullptr;
   double* attn_part = nullptr;      // split attention partials [H][NS][rec]
   unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
+  unsigned long long* amax = nullptr;   // greedy loop: 8 argmax keys, one per 128-byte line, zero between tokens
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int cur_splits = 1;               // split count of the step being enqueued / captured
@@ -262,6 +263,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->partial) hipFree(c->partial);
   if (c->attn_part) hipFree(c->attn_part);
   if (c->attn_counter) hipFree(c->attn_counter);
+  if (c->amax) hipFree(c->amax);
   for (hipEvent_t e : c->probe) hipEventDestroy(e);
   { float* pb[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_xb, c->pf_hb}; for (float* b : pb) if (b) hipFree(b); if (c->pf_tok) hipFree(c->pf_tok); }
   if (c->tokpos) hipFree(c->tokpos);
@@ -361,6 +363,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     CK(hipMalloc(&c->attn_part, (size_t)c->H_loc * maxs * rec * 8));
     CK(hipMalloc(&c->attn_counter, (size_t)c->H_loc * CTR_STRIDE * 4));
     CK(hipMemsetAsync(c->attn_counter, 0, (size_t)c->H_loc * CTR_STRIDE * 4, c->stream));
+    CK(hipMalloc(&c->amax, 8 * 16 * 8));
+    CK(hipMemsetAsync(c->amax, 0, 8 * 16 * 8, c->stream));
   }
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
@@ -417,6 +421,12 @@ extern "C" int l2_tp_unique_id(void* id_out_128) {
   NCCLCHK(g_rccl.GetUniqueId(&uid));
   memcpy(id_out_128, &uid, sizeof(uid));
   return L2_OK;
+}
+
+extern "C" int l2_tp_mode(l2_ctx* c) {
+  if (!c || !c->tp_path) return 0;
+  if (c->loop) return 4;
+  return c->opt_graph ? 2 : 1;
 }
 
 extern "C" int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out) {
@@ -913,7 +923,7 @@ static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
   return L2_OK;
 }
 
-static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
+static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fold_argmax = false) {
   for (int l = 0; l < c->L; ++l) {
     PhaseArgs a = qkv_args(c, l);
     LCHK(launch_phase<MODE_QKV>(c, a, st));
@@ -938,6 +948,7 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host) {
     }
   }
   PhaseArgs a = cls_args(c, to_host);
+  if (fold_argmax) a.amax = c->amax;
   LCHK(launch_phase<MODE_CLS>(c, a, st));
   if (c->tp_path) { const int rc_ = tp_all_gather_logits(c, st); if (rc_) return rc_; }
   return L2_OK;
@@ -957,9 +968,13 @@ static int ensure_ready(l2_ctx* c) {
 }
 
 static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step: forward, argmax, advance
-  int rc = enqueue_forward(c, st);
+  // the classifier's workgroups fold their logits into 8 argmax keys, one wave finishes; a tensor-parallel rank has
+  // only its slice of the logits before the all-gather and takes the maximum over the gathered vector instead
+  const bool fold = !c->tp_path;
+  int rc = enqueue_forward_impl(c, st, false, fold);
   if (rc) return rc;
-  hipLaunchKernelGGL(argmax_advance_kernel, dim3(1), dim3(1024), 0, st, c->logits, c->V, c->tokpos, c->d_tokens);
+  if (fold) hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(64), 0, st, c->amax, c->tokpos, c->d_tokens);
+  else hipLaunchKernelGGL(argmax_advance_kernel, dim3(1), dim3(1024), 0, st, c->logits, c->V, c->tokpos, c->d_tokens);
   LCHK(hipGetLastError());
   return L2_OK;
 }

@@ -236,6 +236,16 @@ napi_value SynthFill(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// l2_forward / l2_prefill write vocab_size floats: a shorter Float32Array would be a heap overflow in the host
+static bool logits_fit(napi_env env, l2_ctx* c, const float* out, size_t n) {
+  if (!out) return true;
+  int32_t hdr[7];
+  if (api.get_header(c, hdr) != 0) { throw_err(env, "cannot read the context's header"); return false; }
+  const size_t V = (size_t)(hdr[5] < 0 ? -hdr[5] : hdr[5]);
+  if (n < V) { throw_err(env, "logits array too small (needs vocab_size floats)"); return false; }
+  return true;
+}
+
 // forward(handle, token, pos, Float32Array|null)             (transformer(), llama2.ts:205-303 / :468)
 napi_value Forward(napi_env env, napi_callback_info info) {
   ARGS(4)
@@ -246,6 +256,7 @@ napi_value Forward(napi_env env, napi_callback_info info) {
   if (!get_ctx(env, argv[0], &c) || !get_i32(env, argv[1], &token) || !get_i32(env, argv[2], &pos) ||
       !get_f32_array(env, argv[3], &out, &n, true))
     return nullptr;
+  if (!logits_fit(env, c, out, n)) return nullptr;
   int rc = api.forward(c, token, pos, out);
   if (rc) return throw_l2(env, rc);
   return nullptr;
@@ -266,6 +277,7 @@ napi_value Prefill(napi_env env, napi_callback_info info) {
   size_t off;
   if (napi_get_typedarray_info(env, argv[1], &tt, &len, &p, &ab, &off) != napi_ok || tt != napi_int32_array)
     return throw_err(env, "expected Int32Array tokens");
+  if (!logits_fit(env, c, out, n)) return nullptr;
   int rc = api.prefill(c, (const int32_t*)p, (int)len, pos0, out);
   if (rc) return throw_l2(env, rc);
   return nullptr;

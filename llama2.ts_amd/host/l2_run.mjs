@@ -1,0 +1,87 @@
+// @ts-check
+// l2_run.mjs -- drive the forward pass from Node with TOKEN IDS in and out (no tokenizer, no text):
+//
+//   node l2_run.mjs <checkpoint> [--steps N] [--prompt 12,7,99] [--temperature T] [--topp P] [--seed S]
+//                   [--loop host|device] [--prefill] [--native-loader]
+//
+// Prints ONE JSON line {"tokens":[...], "tok_s":...}: the ids the reference's loop (llama2.ts:465-508) would have
+// printed as text for the same checkpoint, prompt, flags and seed -- tests/test_cli_gpu.py turns them into text with
+// the tokenizer's vocabulary and compares with what the reference printed.
+//   --loop host    one transformer() call per position through the drop-in boundary, greedy pick here (temperature 0);
+//   --loop device  the library's device-resident loops: l2_decode_greedy, or l2_decode_sample when temperature > 0
+//                  (temperature / softmax / sample / top-p / RNG on the GPU, same ids as the reference for the seed).
+import { openBackend, loadModel, transformer } from "./l2_backend.mjs";
+
+function options(argv) {
+  const o = { steps: 256, prompt: [], temperature: 0, topp: 1, seed: 1n, loop: "host", prefill: false, nativeLoader: false };
+  for (let i = 0; i < argv.length; ++i) {
+    const k = argv[i];
+    if (k == "--prefill") o.prefill = true;
+    else if (k == "--native-loader") o.nativeLoader = true;
+    else if (i + 1 >= argv.length) throw new Error("missing value after " + k);
+    else if (k == "--steps") o.steps = parseInt(argv[++i]);
+    else if (k == "--prompt") o.prompt = argv[++i].split(",").filter((t) => t.length).map((t) => parseInt(t));
+    else if (k == "--temperature") o.temperature = parseFloat(argv[++i]);
+    else if (k == "--topp") o.topp = parseFloat(argv[++i]);
+    else if (k == "--seed") o.seed = BigInt(argv[++i]);
+    else if (k == "--loop") o.loop = argv[++i];
+    else throw new Error("unknown option " + k);
+  }
+  return o;
+}
+
+function firstMaximum(values) {          // the reference's argmax keeps the first of equal maxima (llama2.ts:364-366)
+  let at = 0;
+  for (let i = 1; i < values.length; ++i) if (values[i] > values[at]) at = i;
+  return at;
+}
+
+function run() {
+  const [, , file, ...rest] = process.argv;
+  if (!file) throw new Error("usage: node l2_run.mjs <checkpoint> [--steps N] [--prompt ids] [--temperature T] [--topp P] [--seed S] [--loop host|device] [--prefill] [--native-loader]");
+  const o = options(rest);
+  const be = openBackend();
+  const { config, weights, state } = loadModel(file, be, { device: parseInt(process.env.L2_DEVICE || "0"), nativeLoader: o.nativeLoader });
+  const steps = (o.steps <= 0 || o.steps > config.seq_len) ? config.seq_len : o.steps;
+  const out = [];
+  let token = 1, pos = 0, t0 = 0;          // position 0 is fed BOS (llama2.ts:463)
+
+  // the teacher-forced prompt positions (llama2.ts:471-473): one transformer() each, or one batched l2_prefill
+  const forced = Math.min(o.prompt.length, steps);
+  if (o.prefill && forced > 1) {
+    be.prefill(weights.ctx, Int32Array.from([1, ...o.prompt.slice(0, forced - 1)]), 0, null);
+    for (; pos < forced; ++pos) out.push(token = o.prompt[pos]);
+  }
+  for (; pos < forced; ++pos) { transformer(token, pos, config, state, weights, be); out.push(token = o.prompt[pos]); }
+
+  const seed = new Uint32Array([Number(o.seed & 0xffffffffn), Number(o.seed >> 32n)]);
+  while (pos < steps) {
+    if (!t0) t0 = Date.now();
+    let ids;
+    if (o.loop == "device") {
+      const n = Math.min(16, steps - pos);
+      ids = o.temperature == 0 ? be.decodeGreedy(weights.ctx, token, pos, n) : be.decodeSample(weights.ctx, token, pos, n, o.temperature, o.topp, seed);
+    } else {
+      if (o.temperature != 0) throw new Error("--loop host picks greedily; sampling runs on the device (--loop device)");
+      transformer(token, pos, config, state, weights, be);
+      ids = [firstMaximum(state.logits)];
+    }
+    let stop = false;
+    for (const id of ids) {
+      ++pos;
+      if (id == 1) { stop = true; break; }   // BOS ends the sequence (llama2.ts:499)
+      out.push(token = id);
+    }
+    if (stop) break;
+  }
+  const ms = Date.now() - t0;
+  be.destroy(weights.ctx);
+  process.stdout.write(JSON.stringify({ tokens: out, tok_s: ms > 0 ? (out.length - 1) / ms * 1000 : null }) + "\n");
+}
+
+try {
+  run();
+} catch (e) {
+  console.error(String(e && e.message ? e.message : e));
+  process.exit(1);
+}

@@ -31,7 +31,7 @@ OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_KEEP_ATT = 1, 2, 3
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
                "l2_decode_greedy", "l2_decode_sample", "l2_debug_running_sums", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
-               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ"]
+               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ", "l2_tp_mode"]
 
 
 class L2Error(RuntimeError):
@@ -80,6 +80,8 @@ def lib():
     L.l2_get_header.argtypes = [vp, vp]
     L.l2_prefill.argtypes = [vp, vp, i32, i32, vp]
     L.l2_bench_dominant_in_situ.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(i32)]
+    L.l2_tp_mode.argtypes = [vp]
+    L.l2_tp_mode.restype = i32
     for name in ABI_SYMBOLS:   # fail at load time, not at first use, if the .so is stale
         getattr(L, name)
     _lib = L
@@ -146,8 +148,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().l2_destroy(self._h)
+            lib().l2_destroy(self._h)     # frees the pinned logits buffer: views handed out by logits_host() die here
             self._h = None
+            self._logits_view = None
 
     def __del__(self):
         try:
@@ -169,20 +172,30 @@ class Context:
         return out
 
     # -- forward
-    def forward(self, token, pos, out=None):
-        if out is None:
-            _check(lib().l2_forward(self._h, int(token), int(pos), None))
-            return self.logits_host()
-        _check(lib().l2_forward(self._h, int(token), int(pos), out.ctypes.data))
-        return out
+    def forward(self, token, pos, out=None, view=False):
+        """transformer(token, pos, ...) (llama2.ts:468).  Returns the logits as a fresh array; `out` (float32,
+        contiguous, >= vocab_size) receives them in place; `view=True` returns the library's pinned buffer itself --
+        zero copy, but the NEXT forward / prefill overwrites it and close() frees it (like state.logits in the
+        reference, which every transformer() call rewrites)."""
+        if out is not None:
+            if out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"] or out.size < self.cfg.vocab_size:
+                raise ValueError("logits array must be contiguous float32 with at least vocab_size elements")
+            _check(lib().l2_forward(self._h, int(token), int(pos), out.ctypes.data))
+            return out
+        _check(lib().l2_forward(self._h, int(token), int(pos), None))
+        return self.logits_host() if view else np.array(self.logits_host(), copy=True)
 
     def prefill(self, tokens, pos0=0):
         """Feed a run of (prompt) tokens at pos0.. in chunks of up to 64 tokens; returns the logits of the last position."""
         t = np.ascontiguousarray(tokens, dtype=np.int32)
         _check(lib().l2_prefill(self._h, t.ctypes.data, t.size, int(pos0), None))
-        return self.logits_host()
+        return np.array(self.logits_host(), copy=True)
 
     def logits_host(self):
+        """The pinned host buffer l2_forward fills (V floats), as a numpy VIEW: valid until close(), rewritten by
+        every forward / prefill."""
+        if self._h is None:
+            raise L2Error(-4, "context is closed")
         if self._logits_view is None:
             p = lib().l2_logits_host(self._h)
             self._logits_view = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(self.cfg.vocab_size,))
@@ -239,6 +252,13 @@ class Context:
         us, n = C.c_float(), C.c_int()
         _check(lib().l2_bench_dominant_in_situ(self._h, first_token, pos0, steps, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def tp_mode(self):
+        """How the tensor-parallel step runs (l2_tp_mode): none / RCCL eager / RCCL in a graph / peer-to-peer in a graph."""
+        return {0: "single GPU", 1: "eager launches, 2L RCCL fp64 all-reduces + 1 all-gather per token",
+                2: "one hipGraph per token with the RCCL collectives captured in it",
+                3: "one hipGraph per token, one-shot peer-to-peer fp64 all-reduce inside the residual kernels",
+                4: "loopback test group"}.get(lib().l2_tp_mode(self._h), "?")
 
     def bench_decode(self, first_token, pos0, steps):
         ms = C.c_float()

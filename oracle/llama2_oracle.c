@@ -76,6 +76,10 @@ static inline int32_t synth_c(uint64_t g, uint32_t seed) {
 }
 
 void orc_synth_fill(float* out, uint64_t g0, uint64_t n, uint32_t seed, float scale, float bias) {
+  /* every element is a pure function of its index: the GENERATOR (never the forward pass) may use all host threads */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (n > (1u << 20))
+#endif
   for (uint64_t i = 0; i < n; ++i) {
     const float p = (float)synth_c(g0 + i, seed) * scale; /* one fp32 rounding */
     out[i] = bias + p;                                    /* one fp32 rounding */

@@ -1,9 +1,13 @@
-"""End-to-end drop-in check: `node llama2.mjs <ckpt> ...` (JS host -> N-API -> C ABI -> HIP) must print
-exactly what the TRUE reference printed for the same checkpoint, tokenizer, flags and seed.
+"""End-to-end drop-in check through the JavaScript boundary: Node -> N-API addon -> C ABI -> HIP.
 
-The expected text comes from tests/golden/cli_*.json (oracle/make_goldens.py ran /root/reference/llama2.ts
-under Node with the synthetic tokenizer of tests/synth_tokenizer.py in its working directory).  Covers the
-greedy path, a BPE-encoded prompt, temperature sampling and top-p sampling (host sampler + RNG on GPU logits).
+`llama2.ts_amd/host/l2_run.mjs` drives the forward pass with token ids in and out (the tokenizer, the RNG and the
+printing of the reference's CLI are host-only code outside the hot path).  The ids it returns,
+turned into text here with the tokenizer's vocabulary and the reference's printing rule (llama2.ts:502: the piece
+after BOS loses one leading space), must be exactly what the TRUE reference printed for the same checkpoint, prompt,
+flags and seed -- tests/golden/cli_*.json holds that stdout (oracle/make_goldens.py ran /root/reference/llama2.ts
+under Node with the synthetic tokenizer of tests/synth_tokenizer.py in its working directory).
+Covers: the per-token drop-in call with a greedy pick, a teacher-forced prompt, the device-resident greedy loop, the
+device sampler (temperature, top-p, RNG), the batched prompt prefill and the native checkpoint loader.
 """
 import json
 import os
@@ -19,8 +23,9 @@ import synth_tokenizer
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-HOST = os.path.join(ROOT, "llama2.ts_amd", "host", "llama2.mjs")
-TOKS = re.compile(r"\n\nachieved tok/s: [^\n]*\n\n$")
+HOST = os.path.join(ROOT, "llama2.ts_amd", "host", "l2_run.mjs")
+TRAILER = re.compile(r"\n\nachieved tok/s: [^\n]*\n\n$")
+VOCAB, _ = synth_tokenizer.build_vocab()
 
 
 @pytest.fixture(scope="module")
@@ -32,76 +37,86 @@ def workdir(tmp_path_factory):
     d = tmp_path_factory.mktemp("cli")
     meta = json.load(open(os.path.join(GOLD, "cli_greedy.json")))
     O.synth_write(meta["header"], meta["seed"], str(d / "model.bin"))
-    synth_tokenizer.write(str(d / "tokenizer.bin"))
     return d
 
 
-def run_cli(workdir, argv, env=None):
+def reference_run(name):
+    """(flags of the reference's run, prompt ids, the text it printed without the tok/s trailer)."""
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    flags = dict(zip(meta["argv"][::2], meta["argv"][1::2]))
+    fed = meta["tokens_fed"]
+    prompt_ids = []
+    if meta["prompt"] is not None:      # the teacher-forced ids are the fed tokens whose pieces spell the prompt (llama2.ts:471-473)
+        text = ""
+        for t in fed[1:]:
+            if text == meta["prompt"]:
+                break
+            text += VOCAB[t]
+            prompt_ids.append(t)
+        assert text == meta["prompt"]
+    return flags, prompt_ids, TRAILER.sub("", meta["stdout"])
+
+
+def text_of(ids):
+    out, prev = "", 1
+    for t in ids:
+        piece = VOCAB[t]
+        out += piece[1:] if (prev == 1 and piece.startswith(" ")) else piece     # llama2.ts:502
+        prev = t
+    return out
+
+
+def run_ids(workdir, argv, env=None):
     e = dict(os.environ)
     e.update(env or {})
     r = subprocess.run(["node", HOST, str(workdir / "model.bin"), *argv], cwd=str(workdir), env=e,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    return r.returncode, r.stdout.decode("utf8"), r.stderr.decode("utf8")
+    out = r.stdout.decode("utf8")
+    return r.returncode, (json.loads(out) if r.returncode == 0 else None), r.stderr.decode("utf8")
+
+
+def argv_for(flags, prompt_ids, loop, extra=()):
+    argv = ["--steps", flags["-n"], "--temperature", flags.get("-t", "1.0"), "--topp", flags.get("-p", "1.0"),
+            "--seed", flags.get("-s", "1"), "--loop", loop, *extra]
+    if prompt_ids:
+        argv += ["--prompt", ",".join(map(str, prompt_ids))]
+    return argv
+
+
+@pytest.mark.parametrize("name", ["cli_greedy", "cli_prompt"])
+def test_drop_in_call_per_token_prints_what_the_reference_printed(workdir, name):
+    flags, prompt_ids, want = reference_run(name)
+    rc, res, err = run_ids(workdir, argv_for(flags, prompt_ids, "host"))
+    assert rc == 0, err
+    assert text_of(res["tokens"]) == want
 
 
 @pytest.mark.parametrize("name", ["cli_greedy", "cli_prompt", "cli_temp", "cli_topp"])
-def test_cli_prints_what_the_reference_printed(workdir, name):
-    meta = json.load(open(os.path.join(GOLD, name + ".json")))
-    rc, out, err = run_cli(workdir, meta["argv"])
+@pytest.mark.parametrize("extra", [(), ("--prefill",)])
+def test_device_loops_print_what_the_reference_printed(workdir, name, extra):
+    """l2_decode_greedy / l2_decode_sample (temperature, softmax, sample / sample_topp and the RNG on the GPU), with
+    and without the batched prompt prefill in front."""
+    flags, prompt_ids, want = reference_run(name)
+    rc, res, err = run_ids(workdir, argv_for(flags, prompt_ids, "device", extra))
     assert rc == 0, err
-    assert TOKS.search(out), out[-80:]               # same trailer format as llama2.ts:511
-    assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
+    assert text_of(res["tokens"]) == want
 
 
-def test_cli_device_greedy_extra_prints_the_same(workdir):
-    meta = json.load(open(os.path.join(GOLD, "cli_greedy.json")))
-    rc, out, err = run_cli(workdir, meta["argv"], {"L2_DEVICE_GREEDY": "1"})
+def test_native_loader_prints_the_same(workdir):
+    flags, prompt_ids, want = reference_run("cli_prompt")
+    rc, res, err = run_ids(workdir, argv_for(flags, prompt_ids, "host", ("--native-loader",)))
     assert rc == 0, err
-    assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
+    assert text_of(res["tokens"]) == want
 
 
-@pytest.mark.parametrize("name", ["cli_temp", "cli_topp"])
-def test_cli_device_sampler_extra_prints_the_same(workdir, name):
-    """L2_DEVICE_SAMPLER=1: temperature, softmax, sample / sample_topp and the RNG on the GPU (l2_decode_sample),
-    with and without the batched prompt prefill in front of it."""
-    meta = json.load(open(os.path.join(GOLD, name + ".json")))
-    for extra in ({}, {"L2_PREFILL": "1"}):
-        rc, out, err = run_cli(workdir, meta["argv"], dict({"L2_DEVICE_SAMPLER": "1"}, **extra))
-        assert rc == 0, err
-        assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
-
-
-def test_cli_stats_line_goes_to_stderr_only(workdir):
-    meta = json.load(open(os.path.join(GOLD, "cli_greedy.json")))
-    rc, out, err = run_cli(workdir, meta["argv"], {"L2_STATS": "1"})
-    assert rc == 0, err
-    assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])          # stdout untouched
-    stats = json.loads(err.strip().splitlines()[-1])
-    assert stats["tokens_timed"] == meta["steps_run"] - 1 and stats["algorithmic_bytes_per_token"] > 60_000_000
-    assert 0 < stats["hbm_frac_of_8tbs"] < 1
-
-
-def test_cli_usage_and_errors(workdir):
+def test_errors_surface_as_exit_code_one(workdir):
     r = subprocess.run(["node", HOST], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode == 1 and r.stderr.decode().startswith("Usage: ... llama2.ts <checkpoint> [options]")
-    rc, _, err = run_cli(workdir, ["-x", "1"])
-    assert rc == 1 and "Usage:" in err               # unknown flag (llama2.ts:421)
-    rc, _, err = run_cli(workdir, ["-t"])
-    assert rc == 1 and "Usage:" in err               # flag without value (llama2.ts:410)
-    rc, _, err = run_cli(workdir, ["-t", "0", "-i", "中"])
-    assert rc == 1 and "character not found in vocab" in err   # llama2.ts:310
-
-
-def test_cli_native_loader_prints_the_same(workdir):
-    meta = json.load(open(os.path.join(GOLD, "cli_prompt.json")))
-    rc, out, err = run_cli(workdir, meta["argv"], {"L2_NATIVE_LOADER": "1"})
-    assert rc == 0, err
-    assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
-
-
-@pytest.mark.parametrize("name", ["cli_prompt", "cli_topp"])
-def test_cli_batched_prefill_prints_the_same(workdir, name):
-    meta = json.load(open(os.path.join(GOLD, name + ".json")))
-    rc, out, err = run_cli(workdir, meta["argv"], {"L2_PREFILL": "1"})
-    assert rc == 0, err
-    assert TOKS.sub("", out) == TOKS.sub("", meta["stdout"])
+    assert r.returncode == 1 and "usage" in r.stderr.decode()
+    rc, _, err = run_ids(workdir, ["--bogus", "1"])
+    assert rc == 1 and "unknown option" in err
+    rc, _, err = run_ids(workdir, ["--steps", "4", "--prompt", "99999999"])
+    assert rc == 1 and "token" in err                       # the library rejects ids outside the vocabulary
+    rc, _, err = run_ids(workdir, ["--steps", "4", "--temperature", "0.5"])
+    assert rc == 1 and "device" in err                      # host loop picks greedily only
+    r = subprocess.run(["node", HOST, str(workdir / "missing.bin")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1
