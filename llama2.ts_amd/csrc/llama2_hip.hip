@@ -113,6 +113,8 @@ struct LoopGroup {
   unsigned gen = 0;
   bool broken = false;
   const void* ptrs[16] = {};
+  void* p2p_base[16] = {};     // peer-to-peer exchange: every rank's inbox / logits, registered at create
+  float* p2p_logits[16] = {};
   bool wait() {   // generation barrier; false after 60 s (a rank died: fail instead of hanging the box)
     std::unique_lock<std::mutex> lk(mu);
     if (broken) return false;
@@ -134,6 +136,17 @@ __global__ void loop_sum_kernel(double* out, const LoopPtrs in, int G, int n) {
   out[i] = s;
 }
 
+// one-shot peer-to-peer exchange (kernels and protocol: tp_p2p_* below)
+enum { P2P_MAXG = 8, P2P_FB = 64 };   // ranks; flag words per (parity, source): blocks of the widest exchange
+struct P2PPeers { unsigned long long* flags[P2P_MAXG]; double* inbox[P2P_MAXG]; float* logits[P2P_MAXG]; };
+struct P2PArgs {
+  P2PPeers pr;
+  unsigned long long* epoch;   // this rank's exchange counter
+  unsigned* ticket;            // blocks finished in this launch
+  int* err;
+  int G, rank, n;              // n: elements of this exchange (d, or V_loc)
+};
+
 // ------------------------------------------------------------------------------------------------
 struct l2_ctx {
   int32_t hdr[7];
@@ -151,6 +164,15 @@ struct l2_ctx {
   std::shared_ptr<LoopGroup> loop;   // L2_TP_LOOPBACK test hook (see LoopGroup)
   double* loop_tmp = nullptr;
   bool tp_path = false;   // WO/W2 write fp64 partials + all-reduce; logits all-gathered (G > 1, or forced for tests)
+  // one-shot peer-to-peer exchange (tp_p2p_*): this rank's inbox + flags, the peers' mappings
+  bool p2p = false;
+  void* p2p_base = nullptr;          // uncached: [2][8][64] flag words, then [2][8][d] doubles
+  unsigned long long* p2p_epoch = nullptr;   // + ticket (device)
+  int* p2p_err = nullptr;            // pinned + mapped
+  int* p2p_err_dev = nullptr;
+  P2PPeers p2p_peers = {};
+  std::vector<void*> p2p_opened;     // IPC mappings to close
+  bool p2p_peers_ready = false;
 
   float* w[L2_T_COUNT] = {};
   size_t layer_elems[L2_T_COUNT] = {};  // LOCAL floats per layer (or whole tensor when unlayered)
@@ -254,6 +276,10 @@ extern "C" void l2_destroy(l2_ctx* c) {
   destroy_graphs(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   if (c->loop_tmp) hipFree(c->loop_tmp);
+  for (void* m : c->p2p_opened) hipIpcCloseMemHandle(m);
+  if (c->p2p_base) hipFree(c->p2p_base);
+  if (c->p2p_epoch) hipFree(c->p2p_epoch);
+  if (c->p2p_err) hipHostFree(c->p2p_err);
   l2s::destroy(&c->samp);
   for (int k = 0; k < L2_T_COUNT; ++k)
     if (c->w[k] && !(k == L2_T_WCLS && c->shared)) hipFree(c->w[k]);  // shared wcls aliases the embedding table
@@ -280,6 +306,9 @@ static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s && *s ? atoi(s) : dflt;
 }
+
+static int p2p_alloc(l2_ctx* c);
+static int p2p_connect_ipc(l2_ctx* c);
 
 static int create_impl(const int32_t cfg[7], int device, int rank, int G, const void* nccl_id, l2_ctx** out) {
   if (!cfg || !out) return fail(L2_E_ARG, "null argument");
@@ -338,8 +367,10 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMalloc(&c->hb, c->h_loc * 4)); CK(hipMalloc(&c->hb2, c->h_loc * 4));
   CK(hipMalloc(&c->q, dl * 4)); CK(hipMalloc(&c->k, dl * 4)); CK(hipMalloc(&c->v, dl * 4));
   CK(hipMalloc(&c->att, (size_t)c->H_loc * S * 4));
-  CK(hipMalloc(&c->logits, (size_t)V * 4));
   c->tp_path = G > 1 || env_int("L2_TP_FORCE_COMM", 0);   // the latter: 1-rank communicator, exercises the RCCL path on one GPU
+  // the gathered logits of a tensor-parallel rank are written by its peers (tp_p2p_gather_kernel): uncached memory
+  if (c->tp_path) CK(hipExtMallocWithFlags((void**)&c->logits, (size_t)V * 4, hipDeviceMallocUncached));
+  else CK(hipMalloc(&c->logits, (size_t)V * 4));
   if (c->tp_path) { CK(hipMalloc(&c->logits_loc, (size_t)c->V_loc * 4)); CK(hipMalloc(&c->partial, (size_t)d * 8)); }
   else c->logits_loc = c->logits;
   CK(hipMalloc(&c->kc, kv * 4)); CK(hipMalloc(&c->vc, kv * 4));
@@ -380,6 +411,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
 #endif
   CK(hipStreamSynchronize(c->stream));
 #undef CK
+  if (c->tp_path && !env_int("L2_TP_NO_COMM", 0)) { const int rc_ = p2p_alloc(c); if (rc_) { l2_destroy(c); return rc_; } }
   if (G > 1 && env_int("L2_TP_NO_COMM", 0)) {
     // shard-layout tests on a single GPU: the slices are real, the communicator is absent and every
     // forward on this context fails with L2_E_COMM
@@ -391,6 +423,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     if (!grp) { grp = std::make_shared<LoopGroup>(); grp->G = G; }
     if (grp->G != G) { l2_destroy(c); return fail(L2_E_ARG, "loopback group size mismatch"); }
     c->loop = grp;
+    grp->p2p_base[rank] = c->p2p_base; grp->p2p_logits[rank] = c->logits;
+    c->p2p = c->p2p_base != nullptr;          // peers resolved at the first step, once every rank has registered
   } else if (c->tp_path) {
     int rc = rccl_bind();
     if (rc) { l2_destroy(c); return rc; }
@@ -406,7 +440,10 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     fflush(stdout);
     if (saved_out >= 0) { dup2(saved_out, 1); close(saved_out); }
     if (r != 0) { l2_destroy(c); return fail(L2_E_COMM, "ncclCommInitRank failed: %d", r); }
+    rc = p2p_connect_ipc(c);
+    if (rc) { l2_destroy(c); return rc; }
   }
+  if (c->p2p && !getenv("L2_USE_GRAPH")) c->opt_graph = 1;   // nothing but kernels in the step: one hipGraph per token
   *out = c;
   return L2_OK;
 }
@@ -425,6 +462,7 @@ extern "C" int l2_tp_unique_id(void* id_out_128) {
 
 extern "C" int l2_tp_mode(l2_ctx* c) {
   if (!c || !c->tp_path) return 0;
+  if (c->p2p) return 3;
   if (c->loop) return 4;
   return c->opt_graph ? 2 : 1;
 }
@@ -827,6 +865,85 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // att
   return launch_attn_tile(c, a, a.nsplit, -1, st);
 }
 
+// ---- One-shot peer-to-peer exchange over xGMI -------------------------------------------------
+// The two all-reduces of a layer move d fp64 partials (32 KB at 7B) and the logits gather V/G floats per rank:
+// latency-bound messages, for which a ring or tree collective pays several launches and hops.  Here every rank
+// WRITES its contribution straight into a slot of every peer's inbox (peer-mapped, uncached memory), raises one
+// flag per (peer, block), waits for the G flags of its own inbox and sums the G slots IN RANK ORDER -- every rank
+// adds the same numbers in the same order, so x stays bit-identical across ranks and is rounded to fp32 once
+// (llama2.ts:201), exactly as the RCCL path and the oracle's orc_forward_tp do.  One kernel = exchange + residual;
+// nothing but kernels, so the whole tensor-parallel step is captured in one hipGraph.
+//   * epochs: a device counter per rank counts exchanges (all ranks run the same sequence); a flag holds the epoch
+//     of the exchange that last wrote its slot; slots alternate by epoch parity -- a rank cannot start exchange
+//     e + 2 before every peer has finished reading exchange e, because e + 1 needs their contribution first;
+//   * block b of every rank handles the same elements, so it only waits for block b of its peers;
+//   * release: stores, __threadfence_system(), barrier, then the flags (system-scope atomic stores); acquire:
+//     system-scope atomic polls (bounded: a rank that never arrives sets `err` instead of hanging the GPU), barrier,
+//     system fence, plain loads of the uncached inbox.
+
+__device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) { return *a.epoch + 1; }
+
+// flags of this block up on every peer, then wait for every source's flag in the local inbox
+__device__ __forceinline__ void p2p_sync(const P2PArgs& a, unsigned long long e, int tid) {
+  const int par = (int)(e & 1), b = blockIdx.x;
+  __threadfence_system();
+  __syncthreads();
+  if (tid < a.G) {
+    __hip_atomic_store(a.pr.flags[tid] + ((size_t)(par * P2P_MAXG + a.rank) * P2P_FB + b), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* mine = a.pr.flags[a.rank] + ((size_t)(par * P2P_MAXG + tid) * P2P_FB + b);
+    unsigned spins = 0;
+    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 24)) { *a.err = 1; break; }          // ~1 s: give up, the host reports it
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+}
+
+__device__ __forceinline__ void p2p_end(const P2PArgs& a, unsigned long long e, int tid) {
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) { __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *a.epoch = e; }
+  }
+}
+
+// all-reduce(sum) of the d fp64 partials + ONE fp32 rounding + residual accumulate (llama2.ts:201, 168-170)
+__global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, const double* partial, float* x, const float* res_emb,
+                                                            float* mv_out, const int* tokpos) {
+  const int tid = threadIdx.x, stride = gridDim.x * 256;
+  const unsigned long long e = p2p_begin(a);
+  const size_t slot = (size_t)((int)(e & 1) * P2P_MAXG) * a.n;
+  for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+    const double v = partial[i];
+    for (int p = 0; p < a.G; ++p) a.pr.inbox[p][slot + (size_t)a.rank * a.n + i] = v;
+  }
+  p2p_sync(a, e, tid);
+  for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+    const double* in = a.pr.inbox[a.rank] + slot + i;
+    double s = in[0];
+    for (int r = 1; r < a.G; ++r) s += in[(size_t)r * a.n];      // rank order on every rank
+    const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : x[i];
+    const float mv = (float)s;
+    x[i] = xr + mv;
+    if (mv_out) mv_out[i] = mv;
+  }
+  p2p_end(a, e, tid);
+}
+
+// all-gather of the logits slices: every rank writes its V/G floats into every peer's (uncached) logits vector
+__global__ void __launch_bounds__(256) tp_p2p_gather_kernel(const P2PArgs a, const float* mine) {
+  const int tid = threadIdx.x, stride = gridDim.x * 256;
+  const unsigned long long e = p2p_begin(a);
+  for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+    const float v = mine[i];
+    for (int p = 0; p < a.G; ++p) a.pr.logits[p][(size_t)a.rank * a.n + i] = v;
+  }
+  p2p_sync(a, e, tid);
+  p2p_end(a, e, tid);
+}
+
 __global__ void tp_residual_kernel(float* x, const float* res_emb, const double* sum, float* mv_out, const int* tokpos, int d) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d) return;
@@ -834,6 +951,99 @@ __global__ void tp_residual_kernel(float* x, const float* res_emb, const double*
   const float mv = (float)sum[i];   // ONE rounding of the all-reduced fp64 sum (llama2.ts:201)
   x[i] = xr + mv;                   // accum, llama2.ts:168-170
   if (mv_out) mv_out[i] = mv;
+}
+
+// ---- peer-to-peer exchange: setup -----------------------------------------------------------------------------
+static size_t p2p_bytes(const l2_ctx* c) { return (size_t)2 * P2P_MAXG * P2P_FB * 8 + (size_t)2 * P2P_MAXG * c->d * 8; }
+static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits) {
+  c->p2p_peers.flags[r] = (unsigned long long*)base;
+  c->p2p_peers.inbox[r] = (double*)((char*)base + (size_t)2 * P2P_MAXG * P2P_FB * 8);
+  c->p2p_peers.logits[r] = logits;
+}
+static P2PArgs p2p_args(const l2_ctx* c, int n) {
+  P2PArgs a;
+  a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = (unsigned*)(c->p2p_epoch + 1); a.err = c->p2p_err_dev;
+  a.G = c->G; a.rank = c->rank; a.n = n;
+  return a;
+}
+static int p2p_grid(int n) { const int b = (n + 255) / 256; return b > P2P_FB ? P2P_FB : (b < 1 ? 1 : b); }
+
+// Own buffers (every tensor-parallel context): inbox + flags and the gathered-logits vector are UNCACHED device
+// memory, because peers write them while this GPU's L2 knows nothing about it.
+static int p2p_alloc(l2_ctx* c) {
+  if (c->G > P2P_MAXG) return L2_OK;
+  const char* mode = getenv("L2_TP_ALLREDUCE");
+  if (mode && !strcmp(mode, "rccl")) return L2_OK;
+  if (hipExtMallocWithFlags(&c->p2p_base, p2p_bytes(c), hipDeviceMallocUncached) != hipSuccess) { c->p2p_base = nullptr; (void)hipGetLastError(); return L2_OK; }
+  HIPCHK(hipMemset(c->p2p_base, 0, p2p_bytes(c)));
+  HIPCHK(hipMalloc(&c->p2p_epoch, 16));
+  HIPCHK(hipMemset(c->p2p_epoch, 0, 16));
+  HIPCHK(hipHostMalloc(&c->p2p_err, sizeof(int), hipHostMallocMapped));
+  *c->p2p_err = 0;
+  HIPCHK(hipHostGetDevicePointer((void**)&c->p2p_err_dev, c->p2p_err, 0));
+  return L2_OK;
+}
+
+// Multi-process group: IPC handles of every rank's buffers travel through one RCCL all-gather; then ONE exchange on
+// a known vector is checked against the closed form, and the ranks agree (all-reduce of a flag) whether the
+// peer-to-peer path is used -- any rank that cannot map or complete it sends everybody back to the RCCL collectives.
+enum { NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_MIN = 3 };
+__global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { partial[i] = (double)(rank + 1) + 0.5 * (double)i; x[i] = 0.0f; }
+}
+static int p2p_connect_ipc(l2_ctx* c) {
+  if (!c->p2p_base) return L2_OK;
+  const int G = c->G;
+  struct Rec { hipIpcMemHandle_t base, logits; };
+  static_assert(sizeof(Rec) == 128, "two 64-byte IPC handles");
+  Rec mine;
+  bool ok = hipIpcGetMemHandle(&mine.base, c->p2p_base) == hipSuccess && hipIpcGetMemHandle(&mine.logits, c->logits) == hipSuccess;
+  (void)hipGetLastError();
+  Rec* d_all = nullptr;
+  std::vector<Rec> all(G);
+  HIPCHK(hipMalloc(&d_all, sizeof(Rec) * (G + 1)));
+  HIPCHK(hipMemcpy(d_all + G, &mine, sizeof(Rec), hipMemcpyHostToDevice));
+  NCCLCHK(g_rccl.AllGather(d_all + G, d_all, sizeof(Rec), NCCL_UINT8, c->comm, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(all.data(), d_all, sizeof(Rec) * G, hipMemcpyDeviceToHost));
+  for (int r = 0; r < G && ok; ++r) {
+    if (r == c->rank) { p2p_set_peer(c, r, c->p2p_base, c->logits); continue; }
+    void *pb = nullptr, *pl = nullptr;
+    if (hipIpcOpenMemHandle(&pb, all[r].base, hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
+        hipIpcOpenMemHandle(&pl, all[r].logits, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ok = false; (void)hipGetLastError(); break; }
+    c->p2p_opened.push_back(pb); c->p2p_opened.push_back(pl);
+    p2p_set_peer(c, r, pb, (float*)pl);
+  }
+  // every rank learns whether every rank mapped everything BEFORE anybody waits on a peer
+  int* d_ok = (int*)d_all;
+  int h_ok = ok ? 1 : 0;
+  HIPCHK(hipMemcpy(d_ok, &h_ok, 4, hipMemcpyHostToDevice));
+  NCCLCHK(g_rccl.AllReduce(d_ok, d_ok, 1, NCCL_INT32, NCCL_MIN, c->comm, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(&h_ok, d_ok, 4, hipMemcpyDeviceToHost));
+  if (h_ok) {   // one exchange on a known vector: sum over ranks of (rank + 1 + i / 2)
+    const int n = c->d;
+    hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n);
+    hipLaunchKernelGGL(tp_p2p_reduce_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<float> got(n);
+    HIPCHK(hipMemcpy(got.data(), c->xb2, (size_t)n * 4, hipMemcpyDeviceToHost));
+    h_ok = *c->p2p_err ? 0 : 1;
+    for (int i = 0; i < n && h_ok; ++i) if (got[i] != (float)(0.5 * G * (G + 1) + 0.5 * (double)i * G)) h_ok = 0;
+    *c->p2p_err = 0;
+    HIPCHK(hipMemset(c->xb2, 0, (size_t)n * 4));
+    HIPCHK(hipMemcpy(d_ok, &h_ok, 4, hipMemcpyHostToDevice));
+    NCCLCHK(g_rccl.AllReduce(d_ok, d_ok, 1, NCCL_INT32, NCCL_MIN, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(&h_ok, d_ok, 4, hipMemcpyDeviceToHost));
+  }
+  hipFree(d_all);
+  c->p2p = h_ok != 0;
+  c->p2p_peers_ready = true;
+  if (!c->p2p && getenv("L2_TP_ALLREDUCE") && !strcmp(getenv("L2_TP_ALLREDUCE"), "p2p"))
+    return fail(L2_E_COMM, "L2_TP_ALLREDUCE=p2p but the peer-to-peer exchange could not be set up on every rank");
+  return L2_OK;
 }
 
 #define LCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(L2_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
@@ -930,7 +1140,11 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
     LCHK(launch_attn(c, l, st));
     a = wo_args(c, l);
     LCHK(launch_phase<MODE_WO>(c, a, st));
-    if (c->tp_path) {
+    if (c->p2p) {
+      hipLaunchKernelGGL(tp_p2p_reduce_kernel, dim3(p2p_grid(c->d)), dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x,
+                         (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->xb2, c->tokpos);
+      LCHK(hipGetLastError());
+    } else if (c->tp_path) {
       { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->partial, c->xb2, c->tokpos, c->d);
       LCHK(hipGetLastError());
@@ -941,7 +1155,11 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
     if (c->probe_on && (c->probe_used & 1)) LCHK(hipEventRecord(c->probe[c->probe_used++], st));
     a = w2_args(c, l);
     LCHK(launch_phase<MODE_W2>(c, a, st));
-    if (c->tp_path) {
+    if (c->p2p) {
+      hipLaunchKernelGGL(tp_p2p_reduce_kernel, dim3(p2p_grid(c->d)), dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x,
+                         (const float*)nullptr, (float*)nullptr, c->tokpos);
+      LCHK(hipGetLastError());
+    } else if (c->tp_path) {
       { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, nullptr, c->partial, nullptr, c->tokpos, c->d);
       LCHK(hipGetLastError());
@@ -950,7 +1168,10 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
   PhaseArgs a = cls_args(c, to_host);
   if (fold_argmax) a.amax = c->amax;
   LCHK(launch_phase<MODE_CLS>(c, a, st));
-  if (c->tp_path) { const int rc_ = tp_all_gather_logits(c, st); if (rc_) return rc_; }
+  if (c->p2p) {
+    hipLaunchKernelGGL(tp_p2p_gather_kernel, dim3(p2p_grid(c->V_loc)), dim3(256), 0, st, p2p_args(c, c->V_loc), c->logits_loc);
+    LCHK(hipGetLastError());
+  } else if (c->tp_path) { const int rc_ = tp_all_gather_logits(c, st); if (rc_) return rc_; }
   return L2_OK;
 }
 
@@ -959,11 +1180,24 @@ static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forw
 
 static int ensure_ready(l2_ctx* c) {
   if (c->tp_path && !c->comm && !c->loop) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
+  if (c->loop && c->p2p && !c->p2p_peers_ready) {
+    if (!c->loop->wait()) return fail(L2_E_COMM, "loopback group: a rank never arrived");
+    for (int r = 0; r < c->G; ++r) {
+      if (!c->loop->p2p_base[r]) return fail(L2_E_COMM, "loopback group: rank %d has no peer-to-peer inbox", r);
+      p2p_set_peer(c, r, c->loop->p2p_base[r], c->loop->p2p_logits[r]);
+    }
+    c->p2p_peers_ready = true;
+  }
   for (int k = 0; k < L2_T_COUNT; ++k) {
     if (k == L2_T_WCLS && c->shared) continue;
     for (size_t l = 0; l < c->uploaded[k].size(); ++l)
       if (!c->uploaded[k][l]) return fail(L2_E_STATE, "tensor kind %d layer %zu was never uploaded", k, l);
   }
+  return L2_OK;
+}
+
+static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer wait give up?
+  if (c->p2p_err && *c->p2p_err) { *c->p2p_err = 0; return fail(L2_E_COMM, "peer-to-peer exchange: a rank never raised its flag (bounded wait gave up)"); }
   return L2_OK;
 }
 
@@ -1023,6 +1257,8 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
     HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
+  rc = check_p2p(c);
+  if (rc) return rc;
   if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
   return L2_OK;
 }
@@ -1183,7 +1419,7 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
-  return L2_OK;
+  return check_p2p(c);
 }
 
 extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps, double temperature, double topp,
@@ -1208,7 +1444,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   HIPCHK(hipMemcpyAsync(c->samp.params, params, sizeof(params), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->samp.rng, rng_state, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));                 // the host sources above are stack / caller memory
-  const bool graph = c->opt_graph && !c->loop;
+  const bool graph = c->opt_graph && (!c->loop || c->p2p);
   for (int s = 0; s < steps; ++s) {
     const int lvl = split_level(c, pos0 + s);
     c->cur_splits = splits_of(c, lvl);
@@ -1225,7 +1461,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   HIPCHK(hipMemcpyAsync(tokens_out, c->d_tokens, (size_t)steps * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->ran_forward = true;
-  return L2_OK;
+  return check_p2p(c);
 }
 
 extern "C" int l2_debug_running_sums(int device, const float* values, size_t n, double* sums_out) {

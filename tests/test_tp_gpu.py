@@ -51,16 +51,20 @@ def test_rank_slices_match_plan(G):
         del os.environ["L2_TP_NO_COMM"]
 
 
-def test_rccl_path_with_a_one_rank_communicator():
-    """L2_TP_FORCE_COMM=1: a 1-rank RCCL communicator drives the tensor-parallel code path (fp64 partials,
-    ncclAllReduce(double, sum), residual kernel, ncclAllGather of the logits) on a single GPU.  Results must
-    match the goldens of the TRUE reference like the ordinary path does."""
+@pytest.mark.parametrize("collective", ["rccl", "p2p"])
+def test_one_rank_communicator(collective):
+    """L2_TP_FORCE_COMM=1: a 1-rank RCCL communicator drives the tensor-parallel code path on a single GPU --
+    `rccl`: fp64 partials, ncclAllReduce(double, sum), residual kernel, ncclAllGather of the logits, eager launches;
+    `p2p`: IPC handles through ncclAllGather, the self-test, then the one-shot exchange kernels inside one captured
+    graph per token.  Results must match the goldens of the TRUE reference like the ordinary path does."""
     import json
     meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tiny.json")))
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny.npz"))
     os.environ["L2_TP_FORCE_COMM"] = "1"
+    os.environ["L2_TP_ALLREDUCE"] = collective
     try:
         ctx = runtime.Context(meta["header"])
+        assert ctx.tp_mode().startswith("one hipGraph per token, one-shot peer-to-peer" if collective == "p2p" else "eager launches")
         ctx.synth_fill(meta["seed"])
         for pos, tok in enumerate(meta["tokens_fed"][:24]):
             got = np.array(ctx.forward(tok, pos), copy=True)
@@ -71,9 +75,10 @@ def test_rccl_path_with_a_one_rank_communicator():
         ctx.close()
     finally:
         del os.environ["L2_TP_FORCE_COMM"]
+        del os.environ["L2_TP_ALLREDUCE"]
 
 
-def _run_group(name, G, n_forward, n_greedy, exact=False):
+def _run_group(name, G, n_forward, n_greedy, exact=False, collective="p2p"):
     """G ranks of one tensor-parallel group as G host threads on one device (L2_TP_LOOPBACK test hook in
     llama2_hip.hip: the collectives become device sums/copies between thread barriers; everything else is the
     code the RCCL path runs).  Returns per-rank (logits[n_forward][V], greedy tokens)."""
@@ -98,6 +103,7 @@ def _run_group(name, G, n_forward, n_greedy, exact=False):
             errs[r] = e
 
     os.environ["L2_TP_LOOPBACK"] = "1"
+    os.environ["L2_TP_ALLREDUCE"] = collective   # p2p: the exchange kernels; rccl: host-side stand-ins of the two collectives
     try:
         threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
         for t in threads:
@@ -107,19 +113,25 @@ def _run_group(name, G, n_forward, n_greedy, exact=False):
         assert not any(t.is_alive() for t in threads), "a rank hung"
     finally:
         del os.environ["L2_TP_LOOPBACK"]
+        del os.environ["L2_TP_ALLREDUCE"]
     for e in errs:
         if e is not None:
             raise e
     return meta, out
 
 
+@pytest.mark.parametrize("collective", ["p2p", "rccl"])
 @pytest.mark.parametrize("name,G,steps", [("tiny", 2, 24), ("tiny", 4, 24), ("stories15M", 2, 16),
                                           ("llama2_7b_L2", 4, 6), ("llama2_7b_L2", 8, 6)])
-def test_tensor_parallel_group_matches_reference(name, G, steps):
+def test_tensor_parallel_group_matches_reference(name, G, steps, collective):
     """The whole tensor-parallel step with G > 1 ranks -- row / column slices, fp64 partials of wo and w2 summed
     across ranks and rounded once, logits gathered, greedy loop on the gathered logits -- against the goldens of
-    the TRUE reference.  Every rank must hold the same full logits."""
-    meta, out = _run_group(name, G, steps, steps)
+    the TRUE reference.  Every rank must hold the same full logits.  `p2p`: the one-shot peer-to-peer exchange
+    kernels (the ranks' inboxes are ordinary device pointers here, peer-mapped over xGMI on a real node), one
+    captured graph per token; `rccl`: the loopback stand-ins of ncclAllReduce / ncclAllGather between host barriers."""
+    if collective == "p2p" and G > 4:
+        pytest.skip("eight ranks' exchange kernels wait for each other and need eight hardware queues: one GPU serialises them (real nodes: one GPU per rank)")
+    meta, out = _run_group(name, G, steps, steps, collective=collective)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     for r in range(G):
         logits, toks = out[r]
@@ -168,3 +180,54 @@ def test_tensor_parallel_group_samples_like_a_single_rank():
             raise e
     for r in range(G):
         assert out[r][0].tolist() == want.tolist() and out[r][1] == want_rng
+
+
+def test_two_gpu_group_over_rccl_and_xgmi(tmp_path):
+    """The real thing, on a box with at least two GPUs (skipped on the 1-GPU development boxes): two PROCESSES, one
+    per GPU, started fresh (nothing in this process's GPU state is inherited), rendezvous over gloo on 127.0.0.1,
+    l2_create_tp with a real ncclUniqueId; each rank checks its logits against the goldens of the TRUE reference for
+    both collectives (RCCL, and the peer-to-peer exchange over IPC-mapped inboxes)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch, torch.distributed as dist
+from llama2_ts_amd import runtime
+import ctypes as C
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+meta = json.load(open(os.path.join(%r, "tests", "golden", "llama2_7b_L2.json")))
+g = np.load(os.path.join(%r, "tests", "golden", "llama2_7b_L2.npz"))
+idbuf = torch.zeros(128, dtype=torch.uint8)
+if rank == 0:
+    b = C.create_string_buffer(128)
+    runtime._check(runtime.lib().l2_tp_unique_id(b))
+    idbuf = torch.frombuffer(bytearray(b.raw), dtype=torch.uint8).clone()
+dist.broadcast(idbuf, 0)
+ctx = runtime.Context(meta["header"], device=int(os.environ["LOCAL_RANK"]), tp_rank=rank, tp_size=world, nccl_id=bytes(idbuf.numpy().tobytes()))
+print("rank", rank, "mode:", ctx.tp_mode(), flush=True)
+ctx.synth_fill(meta["seed"])
+keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+for pos, tok in enumerate(meta["tokens_fed"][:66]):
+    lg = ctx.forward(tok, pos)
+    assert runtime.argmax(lg) == meta["argmax"][pos], (rank, pos)
+    if pos in keep:
+        assert np.abs(lg - g["logits"][keep[pos]]).max() <= 1e-4, (rank, pos)
+assert ctx.decode_greedy(1, 0, 66).tolist() == meta["argmax"][:66]
+ctx.close()
+dist.barrier()
+''' % (root, root, root, root))
+    for collective in ("rccl", "p2p"):
+        env = dict(os.environ, L2_TP_ALLREDUCE=collective, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29517", str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        out = r.stdout.decode("utf8", "replace")
+        assert r.returncode == 0, out[-3000:]
+        assert ("peer-to-peer" in out) == (collective == "p2p"), out[-2000:]
