@@ -988,9 +988,9 @@ static int p2p_alloc(l2_ctx* c) {
 // a known vector is checked against the closed form, and the ranks agree (all-reduce of a flag) whether the
 // peer-to-peer path is used -- any rank that cannot map or complete it sends everybody back to the RCCL collectives.
 enum { NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_MIN = 3 };
-__global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n) {
+__global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { partial[i] = (double)(rank + 1) + 0.5 * (double)i; x[i] = 0.0f; }
+  if (i < n) { partial[i] = (double)((rank + 1) * (k + 1)) + 0.5 * (double)i; x[i] = 0.0f; }
 }
 static int p2p_connect_ipc(l2_ctx* c) {
   if (!c->p2p_base) return L2_OK;
@@ -1022,15 +1022,17 @@ static int p2p_connect_ipc(l2_ctx* c) {
   NCCLCHK(g_rccl.AllReduce(d_ok, d_ok, 1, NCCL_INT32, NCCL_MIN, c->comm, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(&h_ok, d_ok, 4, hipMemcpyDeviceToHost));
-  if (h_ok) {   // one exchange on a known vector: sum over ranks of (rank + 1 + i / 2)
+  if (h_ok) {   // four exchanges (each inbox slot is reused once) on known vectors: sum over ranks of ((rank + 1)(k + 1) + i / 2)
     const int n = c->d;
-    hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n);
-    hipLaunchKernelGGL(tp_p2p_reduce_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
-    HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<float> got(n);
-    HIPCHK(hipMemcpy(got.data(), c->xb2, (size_t)n * 4, hipMemcpyDeviceToHost));
-    h_ok = *c->p2p_err ? 0 : 1;
-    for (int i = 0; i < n && h_ok; ++i) if (got[i] != (float)(0.5 * G * (G + 1) + 0.5 * (double)i * G)) h_ok = 0;
+    for (int k = 0; k < 4 && h_ok; ++k) {
+      hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
+      hipLaunchKernelGGL(tp_p2p_reduce_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipMemcpy(got.data(), c->xb2, (size_t)n * 4, hipMemcpyDeviceToHost));
+      if (*c->p2p_err) h_ok = 0;
+      for (int i = 0; i < n && h_ok; ++i) if (got[i] != (float)(0.5 * G * (G + 1) * (k + 1) + 0.5 * (double)i * G)) h_ok = 0;
+    }
     *c->p2p_err = 0;
     HIPCHK(hipMemset(c->xb2, 0, (size_t)n * 4));
     HIPCHK(hipMemcpy(d_ok, &h_ok, 4, hipMemcpyHostToDevice));
