@@ -64,8 +64,9 @@ enum {
   L2_OPT_EXACT_ATTENTION = 1, /* 1: value-accumulate rounds to fp32 at every timestep in t order, exactly as
                                  llama2.ts:260-265 does (bit-faithful, slower); 0 (default): fp64 partial sums */
   L2_OPT_USE_GRAPH = 2,       /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
-  L2_OPT_KEEP_ATT = 3         /* 1: RunState.att (the softmax rows, llama2.ts:158) is written out for l2_read_state(L2_S_ATT);
-                                 0 (default): it stays on chip -- nothing outside transformer() reads it (llama2.ts:244-265) */
+  L2_OPT_KEEP_STATE = 3       /* 1: the RunState fields that only transformer() itself reads (llama2.ts:131-146: att, k, v, hb2, xb2,
+                                 the xb of the FFN half, the final-normed x) are also written out for l2_read_state (parity
+                                 tests); 0 (default): they stay on chip -- q, xb, hb, logits and the KV caches are always there */
 };
 
 typedef struct l2_ctx l2_ctx;
@@ -151,7 +152,8 @@ int l2_debug_running_sums(int device, const float* values, size_t n, double* sum
 int l2_prefill(l2_ctx* ctx, const int32_t* tokens, int n_tokens, int pos0, float* logits_out);
 
 /* Copy a RunState buffer to the host (parity tests).  For per-layer caches `layer` selects the
- * [S][d] slab (-1: all layers).  After a forward, X holds the final-normed x as in llama2.ts:299. */
+ * [S][d] slab (-1: all layers).  After a forward, X holds the final-normed x as in llama2.ts:299.
+ * X, XB2, HB2, K, V and ATT need L2_OPT_KEEP_STATE (set before the forward), else L2_E_STATE. */
 int l2_read_state(l2_ctx* ctx, int which, int layer, float* out, size_t n_floats);
 
 int l2_set_option(l2_ctx* ctx, int key, int value);

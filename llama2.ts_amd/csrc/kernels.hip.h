@@ -504,7 +504,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
       o.z = (float)((double)wv.z * (ss * (double)xv.z));
       o.w = (float)((double)wv.w * (ss * (double)xv.w));
       xs4[c] = o;
-      if (MODE == MODE_CLS && vblock == 0) reinterpret_cast<f4*>(a.aux)[c] = o;  // rmsnorm(x, x, ...) in place, llama2.ts:299
+      if (MODE == MODE_CLS && vblock == 0 && a.aux) reinterpret_cast<f4*>(a.aux)[c] = o;  // rmsnorm(x, x, ...) in place, llama2.ts:299
     }
   }
   __syncthreads();
@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(512) phase_small_kernel(const PhaseArgs a) {
         o.z = (float)((double)wr[u].z * (ss * (double)xr[u].z));
         o.w = (float)((double)wr[u].w * (ss * (double)xr[u].w));
         xs4[u * 64 + lane] = o;
-        if (MODE == MODE_CLS && blockIdx.x == 0 && u * 64 + lane < n4) reinterpret_cast<f4*>(a.aux)[u * 64 + lane] = o;   // llama2.ts:299
+        if (MODE == MODE_CLS && blockIdx.x == 0 && a.aux && u * 64 + lane < n4) reinterpret_cast<f4*>(a.aux)[u * 64 + lane] = o;   // llama2.ts:299
         if (u == 0) STAMP(8);
       }
       STAMP(9);
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
     for (int j = tid; j < n; j += nthreads) {
       const float o = (float)((double)a.rmsw[j] * (ss * (double)src[j]));
       xs[j] = o;
-      if (MODE == MODE_CLS && blockIdx.x == 0) a.aux[j] = o;
+      if (MODE == MODE_CLS && blockIdx.x == 0 && a.aux) a.aux[j] = o;
     }
   } else {
     for (int j = tid; j < n; j += nthreads) xs[j] = src[j];

@@ -208,7 +208,7 @@ struct l2_ctx {
   unsigned long long* dbg = nullptr;  // L2_STAMPS builds
 
   hipGraphExec_t g_step[NLEV] = {}, g_greedy[NLEV] = {};   // one captured graph per attention split level
-  int opt_exact = 0, opt_graph = 1, opt_keep_att = 0;
+  int opt_exact = 0, opt_graph = 1, opt_keep_state = 0;
   int next_pos = 0;
   bool ran_forward = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -443,7 +443,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     rc = p2p_connect_ipc(c);
     if (rc) { l2_destroy(c); return rc; }
   }
-  if (c->p2p && !getenv("L2_USE_GRAPH")) c->opt_graph = 1;   // nothing but kernels in the step: one hipGraph per token
+  if (c->p2p && !c->loop && !getenv("L2_USE_GRAPH")) c->opt_graph = 1;   // nothing but kernels in the step: one hipGraph per token
+  if (c->loop) c->opt_graph = 0;                                          // host barriers between the halves of an exchange
   *out = c;
   return L2_OK;
 }
@@ -462,8 +463,8 @@ extern "C" int l2_tp_unique_id(void* id_out_128) {
 
 extern "C" int l2_tp_mode(l2_ctx* c) {
   if (!c || !c->tp_path) return 0;
-  if (c->p2p) return 3;
   if (c->loop) return 4;
+  if (c->p2p) return 3;
   return c->opt_graph ? 2 : 1;
 }
 
@@ -813,7 +814,7 @@ static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4
 static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
   const size_t loff = (size_t)l * c->S * c->d_loc;
   memset(&a, 0, sizeof(a));
-  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->opt_keep_att ? c->att : nullptr; a.xb = c->xb;
+  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->opt_keep_state ? c->att : nullptr; a.xb = c->xb;
   a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter;
   a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
   a.exact = c->opt_exact;
@@ -883,13 +884,17 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // att
 
 __device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) { return *a.epoch + 1; }
 
-// flags of this block up on every peer, then wait for every source's flag in the local inbox
-__device__ __forceinline__ void p2p_sync(const P2PArgs& a, unsigned long long e, int tid) {
+// flags of this block up on every peer ...
+__device__ __forceinline__ void p2p_raise(const P2PArgs& a, unsigned long long e, int tid) {
   const int par = (int)(e & 1), b = blockIdx.x;
   __threadfence_system();
   __syncthreads();
+  if (tid < a.G) __hip_atomic_store(a.pr.flags[tid] + ((size_t)(par * P2P_MAXG + a.rank) * P2P_FB + b), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... then wait for every source's flag in the local inbox
+__device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e, int tid) {
+  const int par = (int)(e & 1), b = blockIdx.x;
   if (tid < a.G) {
-    __hip_atomic_store(a.pr.flags[tid] + ((size_t)(par * P2P_MAXG + a.rank) * P2P_FB + b), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* mine = a.pr.flags[a.rank] + ((size_t)(par * P2P_MAXG + tid) * P2P_FB + b);
     unsigned spins = 0;
     while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
@@ -909,17 +914,26 @@ __device__ __forceinline__ void p2p_end(const P2PArgs& a, unsigned long long e, 
   }
 }
 
+// PART 0: the whole exchange in one kernel (product path).  PART 1 / 2: its two halves -- contribute, then wait + combine
+// -- as separate launches with a host barrier in between: the loopback test group runs all ranks on ONE GPU, where
+// G kernels that wait for each other are not guaranteed to be resident together (they deadlock until the bounded
+// wait gives up when two ranks' streams share a hardware queue); on a node every rank has its own GPU.
 // all-reduce(sum) of the d fp64 partials + ONE fp32 rounding + residual accumulate (llama2.ts:201, 168-170)
+template <int PART>
 __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, const double* partial, float* x, const float* res_emb,
                                                             float* mv_out, const int* tokpos) {
   const int tid = threadIdx.x, stride = gridDim.x * 256;
   const unsigned long long e = p2p_begin(a);
   const size_t slot = (size_t)((int)(e & 1) * P2P_MAXG) * a.n;
-  for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
-    const double v = partial[i];
-    for (int p = 0; p < a.G; ++p) a.pr.inbox[p][slot + (size_t)a.rank * a.n + i] = v;
+  if (PART != 2) {
+    for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+      const double v = partial[i];
+      for (int p = 0; p < a.G; ++p) a.pr.inbox[p][slot + (size_t)a.rank * a.n + i] = v;
+    }
   }
-  p2p_sync(a, e, tid);
+  if (PART == 1) { p2p_raise(a, e, tid); return; }
+  if (PART == 0) p2p_raise(a, e, tid);
+  p2p_wait(a, e, tid);
   for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
     const double* in = a.pr.inbox[a.rank] + slot + i;
     double s = in[0];
@@ -933,14 +947,19 @@ __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, con
 }
 
 // all-gather of the logits slices: every rank writes its V/G floats into every peer's (uncached) logits vector
+template <int PART>
 __global__ void __launch_bounds__(256) tp_p2p_gather_kernel(const P2PArgs a, const float* mine) {
   const int tid = threadIdx.x, stride = gridDim.x * 256;
   const unsigned long long e = p2p_begin(a);
-  for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
-    const float v = mine[i];
-    for (int p = 0; p < a.G; ++p) a.pr.logits[p][(size_t)a.rank * a.n + i] = v;
+  if (PART != 2) {
+    for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+      const float v = mine[i];
+      for (int p = 0; p < a.G; ++p) a.pr.logits[p][(size_t)a.rank * a.n + i] = v;
+    }
   }
-  p2p_sync(a, e, tid);
+  if (PART == 1) { p2p_raise(a, e, tid); return; }
+  if (PART == 0) p2p_raise(a, e, tid);
+  p2p_wait(a, e, tid);
   p2p_end(a, e, tid);
 }
 
@@ -1027,7 +1046,7 @@ static int p2p_connect_ipc(l2_ctx* c) {
     std::vector<float> got(n);
     for (int k = 0; k < 4 && h_ok; ++k) {
       hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
-      hipLaunchKernelGGL(tp_p2p_reduce_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
+      hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
       HIPCHK(hipStreamSynchronize(c->stream));
       HIPCHK(hipMemcpy(got.data(), c->xb2, (size_t)n * 4, hipMemcpyDeviceToHost));
       if (*c->p2p_err) h_ok = 0;
@@ -1067,14 +1086,15 @@ static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs +
   a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
   a.in = c->x; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr;
   a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * l;
-  a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff; a.aux = c->k; a.aux2 = c->v;
+  a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff;
+  if (c->opt_keep_state) { a.aux = c->k; a.aux2 = c->v; }     // RunState.k / v: the cache rows are what attention reads
   a.n = c->d; a.rows = 3 * c->d_loc; a.dim = c->d_loc;
   return a;
 }
 static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (llama2.ts:270-273)
   PhaseArgs a = base_args(c);
   a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l;
-  a.in = c->xb; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; a.res = c->x; a.out = c->x; a.aux = c->xb2;
+  a.in = c->xb; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; a.res = c->x; a.out = c->x; a.aux = c->opt_keep_state ? c->xb2 : nullptr;
   a.n = c->d_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
   return a;
@@ -1084,14 +1104,14 @@ static PhaseArgs w13_args(const l2_ctx* c, int l) {   // rmsnorm + w1,w3 GEMVs +
   a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l;
   a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
   a.in = c->x; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * l;
-  a.out = c->hb; a.aux = c->hb2;
+  a.out = c->hb; a.aux = c->opt_keep_state ? c->hb2 : nullptr;
   a.n = c->d; a.rows = c->h_loc;
   return a;
 }
 static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (llama2.ts:292-295)
   PhaseArgs a = base_args(c);
   a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l;
-  a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = c->tp_path ? nullptr : c->xb;
+  a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = (c->tp_path || !c->opt_keep_state) ? nullptr : c->xb;
   a.n = c->h_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
   return a;
@@ -1099,7 +1119,7 @@ static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (lla
 static PhaseArgs cls_args(const l2_ctx* c, bool to_host) {   // final rmsnorm + classifier (llama2.ts:299-302)
   PhaseArgs a = base_args(c);
   a.w0 = c->w[L2_T_WCLS];
-  a.in = c->x; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xn;
+  a.in = c->x; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->opt_keep_state ? c->xn : nullptr;
   a.aux2 = (to_host && c->opt_zero_copy && !c->tp_path) ? c->h_logits_dev : nullptr;
   a.n = c->d; a.rows = c->V_loc;
   return a;
@@ -1135,6 +1155,22 @@ static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
   return L2_OK;
 }
 
+// one all-reduce + residual of the tensor-parallel step: ONE kernel; the loopback test group (all ranks on one GPU)
+// runs its two halves around a host barrier instead (see tp_p2p_reduce_kernel)
+static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out) {
+  const dim3 grid(p2p_grid(c->d));
+  if (!c->loop) {
+    hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
+  } else {
+    hipLaunchKernelGGL(tp_p2p_reduce_kernel<1>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
+    HIPCHK(hipStreamSynchronize(st));
+    if (!c->loop->wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");
+    hipLaunchKernelGGL(tp_p2p_reduce_kernel<2>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
+  }
+  LCHK(hipGetLastError());
+  return L2_OK;
+}
+
 static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fold_argmax = false) {
   for (int l = 0; l < c->L; ++l) {
     PhaseArgs a = qkv_args(c, l);
@@ -1143,12 +1179,11 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
     a = wo_args(c, l);
     LCHK(launch_phase<MODE_WO>(c, a, st));
     if (c->p2p) {
-      hipLaunchKernelGGL(tp_p2p_reduce_kernel, dim3(p2p_grid(c->d)), dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x,
-                         (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->xb2, c->tokpos);
-      LCHK(hipGetLastError());
+      const int rc_ = p2p_reduce(c, st, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->opt_keep_state ? c->xb2 : nullptr);
+      if (rc_) return rc_;
     } else if (c->tp_path) {
       { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
-      hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->partial, c->xb2, c->tokpos, c->d);
+      hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->partial, c->opt_keep_state ? c->xb2 : nullptr, c->tokpos, c->d);
       LCHK(hipGetLastError());
     }
     a = w13_args(c, l);
@@ -1158,9 +1193,8 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
     a = w2_args(c, l);
     LCHK(launch_phase<MODE_W2>(c, a, st));
     if (c->p2p) {
-      hipLaunchKernelGGL(tp_p2p_reduce_kernel, dim3(p2p_grid(c->d)), dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x,
-                         (const float*)nullptr, (float*)nullptr, c->tokpos);
-      LCHK(hipGetLastError());
+      const int rc_ = p2p_reduce(c, st, nullptr, nullptr);
+      if (rc_) return rc_;
     } else if (c->tp_path) {
       { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
       hipLaunchKernelGGL(tp_residual_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->x, nullptr, c->partial, nullptr, c->tokpos, c->d);
@@ -1171,7 +1205,14 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
   if (fold_argmax) a.amax = c->amax;
   LCHK(launch_phase<MODE_CLS>(c, a, st));
   if (c->p2p) {
-    hipLaunchKernelGGL(tp_p2p_gather_kernel, dim3(p2p_grid(c->V_loc)), dim3(256), 0, st, p2p_args(c, c->V_loc), c->logits_loc);
+    const dim3 grid(p2p_grid(c->V_loc));
+    if (!c->loop) hipLaunchKernelGGL(tp_p2p_gather_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->V_loc), c->logits_loc);
+    else {
+      hipLaunchKernelGGL(tp_p2p_gather_kernel<1>, grid, dim3(256), 0, st, p2p_args(c, c->V_loc), c->logits_loc);
+      HIPCHK(hipStreamSynchronize(st));
+      if (!c->loop->wait()) return fail(L2_E_COMM, "loopback gather: a rank never arrived");
+      hipLaunchKernelGGL(tp_p2p_gather_kernel<2>, grid, dim3(256), 0, st, p2p_args(c, c->V_loc), c->logits_loc);
+    }
     LCHK(hipGetLastError());
   } else if (c->tp_path) { const int rc_ = tp_all_gather_logits(c, st); if (rc_) return rc_; }
   return L2_OK;
@@ -1446,7 +1487,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   HIPCHK(hipMemcpyAsync(c->samp.params, params, sizeof(params), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->samp.rng, rng_state, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));                 // the host sources above are stack / caller memory
-  const bool graph = c->opt_graph && (!c->loop || c->p2p);
+  const bool graph = c->opt_graph && !c->loop;
   for (int s = 0; s < steps; ++s) {
     const int lvl = split_level(c, pos0 + s);
     c->cur_splits = splits_of(c, lvl);
@@ -1526,8 +1567,10 @@ extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t
   const float* src = nullptr;
   size_t n = 0;
   const size_t slab = (size_t)c->S * c->d_loc;
+  if (!c->opt_keep_state && ((which == L2_S_X && c->ran_forward) || which == L2_S_XB2 || which == L2_S_HB2 || which == L2_S_K || which == L2_S_V || which == L2_S_ATT))
+    return fail(L2_E_STATE, "this RunState field is only read by transformer() itself and stays on chip: set L2_OPT_KEEP_STATE before the forward");
   switch (which) {
-    case L2_S_X: src = c->ran_forward ? c->xn : c->x; n = c->d; break;
+    case L2_S_X: src = c->ran_forward ? c->xn : c->x; n = c->d; break;   // after a forward: the final-normed x (kept state)
     case L2_S_XB: src = c->xb; n = c->d_loc; break;
     case L2_S_XB2: src = c->xb2; n = c->d; break;
     case L2_S_HB: src = c->hb; n = c->h_loc; break;
@@ -1535,9 +1578,7 @@ extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t
     case L2_S_Q: src = c->q; n = c->d_loc; break;
     case L2_S_K: src = c->k; n = c->d_loc; break;
     case L2_S_V: src = c->v; n = c->d_loc; break;
-    case L2_S_ATT:
-      if (!c->opt_keep_att) return fail(L2_E_STATE, "RunState.att is not kept: set L2_OPT_KEEP_ATT before the forward");
-      src = c->att; n = (size_t)c->H_loc * c->S; break;
+    case L2_S_ATT: src = c->att; n = (size_t)c->H_loc * c->S; break;
     case L2_S_LOGITS: src = c->logits; n = c->V; break;
     case L2_S_KEY_CACHE: case L2_S_VALUE_CACHE: {
       const float* base = which == L2_S_KEY_CACHE ? c->kc : c->vc;
@@ -1563,7 +1604,7 @@ extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
       }
       return L2_OK;
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
-    case L2_OPT_KEEP_ATT: if (c->opt_keep_att != !!value) { c->opt_keep_att = !!value; destroy_graphs(c); } return L2_OK;
+    case L2_OPT_KEEP_STATE: if (c->opt_keep_state != !!value) { c->opt_keep_state = !!value; destroy_graphs(c); } return L2_OK;
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }
@@ -1573,7 +1614,7 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
   switch (key) {
     case L2_OPT_EXACT_ATTENTION: *value = c->opt_exact; return L2_OK;
     case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
-    case L2_OPT_KEEP_ATT: *value = c->opt_keep_att; return L2_OK;
+    case L2_OPT_KEEP_STATE: *value = c->opt_keep_state; return L2_OK;
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }

@@ -9,11 +9,6 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-# the loopback tensor-parallel groups run up to 8 ranks' kernels side by side on one GPU, and a rank's exchange kernel
-# waits for its peers': every rank's stream needs a hardware queue of its own (the runtime's default is 4)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: larger CPU cases (still part of the default CPU suite)")

@@ -54,7 +54,7 @@ def test_forward_matches_reference_goldens(built, name, exact):
     ctx = runtime.Context(meta["header"])
     upload_from_oracle(ctx, orc)
     ctx.set_option(runtime.OPT_EXACT_ATTENTION, exact)
-    ctx.set_option(runtime.OPT_KEEP_ATT, 1)
+    ctx.set_option(runtime.OPT_KEEP_STATE, 1)
     keep = {p: i for i, p in enumerate(meta["logit_positions"])}
     worst, biteq, total = 0.0, 0, 0
     for pos, tok in enumerate(meta["tokens_fed"]):
@@ -193,7 +193,7 @@ def test_long_context_full_sequence(built):
     hdr = configs.header("stories110M")
     ctx = runtime.Context(hdr)
     ctx.synth_fill(3)
-    ctx.set_option(runtime.OPT_KEEP_ATT, 1)
+    ctx.set_option(runtime.OPT_KEEP_STATE, 1)
     S = ctx.cfg.seq_len
     toks = ctx.decode_greedy(1, 0, S)
     assert toks.min() >= 0 and toks.max() < ctx.cfg.vocab_size
@@ -220,7 +220,7 @@ def test_split_attention_matches_reference(built, name, splits):
     finally:
         del os.environ["L2_ATTN_SPLITS"]
     ctx.synth_fill(meta["seed"])
-    ctx.set_option(runtime.OPT_KEEP_ATT, 1)
+    ctx.set_option(runtime.OPT_KEEP_STATE, 1)
     keep = {p: i for i, p in enumerate(meta["logit_positions"])}
     for pos, tok in enumerate(meta["tokens_fed"]):
         got = np.array(ctx.forward(tok, pos), copy=True)
@@ -285,7 +285,7 @@ def test_full_size_7b_properties(built):
     hdr = configs.header("llama2_7b")
     ctx = runtime.Context(hdr)
     ctx.synth_fill(11)
-    ctx.set_option(runtime.OPT_KEEP_ATT, 1)
+    ctx.set_option(runtime.OPT_KEEP_STATE, 1)
     a = [np.array(ctx.forward(t, p), copy=True) for p, t in enumerate([1, 5, 9])]
     ctx.set_option(runtime.OPT_USE_GRAPH, 0)
     b = [np.array(ctx.forward(t, p), copy=True) for p, t in enumerate([1, 5, 9])]

@@ -127,10 +127,10 @@ def test_tensor_parallel_group_matches_reference(name, G, steps, collective):
     """The whole tensor-parallel step with G > 1 ranks -- row / column slices, fp64 partials of wo and w2 summed
     across ranks and rounded once, logits gathered, greedy loop on the gathered logits -- against the goldens of
     the TRUE reference.  Every rank must hold the same full logits.  `p2p`: the one-shot peer-to-peer exchange
-    kernels (the ranks' inboxes are ordinary device pointers here, peer-mapped over xGMI on a real node), one
-    captured graph per token; `rccl`: the loopback stand-ins of ncclAllReduce / ncclAllGather between host barriers."""
-    if collective == "p2p" and G > 4:
-        pytest.skip("eight ranks' exchange kernels wait for each other and need eight hardware queues: one GPU serialises them (real nodes: one GPU per rank)")
+    kernels (the ranks' inboxes are ordinary device pointers here, peer-mapped over xGMI on a real node; with all
+    ranks on one GPU the contribute and combine halves of an exchange are two launches around a host barrier --
+    kernels that wait for each other need one GPU per rank -- the single-kernel form runs in test_one_rank_communicator
+    and test_two_gpu_group_over_rccl_and_xgmi); `rccl`: the loopback stand-ins of ncclAllReduce / ncclAllGather between host barriers."""
     meta, out = _run_group(name, G, steps, steps, collective=collective)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     for r in range(G):

@@ -1,0 +1,119 @@
+// Floor of ONE dependent GEMV phase of a small model, step by step.
+//
+// A token of stories110M is 61 dependent launches (5 per layer + classifier); each phase is
+//   [1] the launch boundary -> [2] x arrives (written by the previous launch) -> [3] rmsnorm: sum(x^2), scale, publish
+//   -> [4] the weights arrive from HBM -> [5] fp64 FMAs -> [6] wave reduction + epilogue + store (seen by the next launch).
+// This program replays a chain of 200 launches of a stripped phase kernel inside one hipGraph (each launch reads the
+// vector the previous one wrote, exactly as the model does) and adds the steps one at a time, for the weight sizes of
+// the stories110M phases.  us per launch; the differences are the floors of the steps.  No model code is involved:
+// one wave per output row pair, 16-byte non-temporal loads, x staged by wave 0, DPP reductions, fp64 accumulate.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mbp tools/microbench_phase.hip && /tmp/mbp
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, RM, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, CTRL, RM, 0xf, false));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp<0xB1, 0xf>(v); v += dpp<0x4E, 0xf>(v); v += dpp<0x141, 0xf>(v); v += dpp<0x140, 0xf>(v);
+  v += dpp<0x142, 0xa>(v); v += dpp<0x143, 0xc>(v);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// STEPS: 1 empty | 2 + x in, one value out | 3 + norm published through LDS | 4 + weight stream consumed | 5 + reduction and row stores
+template <int STEPS>
+__global__ void __launch_bounds__(512) phase(const float* w, const float* xin, float* xout, int n, int rows) {
+  if (STEPS < 2) return;
+  __shared__ f4 xs[192];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n4 = n / 4;
+  // seven compute waves request their two rows first, the x wave requests x (the model's latency-form kernel)
+  f4 a[2][3];
+  const int g = (wave - 1) * gridDim.x + blockIdx.x, groups = rows / 2;
+  if (STEPS >= 4 && wave > 0 && g < groups) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int u = 0; u < 3; ++u) a[r][u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(w + (size_t)(2 * g + r) * n) + min(u * 64 + lane, n4 - 1));
+  }
+  if (wave == 0) {
+    f4 x[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) x[u] = reinterpret_cast<const f4*>(xin)[min(u * 64 + lane, n4 - 1)];
+    if (STEPS >= 3) {
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) s += (double)x[u].x * x[u].x + (double)x[u].y * x[u].y + (double)x[u].z * x[u].z + (double)x[u].w * x[u].w;
+      s = wave_sum(s);
+      const double y = 1e-5 + s / n;
+      double rs = __builtin_amdgcn_rsq(y);
+      rs = fma(rs, fma(-0.5 * y * rs, rs, 0.5), rs);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        f4 o = {(float)(rs * x[u].x), (float)(rs * x[u].y), (float)(rs * x[u].z), (float)(rs * x[u].w)};
+        xs[u * 64 + lane] = o;
+      }
+    } else if (lane == 0 && blockIdx.x == 0) {
+      xout[0] = x[0].x + 1.0f;
+    }
+  }
+  if (STEPS < 3) return;
+  __syncthreads();
+  if (wave == 0 || g >= groups) { if (STEPS == 3 && tid == 0 && blockIdx.x == 0) xout[0] = xs[0].x; return; }
+  if (STEPS == 3) return;
+  double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const f4 x = xs[u * 64 + lane];
+    acc0 += (double)a[0][u].x * x.x + (double)a[0][u].y * x.y + (double)a[0][u].z * x.z + (double)a[0][u].w * x.w;
+    acc1 += (double)a[1][u].x * x.x + (double)a[1][u].y * x.y + (double)a[1][u].z * x.z + (double)a[1][u].w * x.w;
+  }
+  if (STEPS == 4) { if (acc0 + acc1 == 12345.678) xout[0] = 1.0f; return; }   // consumed, nothing reduced or stored
+  acc0 = wave_sum(acc0); acc1 = wave_sum(acc1);
+  if (lane < 2 && 2 * g + lane < n) xout[2 * g + lane] = (float)(lane ? acc1 : acc0) * 1e-3f;
+}
+
+template <int STEPS>
+static float chain(const float* w, float* xa, float* xb, int n, int rows) {
+  hipStream_t st; (void)hipStreamCreate(&st);
+  hipGraph_t g; hipGraphExec_t ge;
+  const int groups = rows / 2, grid = groups / 7 + 1 > 256 ? 256 : groups / 7 + 1, nk = 200;
+  (void)hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  for (int i = 0; i < nk; ++i) hipLaunchKernelGGL(phase<STEPS>, dim3(grid), dim3(512), 0, st, w + (size_t)(i % 64) * 4096 * n, (i & 1) ? xb : xa, (i & 1) ? xa : xb, n, rows);
+  (void)hipStreamEndCapture(st, &g);
+  (void)hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int r = 0; r < 3; ++r) (void)hipGraphLaunch(ge, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipEventRecord(e0, st);
+  const int reps = 20;
+  for (int r = 0; r < reps; ++r) (void)hipGraphLaunch(ge, st);
+  (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipStreamDestroy(st);
+  return ms * 1e3f / (reps * nk);
+}
+
+int main() {
+  const int n = 768;
+  struct { const char* name; int rows; } shapes[] = {{"wo  (768 x 768, 2.4 MB)", 768}, {"qkv (2304 x 768, 7.1 MB)", 2304}, {"w13 (4096 x 768, 12.6 MB)", 4096}};
+  float *w, *xa, *xb;
+  (void)hipMalloc(&w, (size_t)4096 * n * 4 * 64);      // 64 copies, one per launch in turn (805 MB): the weights come from HBM, not from the 256 MB Infinity Cache
+  (void)hipMemset(w, 0, (size_t)4096 * n * 4 * 64);
+  (void)hipMalloc(&xa, 65536); (void)hipMalloc(&xb, 65536);
+  std::vector<float> h(16384, 0.01f);
+  (void)hipMemcpy(xa, h.data(), 65536, hipMemcpyHostToDevice); (void)hipMemcpy(xb, h.data(), 65536, hipMemcpyHostToDevice);
+  printf("us per launch in a chain of dependent launches (hipGraph replay), n = %d columns\n", n);
+  printf("%-28s %8s %8s %8s %8s %8s\n", "rows of the phase", "empty", "+x", "+norm", "+weights", "+reduce/store");
+  for (auto& s : shapes) {
+    printf("%-28s %8.2f %8.2f %8.2f %8.2f %8.2f\n", s.name, chain<1>(w, xa, xb, n, s.rows), chain<2>(w, xa, xb, n, s.rows),
+           chain<3>(w, xa, xb, n, s.rows), chain<4>(w, xa, xb, n, s.rows), chain<5>(w, xa, xb, n, s.rows));
+  }
+  printf("(every launch streams its own copy of the matrix from HBM: bytes / 6.3 TB/s = 0.4 / 1.1 / 2.0 us of the '+weights' step for the three shapes)\n");
+  return 0;
+}
