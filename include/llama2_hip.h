@@ -80,6 +80,18 @@ const char* l2_last_error(void);           /* thread-local text of the last fail
 int l2_create(const int32_t cfg[7], int device, l2_ctx** out);
 void l2_destroy(l2_ctx* ctx);
 
+/* SURVEY.md 8(f4) -- checkpoints newer than the reference understands.  The reference parses n_kv_heads and ignores
+ * it (llama2.ts:86, 117-118: wk / wv are always (d, d)) and reads the RoPE tables from the file (:125-126); l2_create
+ * does the same.  l2_create_ex honours, on request:
+ *   L2_F_GQA            n_kv_heads < n_heads: wk / wv are (n_kv_heads * head_size, d) per layer, the KV caches hold
+ *                       n_kv_heads * head_size floats per position and query head h attends over cache head
+ *                       h / (n_heads / n_kv_heads) -- grouped-query attention as llama2.c's run.c defines it;
+ *   L2_F_GENERATE_ROPE  no freq_cis tensors will be uploaded: the tables are computed at creation the way run.c
+ *                       computes them per position (fp32 powf / cosf / sinf).
+ * Neither is pinned by the reference (it cannot run such checkpoints); the oracle's restatement is our own. */
+enum { L2_F_GQA = 1, L2_F_GENERATE_ROPE = 2 };
+int l2_create_ex(const int32_t cfg[7], int device, unsigned flags, l2_ctx** out);
+
 /* Tensor-parallel context: rank `tp_rank` of `tp_size` owns heads / FFN rows
  * [rank*H/G, ...).  `nccl_id` is the 128-byte ncclUniqueId produced by l2_tp_unique_id on rank 0 and
  * handed to the others by the caller (e.g. over torch.distributed).  tp_size 1 == l2_create. */
@@ -104,6 +116,8 @@ int l2_upload(l2_ctx* ctx, int tensor_kind, int layer, const float* host, size_t
  * returns the file bytes consumed.  Equivalent to l2_create + one l2_upload per Float32Array. */
 int l2_load_checkpoint(const char* path, int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out,
                        uint64_t* bytes_read);
+/* The same for a llama2.c "version 1" file (magic "ak42", 256-byte header, norms first, no freq_cis; fp32): detected by
+ * its magic and loaded with L2_F_GQA | L2_F_GENERATE_ROPE.  A file without the magic is the v0 layout above. */
 /* The 7 header ints of a context (what readConfig parsed). */
 int l2_get_header(l2_ctx* ctx, int32_t cfg_out[7]);
 

@@ -33,6 +33,7 @@ struct AttnArgs {
   double* part;          // split form: [H][nsplit][rec] doubles, rec = round_up(hs + 2, 16)
   unsigned* counter;     // split form: [H] merge tickets (one per 128-byte line), zero between launches
   int dim, head_size, seq_len, n_heads, nsplit;
+  int kv_dim, kv_mul;    // floats of a cache row; query heads per cache head (1 unless the context honours n_kv_heads < n_heads)
   double inv_sqrt_hs;    // 1 / sqrt(head_size)
   int exact;             // 1: fp32-rounded t-sequential value accumulate (llama2.ts:263); never with nsplit > 1
   int pos_plus1;         // scalar fallback kernel, prefill: non-zero = the queries are pos0 + blockIdx.y (else tokpos)
@@ -56,7 +57,8 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   constexpr int RG = NT * RPT;         // rows per wave per round
   constexpr int RR = NW * RG;              // rows per workgroup per round
   constexpr int NTH = 64 * NW;
-  const int S = a.seq_len, hs = a.head_size, dim = a.dim, NS = a.nsplit;
+  const int S = a.seq_len, hs = a.head_size, dim = a.kv_dim, NS = a.nsplit;   // `dim`: the stride of the cache rows
+  const int hk = h / a.kv_mul;                                                // this head's columns of a cache row
   const int cmax = (S + NS - 1) / NS;
   float* sc = reinterpret_cast<float*>(smem);
   double* red = reinterpret_cast<double*>(smem + (size_t)((cmax + 3) & ~3) * 4);
@@ -83,7 +85,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   const unsigned slab = (unsigned)max(t1, 0) * (unsigned)dim * 4u;
   const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.kc), 0, slab, 0x00020000);
   const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vc), 0, slab, 0x00020000);
-  const unsigned voff = (unsigned)(((size_t)(t0 + wave * RPT + r) * dim + (size_t)h * hs + cc4) * 4);
+  const unsigned voff = (unsigned)(((size_t)(t0 + wave * RPT + r) * dim + (size_t)hk * hs + cc4) * 4);
   const unsigned tstride = (unsigned)(NW * RPT) * (unsigned)dim * 4u;                            // bytes between a wave's tiles
   auto issue = [&](f4 (&buf)[NT], bool values, int rd) {
 #pragma unroll
@@ -174,7 +176,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   if (a.exact && NS == 1) {
     // bit-faithful: the accumulator is a Float32Array element, rounded at every timestep, t ascending
     for (int i = tid; i < hs; i += NTH) {
-      const float* vp = a.vc + (size_t)h * hs + i;
+      const float* vp = a.vc + (size_t)hk * hs + i;
       float o = 0.0f;
       for (int t = 0; t < n; ++t) o = (float)((double)o + (double)sc[t] * (double)vp[(size_t)t * dim]);
       a.xb[(size_t)h * hs + i] = o;
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(64 * NW) pf_attn_tile_kernel(const AttnArgs a,
 // one thread per timestep, scalar loads.  Correctness only; keeps every rounding of the reference.
 __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int pos0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int S = a.seq_len, hs = a.head_size, dim = a.dim, h = blockIdx.x, tid = threadIdx.x;
+  const int S = a.seq_len, hs = a.head_size, dim = a.dim, kvd = a.kv_dim, h = blockIdx.x, hk = h / a.kv_mul, tid = threadIdx.x;
   float* att = reinterpret_cast<float*>(smem);                    // S floats
   double* red = reinterpret_cast<double*>(att + ((S + 3) & ~3));  // 8 doubles
   const int pos = a.pos_plus1 ? pos0 + (int)blockIdx.y : a.tokpos[1];
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int 
   float* xb = a.xb + (a.pos_plus1 ? (size_t)blockIdx.y * dim : 0) + (size_t)h * hs;
   const double rsq = sqrt((double)hs);
   for (int t = tid; t <= pos; t += 256) {
-    const float* kp = a.kc + (size_t)t * dim + (size_t)h * hs;
+    const float* kp = a.kc + (size_t)t * kvd + (size_t)hk * hs;
     double s = 0.0;
     for (int i = 0; i < hs; ++i) s += (double)q[i] * (double)kp[i];
     att[t] = (float)(s / rsq);
@@ -359,14 +361,14 @@ __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int 
   }
   __syncthreads();
   for (int i = tid; i < hs; i += 256) {
-    const float* vp = a.vc + (size_t)h * hs + i;
+    const float* vp = a.vc + (size_t)hk * hs + i;
     if (a.exact) {
       float o = 0.0f;
-      for (int t = 0; t <= pos; ++t) o = (float)((double)o + (double)att[t] * (double)vp[(size_t)t * dim]);
+      for (int t = 0; t <= pos; ++t) o = (float)((double)o + (double)att[t] * (double)vp[(size_t)t * kvd]);
       xb[i] = o;
     } else {
       double o = 0.0;
-      for (int t = 0; t <= pos; ++t) o += (double)att[t] * (double)vp[(size_t)t * dim];
+      for (int t = 0; t <= pos; ++t) o += (double)att[t] * (double)vp[(size_t)t * kvd];
       xb[i] = (float)o;
     }
   }

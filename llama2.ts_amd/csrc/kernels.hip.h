@@ -75,8 +75,9 @@ struct PhaseArgs {
   const float* fi;    // freq_cis_imag
   const int* tokpos;  // {token, pos, step, _}
   int n;              // input length (columns)
-  int rows;           // output rows (QKV: 3*dim, W13: hidden (pairs of w1/w3 rows))
+  int rows;           // output rows (QKV: dim + 2*kv_dim, W13: hidden (pairs of w1/w3 rows))
   int dim;
+  int kv_dim;         // QKV: rows of wk / wv = floats of a cache row (= dim unless the context honours n_kv_heads < n_heads)
   int head_size;
   // tensor parallel: column-sharded WO/W2 write fp64 partials instead of x
   double* partial;    // non-null (WO/W2 of a tensor-parallel rank): out[i] is not written, partial[i] = fp64 sum
@@ -212,11 +213,11 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// QKV row groups: all q rows, then k, then v.
+// QKV row groups: all q rows (dim), then k, then v (kv_dim each).
 __device__ __forceinline__ void qkv_group(const PhaseArgs& a, int g, int R, int& m, int& i0) {
   const int row0 = g * R;
-  m = (row0 >= a.dim) + (row0 >= 2 * a.dim);   // compares, not a division: this runs once per batch
-  i0 = row0 - m * a.dim;
+  m = (row0 >= a.dim) + (row0 >= a.dim + a.kv_dim);   // compares, not a division: this runs once per batch
+  i0 = row0 - (m >= 1 ? a.dim : 0) - (m == 2 ? a.kv_dim : 0);
 }
 
 template <int MODE, int R>
@@ -226,7 +227,7 @@ __device__ __forceinline__ void row_ptrs(const PhaseArgs& a, int g, int n, const
     qkv_group(a, g, R, m, i0);
     const float* base = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2;
 #pragma unroll
-    for (int r = 0; r < R; ++r) rp[r] = base + (size_t)min(i0 + r, a.dim - 1) * n;
+    for (int r = 0; r < R; ++r) rp[r] = base + (size_t)min(i0 + r, (m == 0 ? a.dim : a.kv_dim) - 1) * n;
   } else if (MODE == MODE_W13) {
     const int row0 = g * (R / 2);
 #pragma unroll
@@ -283,7 +284,7 @@ __device__ __forceinline__ EpiPre epi_prefetch(const PhaseArgs& a, int g, int la
     int m, i0;
     qkv_group(a, g, R, m, i0);
     const int p = min(lane, R / 2 > 0 ? R / 2 - 1 : 0);
-    const int i = min(i0 + 2 * p, a.dim - 2);
+    const int i = min(i0 + 2 * p, (m == 0 ? a.dim : a.kv_dim) - 2);
     const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2;
     e.e0 = a.fr[idx]; e.e1 = a.fi[idx];
   } else if (MODE == MODE_WO || MODE == MODE_W2) {
@@ -306,11 +307,11 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
     static_assert(MODE != MODE_QKV || R % 2 == 0, "RoPE rotates adjacent row pairs");
 #pragma unroll
     for (int p = 0; p < R / 2; ++p) {
-      if (lane == p && i0 + 2 * p < a.dim) {
+      if (lane == p && i0 + 2 * p < (m == 0 ? a.dim : a.kv_dim)) {
         const int i = i0 + 2 * p;
         const float s0 = (float)acc[2 * p], s1 = (float)acc[(2 * p + 1) % R];  // matmul store, llama2.ts:201
         if (m == 2) {  // v: straight into the cache row (llama2.ts:240)
-          float* vc = a.out_v + (size_t)pos * a.dim;
+          float* vc = a.out_v + (size_t)pos * a.kv_dim;
           vc[i] = s0; vc[i + 1] = s1;
           if (a.aux2) { a.aux2[i] = s0; a.aux2[i + 1] = s1; }
         } else {       // RoPE on the adjacent pair (llama2.ts:224-235)
@@ -321,7 +322,7 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
           const float o1 = (float)((double)s0 * fci + (double)s1 * fcr);
           if (m == 0) { a.out[i] = o0; a.out[i + 1] = o1; }
           else {        // k: cache row (llama2.ts:239)
-            float* kc = a.out_k + (size_t)pos * a.dim;
+            float* kc = a.out_k + (size_t)pos * a.kv_dim;
             kc[i] = o0; kc[i + 1] = o1;
             if (a.aux) { a.aux[i] = o0; a.aux[i + 1] = o1; }
           }

@@ -157,6 +157,8 @@ struct l2_ctx {
   // tensor parallel shard (G == 1: everything local)
   int G = 1, rank = 0;
   int d_loc, h_loc, H_loc, V_loc;
+  int KVH, kvd, kvd_loc;             // cache heads honoured (== H unless L2_F_GQA), floats of a cache row, per rank
+  unsigned flags = 0;
   nccl_comm comm = nullptr;
   l2s::Sampler samp;                 // device sampler (l2_decode_sample), created on first use
   hipGraphExec_t g_sample[NLEV][2] = {};  // [attention split level][plain sample / top-p]
@@ -228,7 +230,8 @@ static Slice tensor_slice(const l2_ctx* c, int kind) {
   switch (kind) {
     case L2_T_TOKEN_EMBEDDING: return {V, d, V, d, 0, 0};
     case L2_T_RMS_ATT: case L2_T_RMS_FFN: case L2_T_RMS_FINAL: return {1, d, 1, d, 0, 0};
-    case L2_T_WQ: case L2_T_WK: case L2_T_WV: return {dl, d, d, d, r * dl, 0};  // whole heads
+    case L2_T_WQ: return {dl, d, d, d, r * dl, 0};  // whole heads
+    case L2_T_WK: case L2_T_WV: return {(size_t)c->kvd_loc, d, (size_t)c->kvd, d, r * (size_t)c->kvd_loc, 0};
     case L2_T_WO: return {d, dl, d, d, 0, r * dl};                                 // columns, repacked
     case L2_T_W1: case L2_T_W3: return {hl, d, h, d, r * hl, 0};
     case L2_T_W2: return {d, hl, d, h, 0, r * hl};
@@ -310,7 +313,7 @@ static int env_int(const char* name, int dflt) {
 static int p2p_alloc(l2_ctx* c);
 static int p2p_connect_ipc(l2_ctx* c);
 
-static int create_impl(const int32_t cfg[7], int device, int rank, int G, const void* nccl_id, l2_ctx** out) {
+static int create_impl(const int32_t cfg[7], int device, int rank, int G, const void* nccl_id, l2_ctx** out, unsigned flags = 0) {
   if (!cfg || !out) return fail(L2_E_ARG, "null argument");
   *out = nullptr;
   const int d = cfg[0], h = cfg[1], L = cfg[2], H = cfg[3], V = abs(cfg[5]), S = cfg[6];
@@ -320,6 +323,9 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   if (G < 1 || rank < 0 || rank >= G) return fail(L2_E_ARG, "bad tensor-parallel rank %d of %d", rank, G);
   if (G > 1 && (H % G || h % G || V % G || ((d / G) % 2) || ((h / G) % 1)))
     return fail(L2_E_CONFIG, "shape does not shard over %d ranks (n_heads %d, hidden %d, vocab %d)", G, H, h, V);
+  // the reference parses n_kv_heads and ignores it (llama2.ts:86, 117-118); it is honoured only on request (L2_F_GQA)
+  const int KVH = (flags & L2_F_GQA) ? cfg[4] : H;
+  if (KVH <= 0 || H % KVH || KVH % G) return fail(L2_E_CONFIG, "n_kv_heads %d does not divide n_heads %d (or the %d ranks)", KVH, H, G);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(L2_E_NOGPU, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(L2_E_ARG, "device %d out of range (%d visible)", device, ndev);
@@ -336,6 +342,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->device = device;
   c->G = G; c->rank = rank;
   c->d_loc = d / G; c->h_loc = h / G; c->H_loc = H / G; c->V_loc = V / G;
+  c->KVH = KVH; c->kvd = KVH * (d / H); c->kvd_loc = c->kvd / G; c->flags = flags;
   c->tune_R = env_int("L2_TUNE_R", 0);
   c->tune_U = env_int("L2_TUNE_U", 0);
   c->tune_nwaves = env_int("L2_TUNE_NWAVES", 0);
@@ -361,11 +368,11 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     CK(hipMalloc(&c->w[k], c->layer_elems[k] * c->layers_of[k] * sizeof(float)));
     c->uploaded[k].assign(c->layers_of[k], 0);
   }
-  const size_t dl = c->d_loc, kv = (size_t)L * S * dl;
+  const size_t dl = c->d_loc, kvl = c->kvd_loc, kv = (size_t)L * S * kvl;
   CK(hipMalloc(&c->x, d * 4)); CK(hipMalloc(&c->xn, d * 4));
   CK(hipMalloc(&c->xb, dl * 4)); CK(hipMalloc(&c->xb2, d * 4));
   CK(hipMalloc(&c->hb, c->h_loc * 4)); CK(hipMalloc(&c->hb2, c->h_loc * 4));
-  CK(hipMalloc(&c->q, dl * 4)); CK(hipMalloc(&c->k, dl * 4)); CK(hipMalloc(&c->v, dl * 4));
+  CK(hipMalloc(&c->q, dl * 4)); CK(hipMalloc(&c->k, kvl * 4)); CK(hipMalloc(&c->v, kvl * 4));
   CK(hipMalloc(&c->att, (size_t)c->H_loc * S * 4));
   c->tp_path = G > 1 || env_int("L2_TP_FORCE_COMM", 0);   // the latter: 1-rank communicator, exercises the RCCL path on one GPU
   // the gathered logits of a tensor-parallel rank are written by its peers (tp_p2p_gather_kernel): uncached memory
@@ -376,7 +383,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMalloc(&c->kc, kv * 4)); CK(hipMalloc(&c->vc, kv * 4));
   CK(hipMemsetAsync(c->kc, 0, kv * 4, c->stream)); CK(hipMemsetAsync(c->vc, 0, kv * 4, c->stream));
   float* zero[] = {c->x, c->xn, c->xb, c->xb2, c->hb, c->hb2, c->q, c->k, c->v};
-  const size_t zn[] = {(size_t)d, (size_t)d, dl, (size_t)d, (size_t)c->h_loc, (size_t)c->h_loc, dl, dl, dl};
+  const size_t zn[] = {(size_t)d, (size_t)d, dl, (size_t)d, (size_t)c->h_loc, (size_t)c->h_loc, dl, kvl, kvl};
   for (int i = 0; i < 9; ++i) CK(hipMemsetAsync(zero[i], 0, zn[i] * 4, c->stream));
   CK(hipMemsetAsync(c->att, 0, (size_t)c->H_loc * S * 4, c->stream));
   CK(hipMemsetAsync(c->logits, 0, (size_t)V * 4, c->stream));
@@ -451,6 +458,32 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
 
 extern "C" int l2_create(const int32_t cfg[7], int device, l2_ctx** out) { return create_impl(cfg, device, 0, 1, nullptr, out); }
 
+// RoPE tables the way llama2.c's run.c computes them per position when the checkpoint carries none (newer export
+// versions): freq = 1 / 10000^(j / (head_size / 2))... in fp32, angle = pos * freq, cosf / sinf.
+static int generate_rope(l2_ctx* c) {
+  const int hs2 = c->hs / 2;
+  std::vector<float> re((size_t)c->S * hs2), im((size_t)c->S * hs2);
+  for (int t = 0; t < c->S; ++t)
+    for (int j = 0; j < hs2; ++j) {
+      const float freq = 1.0f / powf(10000.0f, (float)(2 * j) / (float)c->hs);
+      const float val = (float)t * freq;
+      re[(size_t)t * hs2 + j] = cosf(val);
+      im[(size_t)t * hs2 + j] = sinf(val);
+    }
+  HIPCHK(hipMemcpy(c->w[L2_T_FREQ_REAL], re.data(), re.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->w[L2_T_FREQ_IMAG], im.data(), im.size() * 4, hipMemcpyHostToDevice));
+  c->uploaded[L2_T_FREQ_REAL][0] = 1; c->uploaded[L2_T_FREQ_IMAG][0] = 1;
+  return L2_OK;
+}
+
+extern "C" int l2_create_ex(const int32_t cfg[7], int device, unsigned flags, l2_ctx** out) {
+  if (flags & ~(unsigned)(L2_F_GQA | L2_F_GENERATE_ROPE)) return fail(L2_E_ARG, "unknown flag bits 0x%x", flags);
+  int rc = create_impl(cfg, device, 0, 1, nullptr, out, flags);
+  if (rc) return rc;
+  if (flags & L2_F_GENERATE_ROPE) { rc = generate_rope(*out); if (rc) { l2_destroy(*out); *out = nullptr; return rc; } }
+  return L2_OK;
+}
+
 extern "C" int l2_tp_unique_id(void* id_out_128) {
   if (!id_out_128) return fail(L2_E_ARG, "null argument");
   int rc = rccl_bind();
@@ -523,9 +556,29 @@ extern "C" int l2_load_checkpoint(const char* path, int device, int tp_rank, int
   if (!f) return fail(L2_E_ARG, "cannot open checkpoint %s", path);
   int32_t hdr[7];
   if (fread(hdr, 4, 7, f) != 7) { fclose(f); return fail(L2_E_ARG, "checkpoint %s: short header", path); }
+  // llama2.c "version 1" export: magic "ak42", version, the 7 ints, one byte shared_classifier, padded to 256 bytes;
+  // tensors in a different order (norms first) and no freq_cis.  Anything else is the v0 layout the reference reads.
+  static const int order_v0[] = {L2_T_TOKEN_EMBEDDING, L2_T_RMS_ATT, L2_T_WQ, L2_T_WK, L2_T_WV, L2_T_WO, L2_T_RMS_FFN, L2_T_W1, L2_T_W2, L2_T_W3,
+                                 L2_T_RMS_FINAL, L2_T_FREQ_REAL, L2_T_FREQ_IMAG, L2_T_WCLS};
+  static const int order_v1[] = {L2_T_RMS_ATT, L2_T_RMS_FFN, L2_T_RMS_FINAL, L2_T_TOKEN_EMBEDDING, L2_T_WQ, L2_T_WK, L2_T_WV, L2_T_WO, L2_T_W1,
+                                 L2_T_W2, L2_T_W3, L2_T_WCLS};
+  const int* order = order_v0;
+  int n_order = 14;
+  unsigned flags = 0;
+  uint64_t total = 28;
+  if ((uint32_t)hdr[0] == 0x616b3432u) {
+    if (hdr[1] != 1) { fclose(f); return fail(L2_E_CONFIG, "checkpoint %s: version %d export (only the fp32 version 1 is supported)", path, hdr[1]); }
+    int32_t h1[7];
+    unsigned char shared = 0;
+    if (fseek(f, 8, SEEK_SET) || fread(h1, 4, 7, f) != 7 || fread(&shared, 1, 1, f) != 1 || fseek(f, 256, SEEK_SET)) { fclose(f); return fail(L2_E_ARG, "checkpoint %s: short header", path); }
+    memcpy(hdr, h1, sizeof(hdr));
+    hdr[5] = shared ? abs(hdr[5]) : -abs(hdr[5]);        // the v0 convention: sign of vocab_size = shared classifier (llama2.ts:90)
+    order = order_v1; n_order = 12; flags = L2_F_GQA | L2_F_GENERATE_ROPE; total = 256;
+  }
   l2_ctx* c = nullptr;
-  int rc = (tp_size > 1) ? l2_create_tp(hdr, device, tp_rank, tp_size, nccl_id, &c) : l2_create(hdr, device, &c);
+  int rc = (tp_size > 1) ? create_impl(hdr, device, tp_rank, tp_size, nccl_id, &c, flags) : create_impl(hdr, device, 0, 1, nullptr, &c, flags);
   if (rc) { fclose(f); return rc; }
+  if (flags & L2_F_GENERATE_ROPE) { rc = generate_rope(c); if (rc) { fclose(f); l2_destroy(c); return rc; } }
   // two pinned staging buffers: fread into one while the other is in flight to the device
   const size_t CH = (size_t)64 << 20;
   float* stage[2] = {nullptr, nullptr};
@@ -541,9 +594,9 @@ extern "C" int l2_load_checkpoint(const char* path, int device, int tp_rank, int
     if (hipHostMalloc(&stage[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreate(&done[i]) != hipSuccess)
       return cleanup(fail(L2_E_HIP, "cannot allocate pinned staging"));
   }
-  uint64_t total = 28;
   int cur = 0;
-  for (int kind = 0; kind < L2_T_COUNT; ++kind) {
+  for (int oi = 0; oi < n_order; ++oi) {
+    const int kind = order[oi];
     if (kind == L2_T_WCLS && c->shared) continue;
     const Slice sl = tensor_slice(c, kind);
     const size_t full_layer = sl.full_rows * sl.full_cols;
@@ -608,7 +661,8 @@ static uint64_t full_count(const l2_ctx* c, int kind) {
   switch (kind) {
     case L2_T_TOKEN_EMBEDDING: case L2_T_WCLS: return V * d;
     case L2_T_RMS_ATT: case L2_T_RMS_FFN: return L * d;
-    case L2_T_WQ: case L2_T_WK: case L2_T_WV: case L2_T_WO: return L * d * d;
+    case L2_T_WQ: case L2_T_WO: return L * d * d;
+    case L2_T_WK: case L2_T_WV: return L * (size_t)c->kvd * d;
     case L2_T_W1: case L2_T_W2: case L2_T_W3: return L * h * d;
     case L2_T_RMS_FINAL: return d;
     case L2_T_FREQ_REAL: case L2_T_FREQ_IMAG: return S * hs2;
@@ -809,14 +863,15 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   return hipGetLastError();
 }
 
-static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4 == 0) && c->hs <= 256; }
+static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4 == 0) && (c->kvd_loc % 4 == 0) && c->hs <= 256; }
 
 static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
-  const size_t loff = (size_t)l * c->S * c->d_loc;
+  const size_t loff = (size_t)l * c->S * c->kvd_loc;
   memset(&a, 0, sizeof(a));
   a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->opt_keep_state ? c->att : nullptr; a.xb = c->xb;
   a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter;
   a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
+  a.kv_dim = c->kvd_loc; a.kv_mul = c->H / c->KVH;
   a.exact = c->opt_exact;
   a.inv_sqrt_hs = 1.0 / sqrt((double)c->hs);
 #ifdef L2_STAMPS
@@ -1080,7 +1135,7 @@ static PhaseArgs base_args(const l2_ctx* c) {
 }
 static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs + RoPE + KV-cache store (llama2.ts:216-240)
   PhaseArgs a = base_args(c);
-  const size_t loff = (size_t)l * c->S * c->d_loc;
+  const size_t loff = (size_t)l * c->S * c->kvd_loc;
   a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l;
   a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
   a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
@@ -1088,7 +1143,7 @@ static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs +
   a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * l;
   a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff;
   if (c->opt_keep_state) { a.aux = c->k; a.aux2 = c->v; }     // RunState.k / v: the cache rows are what attention reads
-  a.n = c->d; a.rows = 3 * c->d_loc; a.dim = c->d_loc;
+  a.n = c->d; a.rows = c->d_loc + 2 * c->kvd_loc; a.dim = c->d_loc; a.kv_dim = c->kvd_loc;
   return a;
 }
 static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (llama2.ts:270-273)
@@ -1310,7 +1365,7 @@ extern "C" float* l2_logits_host(l2_ctx* c) { return c ? c->h_logits : nullptr; 
 
 // ---- prefill -----------------------------------------------------------------
 static bool can_prefill(const l2_ctx* c) {
-  return !c->tp_path && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
+  return !c->tp_path && c->kvd == c->d && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
 }
 
 // One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1, 2 or 4).  QKV / WO / W2 take their weights through an LDS
@@ -1566,7 +1621,7 @@ extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t
   HIPCHK(hipSetDevice(c->device));
   const float* src = nullptr;
   size_t n = 0;
-  const size_t slab = (size_t)c->S * c->d_loc;
+  const size_t slab = (size_t)c->S * c->kvd_loc;
   if (!c->opt_keep_state && ((which == L2_S_X && c->ran_forward) || which == L2_S_XB2 || which == L2_S_HB2 || which == L2_S_K || which == L2_S_V || which == L2_S_ATT))
     return fail(L2_E_STATE, "this RunState field is only read by transformer() itself and stays on chip: set L2_OPT_KEEP_STATE before the forward");
   switch (which) {
@@ -1576,8 +1631,8 @@ extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t
     case L2_S_HB: src = c->hb; n = c->h_loc; break;
     case L2_S_HB2: src = c->hb2; n = c->h_loc; break;
     case L2_S_Q: src = c->q; n = c->d_loc; break;
-    case L2_S_K: src = c->k; n = c->d_loc; break;
-    case L2_S_V: src = c->v; n = c->d_loc; break;
+    case L2_S_K: src = c->k; n = c->kvd_loc; break;
+    case L2_S_V: src = c->v; n = c->kvd_loc; break;
     case L2_S_ATT: src = c->att; n = (size_t)c->H_loc * c->S; break;
     case L2_S_LOGITS: src = c->logits; n = c->V; break;
     case L2_S_KEY_CACHE: case L2_S_VALUE_CACHE: {
@@ -1648,7 +1703,7 @@ extern "C" int l2_bench_gemv(l2_ctx* c, int kind, int layer, int iters, float* a
   memset(&a, 0, sizeof(a));
   a.tokpos = c->tokpos; a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG]; a.head_size = c->hs; a.dim = c->d;
   a.inv_n = 1.0 / (double)c->d;
-  const size_t loff = (size_t)layer * c->S * c->d_loc;
+  const size_t loff = (size_t)layer * c->S * c->kvd_loc;
   int mode;
   switch (kind) {
     case L2_T_WQ: case L2_T_WK: case L2_T_WV:
@@ -1656,7 +1711,7 @@ extern "C" int l2_bench_gemv(l2_ctx* c, int kind, int layer, int iters, float* a
       a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * layer; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * layer;
       a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * layer;
       a.in = c->xn; a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * layer; a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff;
-      a.n = c->d; a.rows = 3 * c->d_loc; a.dim = c->d_loc; break;
+      a.n = c->d; a.rows = c->d_loc + 2 * c->kvd_loc; a.dim = c->d_loc; a.kv_dim = c->kvd_loc; break;
     case L2_T_WO:
       mode = MODE_WO; a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * layer; a.in = c->xb; a.res = c->xn; a.out = c->xb2;
       a.n = c->d_loc; a.rows = c->d; break;

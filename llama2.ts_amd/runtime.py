@@ -26,12 +26,13 @@ S_X, S_XB, S_XB2, S_HB, S_HB2, S_Q, S_K, S_V, S_ATT, S_LOGITS, S_KEY_CACHE, S_VA
 STATE_IDS = dict(x=S_X, xb=S_XB, xb2=S_XB2, hb=S_HB, hb2=S_HB2, q=S_Q, k=S_K, v=S_V, att=S_ATT, logits=S_LOGITS,
                  key_cache=S_KEY_CACHE, value_cache=S_VALUE_CACHE)
 OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_KEEP_STATE = 1, 2, 3
+F_GQA, F_GENERATE_ROPE = 1, 2     # l2_create_ex flags
 
 # every symbol include/llama2_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
                "l2_decode_greedy", "l2_decode_sample", "l2_debug_running_sums", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
-               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ", "l2_tp_mode"]
+               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ", "l2_tp_mode", "l2_create_ex"]
 
 
 class L2Error(RuntimeError):
@@ -81,6 +82,7 @@ def lib():
     L.l2_prefill.argtypes = [vp, vp, i32, i32, vp]
     L.l2_bench_dominant_in_situ.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(i32)]
     L.l2_tp_mode.argtypes = [vp]
+    L.l2_create_ex.argtypes = [vp, i32, u32, C.POINTER(vp)]
     L.l2_tp_mode.restype = i32
     for name in ABI_SYMBOLS:   # fail at load time, not at first use, if the .so is stale
         getattr(L, name)
@@ -119,10 +121,12 @@ def readConfig(buf):
     return Config(struct.unpack("<7i", bytes(buf[:28])))
 
 
-def tensor_shapes(cfg):
-    """[(kind, n_layers_or_0, per-array float count)] in checkpoint order (llama2.ts:114-127)."""
+def tensor_shapes(cfg, gqa=False):
+    """[(kind, n_layers_or_0, per-array float count)] in checkpoint order (llama2.ts:114-127).  `gqa`: wk / wv have
+    n_kv_heads * head_size rows (contexts created with F_GQA); the reference always reads (d, d)."""
     d, h, L, V, S, hs2 = cfg.dim, cfg.hidden_dim, cfg.n_layers, cfg.vocab_size, cfg.seq_len, cfg.head_size // 2
-    out = [(T_TOKEN_EMBEDDING, 0, V * d), (T_RMS_ATT, L, d), (T_WQ, L, d * d), (T_WK, L, d * d), (T_WV, L, d * d),
+    kvd = cfg.n_kv_heads * cfg.head_size if gqa else d
+    out = [(T_TOKEN_EMBEDDING, 0, V * d), (T_RMS_ATT, L, d), (T_WQ, L, d * d), (T_WK, L, kvd * d), (T_WV, L, kvd * d),
            (T_WO, L, d * d), (T_RMS_FFN, L, d), (T_W1, L, h * d), (T_W2, L, d * h), (T_W3, L, h * d),
            (T_RMS_FINAL, 0, d), (T_FREQ_REAL, 0, S * hs2), (T_FREQ_IMAG, 0, S * hs2)]
     if not cfg.shared_weights:
@@ -133,11 +137,14 @@ def tensor_shapes(cfg):
 class Context:
     """One l2_ctx: weights + RunState of one model on one MI355X (or one rank of a TP group)."""
 
-    def __init__(self, cfg, device=0, tp_rank=0, tp_size=1, nccl_id=None):
+    def __init__(self, cfg, device=0, tp_rank=0, tp_size=1, nccl_id=None, flags=0):
         self.cfg = cfg if isinstance(cfg, Config) else Config(cfg)
         hdr = (C.c_int32 * 7)(*self.cfg.header)
         h = C.c_void_p()
-        if tp_size > 1:
+        self.flags = flags
+        if flags:
+            _check(lib().l2_create_ex(hdr, device, int(flags), C.byref(h)))
+        elif tp_size > 1:
             idbuf = C.create_string_buffer(bytes(nccl_id), 128)
             _check(lib().l2_create_tp(hdr, device, tp_rank, tp_size, idbuf, C.byref(h)))
         else:
@@ -218,8 +225,9 @@ class Context:
     def read_state(self, name, layer=-1):
         c = self.cfg
         dl, hl, Hl = c.dim // self.tp_size, c.hidden_dim // self.tp_size, c.n_heads // self.tp_size
-        slab = c.seq_len * dl
-        n = {"x": c.dim, "xb": dl, "xb2": c.dim, "hb": hl, "hb2": hl, "q": dl, "k": dl, "v": dl, "att": Hl * c.seq_len,
+        kvl = (c.n_kv_heads * c.head_size if getattr(self, "flags", 0) & F_GQA else c.dim) // self.tp_size
+        slab = c.seq_len * kvl
+        n = {"x": c.dim, "xb": dl, "xb2": c.dim, "hb": hl, "hb2": hl, "q": dl, "k": kvl, "v": kvl, "att": Hl * c.seq_len,
              "logits": c.vocab_size, "key_cache": slab * (c.n_layers if layer < 0 else 1),
              "value_cache": slab * (c.n_layers if layer < 0 else 1)}[name]
         out = np.empty(n, dtype=np.float32)
@@ -336,6 +344,8 @@ def load_checkpoint_native(path, device=0):
     ctx = Context.__new__(Context)
     ctx.cfg = Config(tuple(hdr))
     ctx._h, ctx.tp_rank, ctx.tp_size, ctx._logits_view = h, 0, 1, None
+    with open(path, "rb") as f:                     # a version-1 export is loaded with F_GQA | F_GENERATE_ROPE (include/llama2_hip.h)
+        ctx.flags = (F_GQA | F_GENERATE_ROPE) if f.read(4) == b"24ka" else 0
     weights = TransformerWeights(ctx)
     return ctx.cfg, newRunState(ctx.cfg, weights), weights, n.value
 

@@ -17,6 +17,16 @@
 /* ------------------------------------------------------------------------------------------ */
 /* Config + layout                                                                             */
 
+/* SURVEY.md 8(f4) -- PARITY UNPINNED BY THE REFERENCE: llama2.ts parses n_kv_heads and ignores it (llama2.ts:86,
+ * 117-118), so it cannot run a grouped-query checkpoint.  With this switch on, the restatement honours the field the
+ * way llama2.c's run.c does (wk / wv have n_kv_heads * head_size rows, query head h reads cache head
+ * h / (n_heads / n_kv_heads)); everything else keeps the reference's arithmetic.  Off (default) = the reference. */
+static int g_honour_kv_heads = 0;
+void orc_set_gqa(int on) { g_honour_kv_heads = on; }
+static int kv_dim(const orc_config* c) {
+  return (g_honour_kv_heads && c->n_kv_heads > 0 && c->n_kv_heads < c->n_heads) ? c->n_kv_heads * c->head_size : c->dim;
+}
+
 void orc_read_config(const int32_t hdr[7], orc_config* c) {
   /* llama2.ts:80-93 */
   c->dim = hdr[0];
@@ -36,7 +46,8 @@ uint64_t orc_tensor_count(const orc_config* c, int kind) {
   switch (kind) { /* llama2.ts:114-127 */
     case ORC_T_TOKEN_EMBEDDING: return V * d;
     case ORC_T_RMS_ATT: case ORC_T_RMS_FFN: return L * d;
-    case ORC_T_WQ: case ORC_T_WK: case ORC_T_WV: case ORC_T_WO: return L * d * d;
+    case ORC_T_WQ: case ORC_T_WO: return L * d * d;
+    case ORC_T_WK: case ORC_T_WV: return L * (uint64_t)kv_dim(c) * d;
     case ORC_T_W1: case ORC_T_W3: return L * h * d;
     case ORC_T_W2: return L * d * h;
     case ORC_T_RMS_FINAL: return d;
@@ -403,31 +414,36 @@ int orc_next_token(float* logits, int n, double temperature, double topp, uint64
 
 static void rope_and_store(orc_model* m, int l, int pos) {
   const orc_config* p = &m->c;
-  const int dim = p->dim, head_size = p->dim / p->n_heads;
+  const int dim = p->dim, head_size = p->dim / p->n_heads, kvd = kv_dim(p);
   const float* fr = m->w[ORC_T_FREQ_REAL];
   const float* fi = m->w[ORC_T_FREQ_IMAG];
   for (int i = 0; i < dim; i += 2) { /* llama2.ts:224-235 */
-    const double q0 = m->q[i], q1 = m->q[i + 1], k0 = m->k[i], k1 = m->k[i + 1];
     const size_t idx = (size_t)pos * head_size / 2 + (size_t)(i % head_size) / 2;
     const double fcr = fr[idx], fci = fi[idx];
+    const double q0 = m->q[i], q1 = m->q[i + 1];
     m->q[i] = (float)(q0 * fcr - q1 * fci);
     m->q[i + 1] = (float)(q0 * fci + q1 * fcr);
-    m->k[i] = (float)(k0 * fcr - k1 * fci);
-    m->k[i + 1] = (float)(k0 * fci + k1 * fcr);
+    if (i < kvd) {   /* every pair when kvd == dim (the reference); grouped-query: only the cache heads' pairs */
+      const double k0 = m->k[i], k1 = m->k[i + 1];
+      m->k[i] = (float)(k0 * fcr - k1 * fci);
+      m->k[i + 1] = (float)(k0 * fci + k1 * fcr);
+    }
   }
-  const size_t loff = (size_t)l * p->seq_len * dim; /* llama2.ts:238-240 */
-  memcpy(m->key_cache + loff + (size_t)pos * dim, m->k, (size_t)dim * 4);
-  memcpy(m->value_cache + loff + (size_t)pos * dim, m->v, (size_t)dim * 4);
+  const size_t loff = (size_t)l * p->seq_len * kvd; /* llama2.ts:238-240 */
+  memcpy(m->key_cache + loff + (size_t)pos * kvd, m->k, (size_t)kvd * 4);
+  memcpy(m->value_cache + loff + (size_t)pos * kvd, m->v, (size_t)kvd * 4);
 }
 
 static void attention(orc_model* m, int l, int pos) {
   const orc_config* p = &m->c;
-  const int dim = p->dim, head_size = p->dim / p->n_heads;
+  const int head_size = p->dim / p->n_heads, dim = kv_dim(p) /* stride of a cache row */;
+  const int kv_mul = p->dim / dim;                                  /* query heads per cache head: 1 in the reference */
   const size_t loff = (size_t)l * p->seq_len * dim;
   const double inv = sqrt((double)head_size);
-  for (int h = 0; h < p->n_heads; ++h) { /* llama2.ts:244-267 */
-    const float* q = m->q + (size_t)h * head_size;
-    float* att = m->att + (size_t)h * p->seq_len;
+  for (int hq = 0; hq < p->n_heads; ++hq) { /* llama2.ts:244-267 */
+    const int h = hq / kv_mul;
+    const float* q = m->q + (size_t)hq * head_size;
+    float* att = m->att + (size_t)hq * p->seq_len;
     for (int t = 0; t <= pos; ++t) {
       const float* kk = m->key_cache + loff + (size_t)t * dim + (size_t)h * head_size;
       double score = 0.0;
@@ -435,7 +451,7 @@ static void attention(orc_model* m, int l, int pos) {
       att[t] = (float)(score / inv);
     }
     orc_softmax(att, pos + 1);
-    float* xb = m->xb + (size_t)h * head_size;
+    float* xb = m->xb + (size_t)hq * head_size;
     for (int i = 0; i < head_size; ++i) xb[i] = 0.0f;
     for (int t = 0; t <= pos; ++t) {
       const double a = att[t];
@@ -462,8 +478,8 @@ void orc_forward(orc_model* m, int token, int pos, float* logits_out) {
   for (int l = 0; l < p->n_layers; ++l) {
     orc_rmsnorm(m->xb, m->x, orc_weights(m, ORC_T_RMS_ATT, l), dim);           /* :216 */
     orc_matmul(m->q, m->xb, orc_weights(m, ORC_T_WQ, l), dim, dim);             /* :219 */
-    orc_matmul(m->k, m->xb, orc_weights(m, ORC_T_WK, l), dim, dim);             /* :220 */
-    orc_matmul(m->v, m->xb, orc_weights(m, ORC_T_WV, l), dim, dim);             /* :221 */
+    orc_matmul(m->k, m->xb, orc_weights(m, ORC_T_WK, l), dim, kv_dim(p));       /* :220 (dim rows in the reference) */
+    orc_matmul(m->v, m->xb, orc_weights(m, ORC_T_WV, l), dim, kv_dim(p));       /* :221 */
     rope_and_store(m, l, pos);                                                  /* :224-240 */
     attention(m, l, pos);                                                       /* :244-267 */
     orc_matmul(m->xb2, m->xb, orc_weights(m, ORC_T_WO, l), dim, dim);           /* :270 */

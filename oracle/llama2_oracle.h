@@ -62,6 +62,8 @@ typedef struct orc_config {
 typedef struct orc_model orc_model;
 
 /* readConfig (llama2.ts:80-93): 7 little-endian int32, sign of vocab_size = shared flag. */
+/* grouped-query switch (parity unpinned by the reference): see llama2_oracle.c */
+void orc_set_gqa(int on);
 void orc_read_config(const int32_t hdr[7], orc_config* out);
 
 /* Element counts / float-stream offsets of each tensor (layer = -1 for the whole tensor). */

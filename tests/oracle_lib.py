@@ -182,6 +182,12 @@ def synth_tensor(hdr, seed, kind, layer=-1):
     return out
 
 
+def set_gqa(on):
+    """SURVEY.md 8(f4), parity unpinned by the reference: make the restatement honour n_kv_heads < n_heads (grouped-query
+    attention as llama2.c defines it).  Off = the reference's behaviour (the field is parsed and ignored)."""
+    lib().orc_set_gqa(int(bool(on)))
+
+
 def synth_write(hdr, seed, path):
     h = _hdr(hdr)
     if lib().orc_synth_write(h.ctypes.data, seed, path.encode()) != 0:
