@@ -162,13 +162,13 @@ def cpu_baseline(name, hdr, seed):
 def roofline_block(ctx, cfg, K, traffic, traffic_how):
     iters = 200 if cfg.dim * cfg.hidden_dim < (1 << 24) else 50
     kms_isolated = ctx.bench_gemv(runtime.T_W1, cfg.n_layers // 2, iters)
-    kus, nlaunch = ctx.bench_dominant_in_situ(1, 0, min(K, 128))    # HIP event pair around every launch, eager launches of the same kernels
+    kus, nlaunch = ctx.bench_dominant_in_situ(1, 0, min(K, 128))    # HIP events on every dispatch of the kernel, eager launches of the same kernels
     kb = dominant_kernel_bytes(cfg)
     ach = kb / (kus * 1e-6) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_how": traffic_how,
             "kernel": DOMINANT, "bytes_per_launch": kb, "avg_launch_us": round(kus, 3), "launches_timed": nlaunch,
-            "how": "HIP event pair around every launch inside a decode run on the library's stream",
+            "how": "HIP start/stop events attached to every dispatch of this kernel inside a decode run on the library's stream (hipExtLaunchKernelGGL)",
             "isolated_back_to_back_us": round(kms_isolated * 1e3, 3)}
 
 
@@ -190,7 +190,11 @@ def secondary_config(name, seed, device, with_cpu, traffic):
     ctx.synth_fill(seed)
     cfg = ctx.cfg
     K = min(256, hdr[6])
-    ctx.bench_decode(1, 0, 32)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.3:      # untimed: clocks up (see main)
+        ctx.bench_decode(1, 0, 64)
+    ctx.bench_decode(1, 0, 31)
+    ctx.bench_decode(1, K - 1, 1)                  # captures the split-attention graph outside the timed region
     t0 = time.perf_counter()
     ctx.bench_decode(1, 0, K)
     wall = time.perf_counter() - t0
@@ -272,7 +276,17 @@ def main():
             import torch
             torch.cuda.synchronize(device)
 
-    ctx.bench_decode(1, 0, W)                  # W untimed warm-up steps (captures the graph too)
+    # untimed: small models finish their K steps in tens of milliseconds, less than the clock ramp of an idle GPU, so
+    # they first decode for ~0.3 s; then the W warm-up steps, the last of them at the deepest position of the timed run
+    # (it captures the hipGraph of the split-attention level, which would otherwise be captured inside the timed region)
+    if configs.checkpoint_bytes(hdr) < (1 << 30):
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.3:
+            ctx.bench_decode(1, 0, min(64, hdr[6]))
+    if W > 1:
+        ctx.bench_decode(1, 0, W - 1)
+    if W > 0:
+        ctx.bench_decode(1, K - 1, 1)
     sync_all()
     t0 = time.perf_counter()
     dev_ms = ctx.bench_decode(1, 0, K)         # EXACTLY K timed steps, HIP events on the library's stream

@@ -180,8 +180,9 @@ int l2_timer_stop(l2_ctx* ctx, float* elapsed_ms);   /* synchronises */
  * `iters` times back to back and return the average device time per launch.  Scratch use of the RunState
  * buffers: the activations and cache row `pos` are clobbered, call it outside a decode. */
 int l2_bench_gemv(l2_ctx* ctx, int tensor_kind, int layer, int iters, float* avg_ms);
-/* The same kernel timed in situ: `steps` greedy decode steps (eager launches) with a HIP event pair around every
- * launch of the rmsnorm + w1/w3 + SwiGLU kernel on the library's stream; mean duration in microseconds. */
+/* The same kernel timed in situ: `steps` greedy decode steps (eager launches) with a HIP start / stop event pair attached
+ * to every dispatch of the rmsnorm + w1/w3 + SwiGLU kernel on the library's stream (hipExtLaunchKernelGGL: the events
+ * bracket the kernel's execution, as a kernel trace does); mean duration in microseconds. */
 int l2_bench_dominant_in_situ(l2_ctx* ctx, int first_token, int pos0, int steps, float* avg_us, int* launches);
 /* `steps` forwards (greedy feed, device-resident) timed with events: total device ms. */
 int l2_bench_decode(l2_ctx* ctx, int first_token, int pos0, int steps, float* total_ms);
