@@ -28,7 +28,7 @@ enum {
   L2_E_ARG = -1,     /* bad argument (null pointer, index out of range, wrong size) */
   L2_E_CONFIG = -2,  /* unsupported header (dim % n_heads, odd head_size, non-positive sizes) */
   L2_E_HIP = -3,     /* a HIP runtime call failed */
-  L2_E_STATE = -4,   /* call order violated (forward before all tensors uploaded, pos not sequential) */
+  L2_E_STATE = -4,   /* call order violated (forward before all tensors uploaded, a kept-state read without L2_OPT_KEEP_STATE) */
   L2_E_NOGPU = -5,   /* no gfx950 device visible */
   L2_E_COMM = -6     /* RCCL failure (tensor-parallel contexts) */
 };
@@ -129,8 +129,9 @@ int l2_read_tensor(l2_ctx* ctx, int tensor_kind, int layer, size_t offset, float
 
 /* Replaces transformer(token, pos, p, s, w) (llama2.ts:205-303, call site :468).  Blocking: when it
  * returns, logits_out[0..V) holds state.logits for this position and the device KV cache holds rows
- * 0..pos.  pos must be 0 <= pos < seq_len; token in [0, V).  logits_out may be NULL (logits stay
- * readable through l2_logits_host / l2_read_state). */
+ * 0..pos.  pos must be 0 <= pos < seq_len; token in [0, V).  The reference's loop feeds pos = 0, 1, 2, ... (llama2.ts:464,
+ * 496); any pos is accepted here -- attention then reads whatever rows 0..pos-1 the cache holds from earlier calls.
+ * logits_out may be NULL (logits stay readable through l2_logits_host / l2_read_state). */
 int l2_forward(l2_ctx* ctx, int token, int pos, float* logits_out);
 /* Pinned host buffer (V floats) that l2_forward fills; a binding may wrap it as RunState.logits to
  * skip the copy into logits_out. */

@@ -327,6 +327,13 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   // the reference parses n_kv_heads and ignores it (llama2.ts:86, 117-118); it is honoured only on request (L2_F_GQA)
   const int KVH = (flags & L2_F_GQA) ? cfg[4] : H;
   if (KVH <= 0 || H % KVH || KVH % G) return fail(L2_E_CONFIG, "n_kv_heads %d does not divide n_heads %d (or the %d ranks)", KVH, H, G);
+  // limits of the kernels, reported here instead of as an opaque launch failure: the attention tiles address a layer's
+  // cache slab through a 32-bit buffer descriptor and keep one score per position of a split in LDS (160 KiB per CU);
+  // the GEMV phases stage x (and the norm weight) in LDS
+  if ((unsigned long long)S * (unsigned long long)(KVH * (d / H) / G) * 4ull >= (1ull << 32))
+    return fail(L2_E_CONFIG, "seq_len %d x kv_dim %d: a layer's cache slab exceeds 4 GiB", S, KVH * (d / H) / G);
+  if ((size_t)S * 4 + 40 * 1024 > 160 * 1024) return fail(L2_E_CONFIG, "seq_len %d: the attention kernel keeps one score per position in LDS (at most ~30 000)", S);
+  if ((size_t)(d > h / G ? d : h / G) * 4 * 2 + 4096 > 160 * 1024) return fail(L2_E_CONFIG, "dim %d / hidden_dim %d: the input vector of a phase does not fit the 160 KiB LDS", d, h);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(L2_E_NOGPU, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(L2_E_ARG, "device %d out of range (%d visible)", device, ndev);
@@ -969,7 +976,7 @@ __device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e,
     unsigned spins = 0;
     while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 24)) { *a.err = 1; break; }          // ~1 s: give up, the host reports it
+      if (++spins > (1u << 22)) { *a.err = 1; break; }          // a few seconds: give up, the host reports it
     }
   }
   __syncthreads();
