@@ -769,7 +769,9 @@ static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
   if (c->tune_nwaves == 1 || c->tune_nwaves == 2 || c->tune_nwaves == 4) g.nwaves = c->tune_nwaves;
   // staging: PRE float4 per thread per round, one round if it can cover the (padded) vector
   const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 64 * g.nwaves;
-  g.pre = (npad4 <= nth) ? 1 : (npad4 <= 2 * nth ? 2 : 4);
+  // one staging round whenever 12 float4 per thread cover the vector (w2 of Llama-2-7B: 11008 floats = 2752 float4 on 256
+  // threads): every extra round is one more dependent L2 round trip in front of the first FMA
+  g.pre = (npad4 <= nth) ? 1 : (npad4 <= 2 * nth ? 2 : (npad4 <= 4 * nth ? 4 : 12));
   int grid = (groups + g.nwaves - 1) / g.nwaves;
   // persistent grid: 2 workgroups (8 waves) per CU, each wave looping over row groups with both register sets
   // full, measured best on the 7B shapes (129.6 us of GEMV per layer vs 134.1 at 6 per CU)
@@ -878,7 +880,7 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   const size_t lds = (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
 #define L2_LAUNCH(UU, PP) do { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \
                                launch_probed(c, phase_kernel<MODE, 2, UU, PP>, grid, block, lds, st, a, MODE == MODE_W13); } while (0)
-#define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else L2_LAUNCH(UU, 4); } while (0)
+#define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else if (g.pre == 4) L2_LAUNCH(UU, 4); else L2_LAUNCH(UU, 12); } while (0)
   if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
 #undef L2_LAUNCH_U
 #undef L2_LAUNCH
