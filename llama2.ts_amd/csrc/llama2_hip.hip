@@ -1585,7 +1585,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
 }
 
 extern "C" int l2_debug_running_sums(int device, const float* values, size_t n, double* sums_out) {
-  if (!values || !sums_out || n == 0 || n > (size_t)1 << 28) return fail(L2_E_ARG, "bad argument");
+  if (!values || !sums_out || n == 0 || n > (size_t)l2s::MAX_VOCAB) return fail(L2_E_ARG, "bad argument (1 .. %d values)", (int)l2s::MAX_VOCAB);
   HIPCHK(hipSetDevice(device));
   float* dx = nullptr; double* dp = nullptr;
   HIPCHK(hipMalloc(&dx, n * 4));

@@ -18,11 +18,25 @@ struct Sampler {
   size_t sort_temp_bytes = 0;
   double* params = nullptr;      // device {temperature, topp}
   unsigned long long* rng = nullptr;   // device xorshift* state (the reference's BigInt rng_seed)
-  double* prefix = nullptr;      // (V) running sums (exact parallel form)
+  // whole-chip form: tiles of 1024 elements (sampler.hip)
+  int G = 0;                     // tiles
+  float* run_p = nullptr;        // (G * 1024) tiles sorted one by one (top-p)
+  double* part = nullptr;        // (G) approximate tile sums
+  void* recs = nullptr;          // (G * 1025) xs::Run records
+  int* cnt = nullptr;            // (G) records per tile
+  int* off = nullptr;            // (G + 1)
+  double* runS = nullptr;        // per run: exact running sum after it
+  int* runEnd = nullptr;
+  int* runBad = nullptr;
+  unsigned long long* cq = nullptr;   // (G * 1024) per element: grid composite since the start of its run
+  int* cm = nullptr;
+  double* sum = nullptr;         // softmax denominator
+  unsigned* mxkey = nullptr;     // max of the scaled logits (order-preserving key), zero between tokens
+  bool own_sort = false;         // top-p order by tile sort + rank merge (vocabularies up to 40 960); else rocPRIM radix sort
   bool serial = false;           // L2_SAMPLER_SERIAL=1: one lane accumulates (the straightforward form, kept for A/B)
 };
 
-enum { MAX_VOCAB = 512 * 1024 };   // boundary-prefix table: 1024 segments of 512
+enum { MAX_VOCAB = 256 * 1024 };   // one chain thread per 1024-element tile
 
 hipError_t create(Sampler* s, int V);
 void destroy(Sampler* s);
@@ -32,7 +46,8 @@ void destroy(Sampler* s);
 // (0 < topp < 1); temperature and topp themselves are read from s.params at run time.
 hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, hipStream_t st);
 
-// Diagnostic: running sums S_i = fl(S_{i-1} + x_i) of n non-negative fp32 values, by the exact parallel algorithm.
+// Diagnostic: running sums S_i = fl(S_{i-1} + x_i) of n <= MAX_VOCAB non-negative fp32 values, by the exact parallel
+// algorithm (synchronous).
 hipError_t running_sums(const float* x_dev, int n, double* prefix_dev, hipStream_t st);
 
 }  // namespace l2s

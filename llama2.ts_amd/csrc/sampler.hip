@@ -3,15 +3,22 @@
 //
 // What makes that non-trivial: the reference's sums are sequential fp64 accumulations of fp32 values
 // (softmax :189, sample :369/:373, sample_topp :385/:391) and the chosen index depends on comparing a random
-// threshold against those running sums.  A parallel (tree) sum differs in the last bits and can flip an index,
-// so every running sum here is produced by ONE lane adding in index order -- ~10 cycles per element, ~130 us per
-// pass over 32 000 values -- while everything that is elementwise (divide, exp, normalise, search) uses the
-// whole 1024-thread workgroup.  The index search avoids a second full sequential pass: the running sum is
-// recorded at every 512th element; once the threshold is known the (monotone) boundary values locate the
-// segment of the first crossing and only that segment is re-accumulated from its exact starting value.
-// The descending stable sort of sample_topp (Array.prototype.sort is stable in V8 >= 7.0) is rocPRIM's radix sort
-// on (probability, id) pairs: stable, so ties stay in id order.
+// threshold against those running sums, so a tree sum (different in the last bits) can flip a token.
+//
+// Default form (whole chip, ~10 short launches per token):
+//   max -> exp + tile sums -> runs -> chain (exact sum) -> normalise + tile sums -> [top-p: tile sort -> rank merge ->
+//   tile sums] -> runs -> chain (exact running sums, threshold, search, advance)
+// "runs" / "chain" are exact_sum.h: every 1024-element tile turns its elements into integer increments on the grid its
+// approximate prefix predicts, one lane walks the ~50 runs of a 32 000-element vector with exact fp64 state, checking
+// every prediction, and the searched index is evaluated inside the one run that contains it.  Bit-identical to the
+// serial loop by construction (tests/test_exact_sum_cpu.py on the host, l2_debug_running_sums on the GPU).
+// The descending stable sort of sample_topp (Array.prototype.sort is stable in V8 >= 7.0) is a bitonic sort of
+// (probability, id) keys per tile followed by one rank-by-binary-search merge of the 32 sorted tiles out of LDS.
+//
+// L2_SAMPLER_SERIAL=1 keeps the straightforward form for A/B: ONE lane adds in index order (~10 cycles per element,
+// ~130 us per pass over 32 000 values) inside a single 1024-thread workgroup, rocPRIM's radix sort for top-p.
 #include "sampler.h"
+#include "exact_sum.h"
 
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
@@ -20,7 +27,7 @@ namespace l2s {
 
 #pragma clang fp contract(off)
 
-constexpr int NT = 1024;     // threads of the one workgroup
+constexpr int NT = 1024;     // threads of the one workgroup of the serial form
 constexpr int CH = 4096;     // values staged in LDS per chunk, widened to fp64 (32 KB)
 constexpr int SEG = 512;     // spacing of recorded running sums
 constexpr int MAXSEG = MAX_VOCAB / SEG;
@@ -215,305 +222,730 @@ __global__ void __launch_bounds__(NT) topp_kernel(const float* sorted, const int
 }
 
 
+
+
 // ------------------------------------------------------------------------------------------------
-// The same running sums, exactly, but in parallel.
-//
-// S_i = fl(S_{i-1} + x_i) with x_i >= 0 fp32 and S fp64 is a serial recurrence, and on this chip a dependent
-// v_add_f64 costs ~19 cycles: 2 x 32 000 of them are 0.5 ms per sampled token.  But while the exponent E of S
-// does not change, S lives on the grid g = 2^(E-52), S = M g with 2^52 <= M < 2^53, and rounding S + x to
-// nearest is M + rn(x / g) -- integer arithmetic, associative -- except that a tie (x / g = k + 1/2) goes to the
-// EVEN neighbour, which depends on the parity of the running M.  After a tie the sum is even by construction, so
-// the parity seen by every element is a segmented XOR scan with ties as reset points.  So, per window of 4096
-// elements and per exponent: (1) every thread reduces its elements to (k, tie?) on the current grid,
-// (2) a block scan gives each element the parity in front of it, which settles the ties, (3) a saturating block
-// scan of the integer increments gives every M_i at once, (4) the first element that reaches 2^53 (S crosses a
-// power of two -- ~17 times over a whole pass) is added the ordinary way and the grid is re-based there.
-// Bit-identical to the serial loop by construction; checked against the oracle's loop on adversarial vectors
-// (ties, power-of-two crossings, zeros, subnormals) through l2_debug_running_sums.
-constexpr int IT = 4, WIN = NT * IT;   // measured: 4 beats 8 and 16 (per-thread work, not barriers, sets the iteration time)
-constexpr unsigned long long TWO52 = 1ull << 52, TWO53 = 1ull << 53, CAP = 1ull << 54;
+// The whole-chip form.  A vector is cut into tiles of TILE = 1024 consecutive elements, one 256-thread workgroup per
+// tile, IT = 4 consecutive elements per thread.
+constexpr int TN = 256, IT = 4, TILE = TN * IT, NWV = TN / 64;
+constexpr int RUN_CAP = 1024;                  // runs the chain stages in LDS (a 32 000-element softmax has ~50)
+static_assert(MAX_VOCAB <= TN * TILE, "one chain thread per tile");
 
-struct SatAdd {
-  __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const {
-    const unsigned long long s = a + b;
-    return s > CAP ? CAP : s;
-  }
-};
-struct ParityOp {   // bit 1: a tie (reset to even) lies inside the range; bit 0: XOR of the increments after the last reset
-  __device__ __forceinline__ int operator()(int a, int b) const { return (b & 2) ? b : ((a & 2) | ((a ^ b) & 1)); }
-};
+using xs::Comp;
+using xs::Run;
+using xs::E_NONE;
 
-typedef hipcub::BlockScan<int, NT, hipcub::BLOCK_SCAN_WARP_SCANS> ParScan;
-typedef hipcub::BlockScan<unsigned long long, NT, hipcub::BLOCK_SCAN_WARP_SCANS> SumScan;
-struct ExactShared {
-  union { typename ParScan::TempStorage par; typename SumScan::TempStorage sum; } scan;
-  double S;
-  int first;
-};
+// Scan element: composite of the open run (q0, d), its grid E, "a run starts inside the range" (flag) and the number of
+// serial elements in the range (cnt), the last four packed into one word so that a lane exchange moves three dwords:
+//   meta = d + 1 (bits 0-1) | flag (bit 2) | cnt (bits 4-15) | E (bits 16-31)
+struct Seg { unsigned long long q0; int meta; };
+constexpr int SEG_CNT = 0xfff0, SEG_FLAG = 4, SEG_ID = 1 | (int)((unsigned)E_NONE << 16);   // identity: d = 0, no grid
 
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+__device__ __forceinline__ Seg seg_identity() { Seg s; s.q0 = 0; s.meta = SEG_ID; return s; }
+__device__ __forceinline__ Seg seg_make(const Comp& c, int E, bool flag, bool serial) {
+  Seg s; s.q0 = c.q0; s.meta = (c.d + 1) | (flag ? SEG_FLAG : 0) | (serial ? 16 : 0) | (int)((unsigned)E << 16);
+  return s;
+}
+__device__ __forceinline__ int seg_d(const Seg& s) { return (s.meta & 3) - 1; }
+__device__ __forceinline__ int seg_E(const Seg& s) { return s.meta >> 16; }
+__device__ __forceinline__ int seg_cnt(const Seg& s) { return (s.meta & SEG_CNT) >> 4; }
+__device__ __forceinline__ Seg seg_op(const Seg& a, const Seg& b) {            // a first, then b
+  const int cnt = (a.meta & SEG_CNT) + (b.meta & SEG_CNT);
+  Seg r;
+  if (b.meta & SEG_FLAG) { r.q0 = b.q0; r.meta = (b.meta & ~SEG_CNT) | cnt; return r; }
+  Comp ca; ca.q0 = a.q0; ca.d = seg_d(a);
+  Comp cb; cb.q0 = b.q0; cb.d = seg_d(b);
+  const Comp c = xs::compose(ca, cb);
+  const int e = (seg_E(b) != E_NONE) ? (b.meta & (int)0xffff0000) : (a.meta & (int)0xffff0000);
+  r.q0 = c.q0; r.meta = e | cnt | (a.meta & SEG_FLAG) | (c.d + 1);
+  return r;
+}
+
+// Lane exchanges of the wave scans: data-parallel primitives, no LDS.  `old` is what a lane without a source keeps.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {                          // identity 0.0
+  return __hiloint2double(dpp_i32<CTRL, ROW_MASK>(0, __double2hiint(v)), dpp_i32<CTRL, ROW_MASK>(0, __double2loint(v)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Seg dpp_seg(const Seg& v) {
+  Seg r;
+  r.q0 = ((unsigned long long)(unsigned)dpp_i32<CTRL, ROW_MASK>(0, (int)(v.q0 >> 32)) << 32) | (unsigned)dpp_i32<CTRL, ROW_MASK>(0, (int)v.q0);
+  r.meta = dpp_i32<CTRL, ROW_MASK>(SEG_ID, v.meta);
+  return r;
+}
+// inclusive scans over the 64 lanes: row_shr 1, 2, 4, 8, then row 0 -> 1 and 2 -> 3 (row_bcast:15), rows 0-1 -> 2-3 (row_bcast:31)
+__device__ __forceinline__ double wave_scan_f64(double v) {
+  v += dpp_f64<0x111, 0xf>(v); v += dpp_f64<0x112, 0xf>(v); v += dpp_f64<0x114, 0xf>(v); v += dpp_f64<0x118, 0xf>(v);
+  v += dpp_f64<0x142, 0xa>(v); v += dpp_f64<0x143, 0xc>(v);
+  return v;
+}
+__device__ __forceinline__ Seg wave_scan_seg(Seg v) {
+  v = seg_op(dpp_seg<0x111, 0xf>(v), v); v = seg_op(dpp_seg<0x112, 0xf>(v), v); v = seg_op(dpp_seg<0x114, 0xf>(v), v);
+  v = seg_op(dpp_seg<0x118, 0xf>(v), v); v = seg_op(dpp_seg<0x142, 0xa>(v), v); v = seg_op(dpp_seg<0x143, 0xc>(v), v);
   return v;
 }
 
-// prefix[i] (may be null) = S_i for i in [0, n); returns S_{n-1} (0 for n = 0).  Whole workgroup, uniform control flow.
-// Windows are fixed ([w0, w0 + WIN), values held in registers); inside a window `pos` moves forward at every
-// power-of-two crossing and elements in front of it are final.  The first HEAD elements are added by one lane:
-// while S is still small nearly every add crosses a power of two, so the grid trick has nothing to work with there.
-constexpr int HEAD = 512;
-__device__ __forceinline__ double exact_running_sums(const float* x, int n, double* prefix, ExactShared& sh, double* headbuf) {
-  const int tid = threadIdx.x;
-  const int nh = min(n, HEAD);
-  for (int i = tid; i < nh; i += NT) headbuf[i] = (double)x[i];
-  __syncthreads();
-  if (tid == 0) {
-    double a = 0.0;
-    for (int i = 0; i < nh; ++i) { a += headbuf[i]; headbuf[i] = a; }
-    sh.S = a;
+struct TileShared {
+  double wsum[NWV];
+  int wser[NWV];
+  Seg wagg[NWV];
+};
+
+__device__ __forceinline__ void load_tile(const float* x, int V, int tile, float (&v)[IT]) {
+  const int i0 = tile * TILE + threadIdx.x * IT;
+  if (i0 + IT <= V && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const float4 q = *reinterpret_cast<const float4*>(x + i0);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < IT; ++k) v[k] = (i0 + k < V) ? x[i0 + k] : 0.0f;
   }
+}
+
+// Approximate sum of one tile (any fixed order); every thread gets the same value.
+__device__ __forceinline__ double tile_total(const float (&v)[IT], double* wsum) {
+  double t = ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
   __syncthreads();
-  if (prefix) for (int i = tid; i < nh; i += NT) prefix[i] = headbuf[i];
-  double S = sh.S;
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = t;
   __syncthreads();
-  for (int w0 = nh; w0 < n; w0 += WIN) {
-    const int wend = min(n, w0 + WIN);
-    const int i0 = w0 + tid * IT;                      // blocked arrangement: thread t owns IT consecutive elements
-    float xv[IT];
+  return (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// Approximate sum of the tiles in front of `tile`; the same instruction sequence in every kernel that needs it, and a
+// butterfly of commutative adds, so every lane of every wave holds the same bits.
+__device__ __forceinline__ double tile_base(const double* part, int tile) {
+  double s = 0.0;
+  for (int j = threadIdx.x & 63; j < tile; j += 64) s += part[j];
 #pragma unroll
-    for (int k = 0; k < IT; ++k) xv[k] = (i0 + k < wend) ? x[i0 + k] : 0.0f;
-    int pos = w0;
-    while (pos < wend) {
-      if (tid == 0) sh.first = 0x7fffffff;
-      __syncthreads();
-      if (S == 0.0) {                                  // leading zeros: 0 + x is exact, the first non-zero value becomes S
-        int f = 0x7fffffff;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  return s;
+}
+
+struct Elems {
+  Seg inc[IT];        // inclusive segmented scan at the element: composite of the regular elements of its run up to it, .cnt serial elements up to it
+  bool serial[IT];
+};
+
+// Classify the tile's elements (exact_sum.h) and scan their grid composites run by run.
+__device__ __forceinline__ void tile_scan(const float (&v)[IT], double base, TileShared& sh, Elems& o) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double a[IT];
+  a[0] = (double)v[0];
 #pragma unroll
-        for (int k = IT - 1; k >= 0; --k) if (i0 + k >= pos && i0 + k < wend && xv[k] != 0.0f) f = i0 + k;
-        f = wave_min_i32(f);
-        if ((tid & 63) == 0 && f != 0x7fffffff) atomicMin(&sh.first, f);
-        __syncthreads();
-        const int first = sh.first;
-        const int upto = min(first, wend);
+  for (int k = 1; k < IT; ++k) a[k] = a[k - 1] + (double)v[k];
+  const double incl = wave_scan_f64(a[IT - 1]);
+  __syncthreads();                                         // sh may still be read by a previous call
+  if (lane == 63) sh.wsum[wave] = incl;
+  __syncthreads();
+  double wbase = 0.0;
+  for (int w = 0; w < wave; ++w) wbase += sh.wsum[w];
+  const double tb = (base + wbase) + dpp_f64<0x138, 0xf>(incl);   // wave_shr:1 -- the lane in front, 0 for lane 0
+
+  bool ser[IT];
+  int eE[IT];
+  // the common case first: the whole thread sits in one binade, nothing to decide per element
+  int Eq;
+  const bool quiet = !xs::classify(tb, tb + a[IT - 1], 1.0f, &Eq);
 #pragma unroll
-        for (int k = 0; k < IT; ++k) {
-          const int i = i0 + k;
-          if (i >= pos && i < upto && prefix) prefix[i] = 0.0;
-          if (i == first && i < wend) { sh.S = (double)xv[k]; if (prefix) prefix[i] = (double)xv[k]; }
-        }
-        __syncthreads();
-        if (first < wend) { S = sh.S; pos = first + 1; } else pos = wend;
-        __syncthreads();
-        continue;
-      }
-      const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
-      const int E = (int)((sb >> 52) & 0x7ff) - 1023;   // S is a normal double here (>= 2^-149)
-      const unsigned long long M = (sb & (TWO52 - 1)) | TWO52;
-      unsigned long long r[IT];
-      int fv[IT];
+  for (int k = 0; k < IT; ++k) {
+    if (quiet) { ser[k] = false; eE[k] = (v[k] == 0.0f) ? E_NONE : Eq; }
+    else ser[k] = xs::classify(k ? tb + a[k - 1] : tb, tb + a[k], v[k], &eE[k]);
+  }
+  const int last = ser[IT - 1] ? 1 : 0;
+  if (lane == 63) sh.wser[wave] = last;
+  __syncthreads();
+  int prev = dpp_i32<0x138, 0xf>(0, last);
+  if (lane == 0) prev = wave ? sh.wser[wave - 1] : 1;      // a run starts with the tile
+
+  Seg l[IT];
 #pragma unroll
-      for (int k = 0; k < IT; ++k) {                    // x = m 2^lsb on the grid 2^(E-52); elements before pos are done: 0
-        const unsigned xb = (i0 + k >= pos) ? __float_as_uint(xv[k]) : 0u;
-        const int ef = (int)((xb >> 23) & 0xff);
-        const unsigned m = (xb & 0x7fffffu) | (ef ? 0x800000u : 0u);
-        const int shift = (ef ? ef - 127 : -126) - 23 - (E - 52);
-        unsigned long long q = 0;
-        int tie = 0;
-        if (m != 0) {
-          if (shift >= 0) q = (shift > 30) ? CAP : ((unsigned long long)m << shift);
-          else if (shift > -25) {
-            const int sft = -shift;
-            const unsigned rem = m & ((1u << sft) - 1u), half = 1u << (sft - 1);
-            q = (unsigned long long)(m >> sft) + (rem > half ? 1u : 0u);
-            tie = (rem == half);
-          }
-        }
-        r[k] = q;
-        fv[k] = tie ? 2 : (int)(q & 1);
-      }
-      int pin[IT];
-      ParScan(sh.scan.par).ExclusiveScan(fv, pin, 0, ParityOp());
-      __syncthreads();
-      const int p0 = (int)(M & 1);
+  for (int k = 0; k < IT; ++k) {
+    o.serial[k] = ser[k];
+    const Comp c = (ser[k] || eE[k] == E_NONE) ? xs::identity() : xs::on_grid(v[k], eE[k]);
+    const Seg e = seg_make(c, ser[k] ? E_NONE : eE[k], k ? ser[k - 1] : prev != 0, ser[k]);
+    l[k] = k ? seg_op(l[k - 1], e) : e;
+  }
+  const Seg agg = wave_scan_seg(l[IT - 1]);
+  if (lane == 63) sh.wagg[wave] = agg;
+  Seg pre = dpp_seg<0x138, 0xf>(agg);                       // exclusive: identity for lane 0
+  __syncthreads();
+  Seg wpre = seg_identity();
+  for (int w = 0; w < wave; ++w) wpre = seg_op(wpre, sh.wagg[w]);
+  pre = seg_op(wpre, pre);
 #pragma unroll
-      for (int k = 0; k < IT; ++k) {
-        if (fv[k] & 2) {                                 // tie: round half to even
-          const int before = (pin[k] & 2) ? (pin[k] & 1) : (p0 ^ (pin[k] & 1));
-          r[k] += (unsigned long long)((before + (int)(r[k] & 1)) & 1);
-        }
-      }
-      unsigned long long tex[IT];
-      SumScan(sh.scan.sum).ExclusiveScan(r, tex, 0ull, SatAdd());
-      int ov = 0x7fffffff;
+  for (int k = 0; k < IT; ++k) o.inc[k] = seg_op(pre, l[k]);
+}
+
+__device__ __forceinline__ unsigned order_key(float x) { const unsigned b = __float_as_uint(x); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float order_value(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// max over state.logits[q] / temperature (:482, softmax :183-186)
+__global__ void __launch_bounds__(TN) scaled_max_kernel(const float* logits, int V, const double* params, unsigned* mxkey) {
+  float v[IT];
+  load_tile(logits, V, blockIdx.x, v);
+  const double T = params[0];
+  const int i0 = blockIdx.x * TILE + threadIdx.x * IT;
+  unsigned key = 0;
 #pragma unroll
-      for (int k = IT - 1; k >= 0; --k) if (i0 + k >= pos && i0 + k < wend && M + SatAdd()(tex[k], r[k]) >= TWO53) ov = i0 + k;
-      ov = wave_min_i32(ov);
-      if ((tid & 63) == 0 && ov != 0x7fffffff) atomicMin(&sh.first, ov);
-      __syncthreads();
-      const int first = sh.first;                         // first element at which S reaches the next power of two
-      const int upto = min(first, wend);
-      const double g = __longlong_as_double((long long)(E - 52 + 1023) << 52);
+  for (int k = 0; k < IT; ++k) if (i0 + k < V) key = max(key, order_key((float)((double)v[k] / T)));
 #pragma unroll
-      for (int k = 0; k < IT; ++k) {
-        const int i = i0 + k;
-        if (i >= pos && i < upto) {
-          const double Si = (double)(M + tex[k] + r[k]) * g;   // < 2^53: exact
-          if (prefix) prefix[i] = Si;
-          if (i == wend - 1) sh.S = Si;
-        } else if (i == first && i < wend) {
-          const double Sn = (double)(M + tex[k]) * g + (double)xv[k];   // the ordinary add re-bases the grid
-          if (prefix) prefix[i] = Sn;
-          sh.S = Sn;
-        }
-      }
-      __syncthreads();
-      S = sh.S;
-      pos = (first < wend) ? first + 1 : wend;
-      __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(mxkey, key);
+}
+
+// probs[i] = (float)exp(x_i - max)  (:187) and the tile sums for the approximate prefix
+__global__ void __launch_bounds__(TN) exp_kernel(const float* logits, int V, const double* params, const unsigned* mxkey, float* probs, double* part) {
+  __shared__ double wsum[NWV];
+  float v[IT];
+  load_tile(logits, V, blockIdx.x, v);
+  const double T = params[0];
+  const float mx = order_value(*mxkey);
+  const int i0 = blockIdx.x * TILE + threadIdx.x * IT;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const float x = (float)((double)v[k] / T);
+    v[k] = (i0 + k < V) ? (float)exp((double)x - (double)mx) : 0.0f;
+    if (i0 + k < V) probs[i0 + k] = v[k];
+  }
+  const double t = tile_total(v, wsum);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// probs[i] /= sum  (:192) and the tile sums of the result
+__global__ void __launch_bounds__(TN) normalise_kernel(float* probs, int V, const double* sum, double* part) {
+  __shared__ double wsum[NWV];
+  float v[IT];
+  load_tile(probs, V, blockIdx.x, v);
+  const double s = *sum;
+  const int i0 = blockIdx.x * TILE + threadIdx.x * IT;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    v[k] = (i0 + k < V) ? (float)((double)v[k] / s) : 0.0f;
+    if (i0 + k < V) probs[i0 + k] = v[k];
+  }
+  const double t = tile_total(v, wsum);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(TN) tile_sums_kernel(const float* x, int V, double* part) {
+  __shared__ double wsum[NWV];
+  float v[IT];
+  load_tile(x, V, blockIdx.x, v);
+  const double t = tile_total(v, wsum);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// One record per run of the tile: recs[tile * (TILE + 1) + r], cnt[tile] of them; and per element its composite since the
+// start of its run (cq) with {d + 1, serial, grid} packed into cm, which is what the search needs to turn the exact
+// sum in front of a run into the exact running sum at any element of it.
+__device__ __forceinline__ int pack_meta(const Seg& s, bool serial) { return (s.meta & 3) | (serial ? 4 : 0) | (s.meta & (int)0xffff0000); }
+__global__ void __launch_bounds__(TN) runs_kernel(const float* x, int V, const double* part, Run* recs, int* cnt, unsigned long long* cq, int* cm) {
+  __shared__ TileShared sh;
+  float v[IT];
+  load_tile(x, V, blockIdx.x, v);
+  Elems el;
+  tile_scan(v, tile_base(part, blockIdx.x), sh, el);
+  Run* out = recs + (size_t)blockIdx.x * (TILE + 1);
+  const int i0 = blockIdx.x * TILE + threadIdx.x * IT;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const Seg& s = el.inc[k];
+    cq[i0 + k] = s.q0;
+    cm[i0 + k] = pack_meta(s, el.serial[k]);
+    const bool tile_end = threadIdx.x == TN - 1 && k == IT - 1;
+    if (el.serial[k] || tile_end) {
+      Run r; r.q0 = s.q0; r.d = seg_d(s); r.E = seg_E(s); r.x = el.serial[k] ? v[k] : 0.0f; r.end = min(i0 + k, V - 1);
+      out[el.serial[k] ? seg_cnt(s) - 1 : seg_cnt(s)] = r;
+      if (tile_end) cnt[blockIdx.x] = seg_cnt(s) + (el.serial[k] ? 0 : 1);
     }
   }
-  return S;
 }
 
-__device__ __forceinline__ float block_max_f32(float mx, float* redf) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-  if ((tid & 63) == 0) redf[tid >> 6] = mx;
-  __syncthreads();
-  mx = redf[0];
-  for (int w = 1; w < NT / 64; ++w) mx = fmaxf(mx, redf[w]);
-  return mx;
-}
+struct ChainArgs {
+  const float* x;            // the vector being accumulated
+  int V, G;
+  const double* part;
+  const Run* recs;
+  const int* cnt;
+  int* off;                  // (G + 1) first run of every tile
+  double* S;                 // per run: exact sum after it
+  int* End;                  // per run: index of its last element
+  int* Bad;                  // per run: prediction failed, its elements were added one by one
+  double* sum_out;
+  const double* params;
+  unsigned long long* rng;
+  int* tokpos;
+  int* tokens_out;
+  const unsigned long long* cq;   // per element: composite since the start of its run
+  const int* cm;
+  const int* ids;            // top-p: token ids in sorted order
+  unsigned* mxkey;           // reset for the next token
+};
 
-__device__ __forceinline__ void softmax_in_place_par(const float* logits, int V, double T, float* probs, int* idx, float* redf, ExactShared& sh, double* headbuf) {
-  const int tid = threadIdx.x;
-  float mx = -INFINITY;
-  for (int i = tid; i < V; i += NT) {
-    const float x = (float)((double)logits[i] / T);        // :482
-    probs[i] = x;
-    mx = fmaxf(mx, x);
-  }
-  mx = block_max_f32(mx, redf);
-  for (int i = tid; i < V; i += NT) probs[i] = (float)exp((double)probs[i] - (double)mx);   // :187
-  __syncthreads();
-  const double sum = exact_running_sums(probs, V, nullptr, sh, headbuf);                               // :189
-  for (int i = tid; i < V; i += NT) {
-    probs[i] = (float)((double)probs[i] / sum);             // :192
-    if (idx) idx[i] = i;
-  }
-  __syncthreads();
-}
+struct ChainShared {
+  TileShared tile;
+  Run rec[RUN_CAP];
+  double S[RUN_CAP];         // per-run state when the runs fit (else ChainArgs' arrays in global memory)
+  int End[RUN_CAP];
+  int Bad[RUN_CAP];
+  int off[TN + 1];
+  int wtot[NWV];
+  int slot;
+  double val;
+};
 
-// first i in [0, limit) with pred(prefix[i]); 0x7fffffff if none
-template <class Pred>
-__device__ __forceinline__ int first_index(const double* prefix, int limit, Pred pred, int* slot) {
+// First index i < limit whose exact running sum satisfies pred (pred is monotone in S); -1 if none.  *at = that sum.
+// Per-run state of the chain: LDS when the runs fit there, the arrays in global memory otherwise (and for the diagnostic).
+// A compile-time choice, so that no access turns into a flat instruction (those wait on both memory counters).
+template <bool IN_LDS>
+struct RunState {
+  ChainShared& sh;
+  const ChainArgs& a;
+  __device__ __forceinline__ double& S(int k) const { if (IN_LDS) return sh.S[k]; return a.S[k]; }
+  __device__ __forceinline__ int& End(int k) const { if (IN_LDS) return sh.End[k]; return a.End[k]; }
+  __device__ __forceinline__ int& Bad(int k) const { if (IN_LDS) return sh.Bad[k]; return a.Bad[k]; }
+};
+
+template <bool IN_LDS, class Pred>
+__device__ __forceinline__ int find_first(const ChainArgs& a, ChainShared& sh, const RunState<IN_LDS>& rs, int T, Pred pred, int limit, double* at) {
   const int tid = threadIdx.x;
-  if (tid == 0) *slot = 0x7fffffff;
+  __syncthreads();
+  if (tid == 0) sh.slot = 0x7fffffff;
   __syncthreads();
   int f = 0x7fffffff;
-  for (int i = tid; i < limit; i += NT) if (pred(prefix[i])) { f = i; break; }
-  if (f != 0x7fffffff) atomicMin(slot, f);
+  for (int k = tid; k < T; k += TN) if (pred(rs.S(k))) { f = k; break; }
+  if (f != 0x7fffffff) atomicMin(&sh.slot, f);
   __syncthreads();
-  const int out = *slot;
+  const int kr = sh.slot;
   __syncthreads();
-  return out;
+  if (kr == 0x7fffffff) return -1;
+  const int start = kr ? rs.End(kr - 1) + 1 : 0, end = rs.End(kr);
+  const double S0 = kr ? rs.S(kr - 1) : 0.0;
+  if (tid == 0) sh.slot = 0x7fffffff;
+  __syncthreads();
+  if (rs.Bad(kr)) {
+    if (tid == 0) {
+      double S = S0;
+      for (int j = start; j <= end && j < a.V; ++j) { S += (double)a.x[j]; if (pred(S)) { sh.slot = j; sh.val = S; break; } }
+    }
+  } else {
+    const int tile = start / TILE, i0 = tile * TILE + tid * IT;
+    unsigned long long q[IT];
+    int m[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) { q[k] = a.cq[i0 + k]; m[k] = a.cm[i0 + k]; }
+    const double Send = rs.S(kr);
+    double mine_S = 0.0;
+    int mine = 0x7fffffff;
+#pragma unroll
+    for (int k = IT - 1; k >= 0; --k) {
+      const int i = i0 + k;
+      Comp c; c.q0 = q[k]; c.d = (m[k] & 3) - 1;
+      const double Si = (m[k] & 4) ? Send : xs::value_at(S0, c, m[k] >> 16);
+      if (i >= start && i <= end && pred(Si)) { mine = i; mine_S = Si; }
+    }
+    if (mine != 0x7fffffff) atomicMin(&sh.slot, mine);
+    __syncthreads();
+    if (mine != 0x7fffffff && mine == sh.slot) sh.val = mine_S;
+  }
+  __syncthreads();
+  const int hit = sh.slot;
+  *at = sh.val;
+  return (hit != 0x7fffffff && hit < limit) ? hit : -1;
 }
 
-__global__ void __launch_bounds__(NT) sample_par_kernel(const float* logits, int V, const double* params, float* probs, double* prefix,
-                                                         unsigned long long* rng, int* tokpos, int* tokens_out) {
-  __shared__ ExactShared sh;
-  __shared__ float redf[NT / 64];
-  __shared__ double shr;
-  __shared__ int slot;
-  __shared__ double headbuf[HEAD];
-  softmax_in_place_par(logits, V, params[0], probs, nullptr, redf, sh, headbuf);
-  const double total = exact_running_sums(probs, V, prefix, sh, headbuf);
-  if (threadIdx.x == 0) shr = (double)random_f32(rng) * total;     // :370
+enum { CHAIN_SUM = 0, CHAIN_SAMPLE = 1, CHAIN_TOPP = 2, CHAIN_DEBUG = 3 };
+
+// One workgroup: order the runs, walk them with the exact fp64 state, then whatever the caller wants from the sums.
+template <int MODE, bool IN_LDS>
+__device__ __forceinline__ void chain_body(const ChainArgs& a, ChainShared& sh, int T) {
+  const int tid = threadIdx.x;
+
+  const RunState<IN_LDS> rs{sh, a};
+  // Fast walk (runs staged in LDS): lane l of wave 0 holds run l's increments, the state S is uniform, and one step is
+  // "add the increment picked by the parity of S to the BIT PATTERN of S" (that many grid steps inside the binade)
+  // followed by the ordinary add of the run's serial element: ~5 dependent instructions.  The checks ride along; if any
+  // fails (never observed) the generic loop below redoes the walk run by run with the element-wise fallback.
+  bool fast_ok = false;
+#ifdef L2_SAMPLER_TRACE
+  const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+  if (IN_LDS && tid < 64) {
+    double S = 0.0;
+    bool allok = true;
+    for (int c0 = 0; c0 < T; c0 += 64) {
+      const int k = c0 + tid;
+      Run r; r.q0 = 0; r.d = 0; r.E = E_NONE; r.x = 0.0f; r.end = 0;
+      if (k < T) r = sh.rec[k];
+      const bool has = (r.q0 | (unsigned long long)(unsigned)r.d) != 0;
+      const unsigned long long inc0 = r.q0, inc1 = r.q0 + (unsigned long long)(long long)r.d;
+      const int eb = has ? r.E + 1023 : -1;
+      const double x = (double)r.x;
+      allok = allok && r.q0 < xs::TWO53;
+      double Sk = 0.0;
+      const int n = min(64, T - c0);
+      int bad = 0;
+      for (int j = 0; j < n; ++j) {
+        const unsigned long long i0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(inc0 >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)inc0, j);
+        const unsigned long long i1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(inc1 >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)inc1, j);
+        const int e = __builtin_amdgcn_readlane(eb, j);
+        const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), j), __builtin_amdgcn_readlane(__double2loint(x), j));
+        asm volatile("" : "+v"(S));                           // keep the state in vector registers: no scalar round trip per step
+        const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
+        const unsigned long long sb2 = sb + ((sb & 1) ? i1 : i0);
+        bad |= (e >= 0) & (((int)(sb >> 52) != e) | ((int)(sb2 >> 52) != e));
+        S = __longlong_as_double((long long)sb2) + xj;
+        Sk = (tid == j) ? S : Sk;
+      }
+      allok = allok && bad == 0;
+      if (k < T) { rs.S(k) = Sk; rs.End(k) = r.end; rs.Bad(k) = 0; }
+    }
+    fast_ok = __all(allok);
+#ifdef L2_SAMPLER_TRACE
+    if (tid == 0) printf("mode %d: %d runs, fast walk ok %d, %llu clocks\n", MODE, T, (int)fast_ok, __builtin_amdgcn_s_memtime() - t2);
+#endif
+    if (tid == 0 && fast_ok) {
+      sh.val = S;
+      if (MODE == CHAIN_SUM) *a.sum_out = S;
+    }
+  }
+  if (tid == 0 && !fast_ok) {
+    double S = 0.0;
+    int start = 0;
+    auto step = [&](int k, const Run& rec) {
+      bool ok;
+      double S2 = xs::chain_step(S, rec, &ok);
+      if (!ok) {
+        S2 = S;
+        for (int j = start; j <= rec.end && j < a.V; ++j) S2 += (double)a.x[j];
+      }
+      rs.S(k) = S2; rs.End(k) = rec.end; rs.Bad(k) = ok ? 0 : 1;
+      S = S2; start = rec.end + 1;
+    };
+    if (IN_LDS) {
+      for (int k = 0; k < T; ++k) step(k, sh.rec[k]);
+    } else {
+      int k = 0;
+      for (int t = 0; t < a.G; ++t)
+        for (int r = 0, n = sh.off[t + 1] - sh.off[t]; r < n; ++r, ++k) step(k, a.recs[(size_t)t * (TILE + 1) + r]);
+    }
+    sh.val = S;
+    if (MODE == CHAIN_SUM) *a.sum_out = S;
+  }
   __syncthreads();
-  const double r = shr;
-  const int hit = first_index(prefix, V, [r](double c) { return r < c; }, &slot);   // :373
-  if (threadIdx.x == 0) advance(tokpos, tokens_out, hit == 0x7fffffff ? 0 : hit);
-}
-
-__global__ void __launch_bounds__(NT) softmax_par_kernel(const float* logits, int V, const double* params, float* probs, int* idx) {
-  __shared__ ExactShared sh;
-  __shared__ float redf[NT / 64];
-  __shared__ double headbuf[HEAD];
-  softmax_in_place_par(logits, V, params[0], probs, idx, redf, sh, headbuf);
-}
-
-__global__ void __launch_bounds__(NT) topp_par_kernel(const float* sorted, const int* sorted_idx, int V, const double* params, double* prefix,
-                                                       unsigned long long* rng, int* tokpos, int* tokens_out) {
-  __shared__ ExactShared sh;
-  __shared__ double shr;
-  __shared__ int slot;
-  __shared__ double headbuf[HEAD];
-  const double topp = params[1];
-  const double total = exact_running_sums(sorted, V, prefix, sh, headbuf);
-  const int cross = first_index(prefix, V, [topp](double c) { return c > topp; }, &slot);   // :385
-  const int last = cross == 0x7fffffff ? 0 : cross;                                        // never crossed: lastIdx stays 0
-  if (threadIdx.x == 0) shr = (double)random_f32(rng) * (cross == 0x7fffffff ? total : prefix[cross]);   // :388
+  if (MODE == CHAIN_SUM || MODE == CHAIN_DEBUG) return;
+  const double total = sh.val;
   __syncthreads();
-  const double r = shr;
-  const int hit = first_index(prefix, last, [r](double c) { return r < c; }, &slot);       // i < lastIdx (:390)
-  if (threadIdx.x == 0) advance(tokpos, tokens_out, hit == 0x7fffffff ? 0 : sorted_idx[hit]);
+  double at = 0.0;
+  if (MODE == CHAIN_SAMPLE) {
+    if (tid == 0) sh.val = (double)random_f32(a.rng) * total;                    // randValue = random_f32() * sum (:370)
+    __syncthreads();
+    const double r = sh.val;
+    const int hit = find_first(a, sh, rs, T, [r](double S) { return r < S; }, a.V, &at);   // :373
+    if (tid == 0) { advance(a.tokpos, a.tokens_out, hit < 0 ? 0 : hit); *a.mxkey = 0; }   // fall-through returns 0 (:375)
+  } else {
+    const double topp = a.params[1];
+    const int cross = find_first(a, sh, rs, T, [topp](double S) { return S > topp; }, a.V, &at);   // :385
+    const int last = cross < 0 ? 0 : cross;                                      // never crossed: lastIdx stays 0 (:383)
+    __syncthreads();
+    if (tid == 0) sh.val = (double)random_f32(a.rng) * (cross < 0 ? total : at);  // cumProb as the loop left it (:388)
+    __syncthreads();
+    const double r = sh.val;
+    const int hit = find_first(a, sh, rs, T, [r](double S) { return r < S; }, last, &at);   // i < lastIdx only (:390)
+    if (tid == 0) { advance(a.tokpos, a.tokens_out, hit < 0 ? 0 : a.ids[hit]); *a.mxkey = 0; }
+  }
 }
 
-// Diagnostic: the running sums of an arbitrary vector (tests of exact_running_sums against the oracle's serial loop).
-__global__ void __launch_bounds__(NT) running_sums_kernel(const float* x, int n, double* prefix) {
-  __shared__ ExactShared sh;
-  __shared__ double headbuf[HEAD];
-  exact_running_sums(x, n, prefix, sh, headbuf);
+template <int MODE>
+__global__ void __launch_bounds__(TN) chain_kernel(ChainArgs a) {
+  __shared__ ChainShared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = tid < a.G ? a.cnt[tid] : 0;
+  Run r0, r1;                                              // nearly every tile has one or two runs: fetched together with the count
+  if (tid < a.G) { r0 = a.recs[(size_t)tid * (TILE + 1)]; r1 = a.recs[(size_t)tid * (TILE + 1) + 1]; }
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+  if (lane == 63) sh.wtot[wave] = incl;
+  __syncthreads();
+  int wb = 0;
+  for (int w = 0; w < wave; ++w) wb += sh.wtot[w];
+  const int first = wb + incl - c;
+  sh.off[tid] = first;
+  if (tid == TN - 1) sh.off[TN] = first + c;
+  if (MODE == CHAIN_DEBUG) { if (tid < a.G) a.off[tid] = first; if (tid == TN - 1) a.off[a.G] = first + c; }
+  __syncthreads();
+  const int T = sh.off[TN];
+  if (MODE != CHAIN_DEBUG && T <= RUN_CAP) {
+    if (tid < a.G) {
+      if (c > 0) sh.rec[first] = r0;
+      if (c > 1) sh.rec[first + 1] = r1;
+      for (int r = 2; r < c; ++r) sh.rec[first + r] = a.recs[(size_t)tid * (TILE + 1) + r];
+    }
+    __syncthreads();
+    chain_body<MODE, true>(a, sh, T);
+  } else {
+    chain_body<MODE, false>(a, sh, T);
+  }
+}
+
+// Diagnostic (l2_debug_running_sums): every running sum, from the chain's per-run state.
+__global__ void __launch_bounds__(TN) prefix_kernel(const float* x, int V, const double* part, const int* off, const double* S, const int* Bad,
+                                                     const int* End, double* prefix) {
+  __shared__ TileShared sh;
+  float v[IT];
+  load_tile(x, V, blockIdx.x, v);
+  Elems el;
+  tile_scan(v, tile_base(part, blockIdx.x), sh, el);
+  const int i0 = blockIdx.x * TILE + threadIdx.x * IT, k0 = off[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = i0 + k;
+    if (i >= V) continue;
+    const int run = k0 + seg_cnt(el.inc[k]) - (el.serial[k] ? 1 : 0);
+    if (Bad[run]) continue;
+    Comp c; c.q0 = el.inc[k].q0; c.d = seg_d(el.inc[k]);
+    prefix[i] = el.serial[k] ? S[run] : xs::value_at(run ? S[run - 1] : 0.0, c, seg_E(el.inc[k]));
+  }
+  if (threadIdx.x == 0) {
+    for (int run = k0; run < off[blockIdx.x + 1]; ++run) {
+      if (!Bad[run]) continue;
+      double acc = run ? S[run - 1] : 0.0;
+      for (int j = run ? End[run - 1] + 1 : 0; j <= End[run] && j < V; ++j) { acc += (double)x[j]; prefix[j] = acc; }
+    }
+  }
+}
+
+// ---- top-p: descending stable order = ascending order of the key (~probability bits, id)
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void order_pair(u64& a, u64& b, bool up) {
+  const bool sw = (a > b) == up;
+  const u64 lo = sw ? b : a, hi = sw ? a : b;
+  a = lo; b = hi;
+}
+
+// Bitonic sort of one tile's 1024 keys: 4 consecutive positions per thread, so strides 1 and 2 stay inside a thread,
+// strides 4..128 are lane exchanges inside a wave, and only strides 256 / 512 (3 of the 55 stages) go through LDS.
+template <bool FUSED>
+__global__ void __launch_bounds__(TN) sort_tile_kernel(const float* probs, int V, const double* sum, float* run_p, int* run_id) {
+  __shared__ u64 xch[TILE];
+  const int tid = threadIdx.x, base = blockIdx.x * TILE, p0 = tid * IT;
+  float pv[IT];
+  load_tile(probs, V, blockIdx.x, pv);
+  u64 v[IT];
+  const double s = FUSED ? *sum : 1.0;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = base + p0 + k;
+    const float p = FUSED ? (float)((double)pv[k] / s) : pv[k];              // FUSED: probs still holds the exps (:192)
+    v[k] = (i < V) ? (((u64)(0xffffffffu - __float_as_uint(p)) << 32) | (unsigned)i) : ~0ull;
+  }
+#pragma unroll
+  for (int k2 = 2; k2 <= TILE; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      if (j == 1) {
+        order_pair(v[0], v[1], ((p0 + 0) & k2) == 0);
+        order_pair(v[2], v[3], ((p0 + 2) & k2) == 0);
+      } else if (j == 2) {
+        order_pair(v[0], v[2], ((p0 + 0) & k2) == 0);
+        order_pair(v[1], v[3], ((p0 + 1) & k2) == 0);
+      } else {
+        const bool keep_min = ((p0 & j) == 0) == ((p0 & k2) == 0);
+        u64 o[IT];
+        if (j < 64 * IT) {
+#pragma unroll
+          for (int k = 0; k < IT; ++k) o[k] = __shfl_xor(v[k], j / IT, 64);
+        } else {
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < IT; ++k) xch[p0 + k] = v[k];
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < IT; ++k) o[k] = xch[(p0 ^ j) + k];
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) v[k] = keep_min ? (v[k] < o[k] ? v[k] : o[k]) : (v[k] > o[k] ? v[k] : o[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const bool pad = v[k] == ~0ull;
+    run_p[base + p0 + k] = pad ? -1.0f : __uint_as_float(0xffffffffu - (unsigned)(v[k] >> 32));
+    run_id[base + p0 + k] = pad ? -1 : (int)(unsigned)v[k];
+  }
+}
+
+// Every element's place in the merged order: its place in its own tile + the number of elements of every other tile
+// in front of it (ties: the tile with the smaller ids first), by binary search in the G sorted tiles held in LDS.
+constexpr int RT = 512;                                           // threads = elements per workgroup of the rank merge
+__global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const int* run_id, int G, float* sorted, int* ids) {
+  extern __shared__ int lds_p[];                                // G * TILE probability bit patterns (pads: negative)
+  const int tid = threadIdx.x, n = G * TILE;
+  constexpr int B = 8;                                          // 16-byte loads in flight per thread
+  for (int j0 = tid * 4; j0 < n; j0 += RT * 4 * B) {
+    int4 q[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) q[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(run_p) + min(j0 + u * RT * 4, n - 4));
+#pragma unroll
+    for (int u = 0; u < B; ++u) if (j0 + u * RT * 4 < n) *reinterpret_cast<int4*>(lds_p + j0 + u * RT * 4) = q[u];
+  }
+  const int e = blockIdx.x * RT + tid;
+  const int my_id = e < n ? run_id[e] : -1;
+  __syncthreads();
+  if (e >= n) return;
+  const int mine = lds_p[e];
+  if (mine < 0) return;                                         // pad
+  const int own = e / TILE;
+  int rank = e - own * TILE;
+  constexpr int U = 8;                                          // searches in flight per thread
+  for (int b0 = 0; b0 < G; b0 += U) {
+    int lo[U], thr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = min(b0 + u, G - 1);
+      lo[u] = b * TILE;
+      thr[u] = mine - (b < own ? 1 : 0);                        // earlier tile: elements >= mine come first; later tile: only > mine
+    }
+#pragma unroll
+    for (int s = TILE / 2; s > 0; s >>= 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (lds_p[lo[u] + s - 1] > thr[u]) lo[u] += s;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = min(b0 + u, G - 1);
+      int cnt = lo[u] - b * TILE;
+      if (cnt == TILE - 1 && lds_p[lo[u]] > thr[u]) cnt = TILE;
+      if (b0 + u < G && b != own) rank += cnt;
+    }
+  }
+  sorted[rank] = __int_as_float(mine);
+  ids[rank] = my_id;
+}
+
+static hipError_t enqueue_exact(const Sampler& s, const float* x, int mode, int* tokpos, int* tokens_out, const int* ids, hipStream_t st) {
+  hipLaunchKernelGGL(runs_kernel, dim3(s.G), dim3(TN), 0, st, x, s.V, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
+  ChainArgs a;
+  a.x = x; a.V = s.V; a.G = s.G; a.part = s.part; a.recs = (const Run*)s.recs; a.cnt = s.cnt; a.off = s.off; a.S = s.runS; a.End = s.runEnd;
+  a.Bad = s.runBad; a.cq = s.cq; a.cm = s.cm; a.sum_out = s.sum; a.params = s.params; a.rng = s.rng; a.tokpos = tokpos; a.tokens_out = tokens_out; a.ids = ids; a.mxkey = s.mxkey;
+  if (mode == CHAIN_SUM) hipLaunchKernelGGL(chain_kernel<CHAIN_SUM>, dim3(1), dim3(TN), 0, st, a);
+  else if (mode == CHAIN_SAMPLE) hipLaunchKernelGGL(chain_kernel<CHAIN_SAMPLE>, dim3(1), dim3(TN), 0, st, a);
+  else if (mode == CHAIN_TOPP) hipLaunchKernelGGL(chain_kernel<CHAIN_TOPP>, dim3(1), dim3(TN), 0, st, a);
+  else hipLaunchKernelGGL(chain_kernel<CHAIN_DEBUG>, dim3(1), dim3(TN), 0, st, a);
+  return hipGetLastError();
 }
 
 hipError_t running_sums(const float* x_dev, int n, double* prefix_dev, hipStream_t st) {
-  hipLaunchKernelGGL(running_sums_kernel, dim3(1), dim3(NT), 0, st, x_dev, n, prefix_dev);
-  return hipGetLastError();
+  Sampler s;
+  hipError_t e = create(&s, n);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(tile_sums_kernel, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part);
+  e = enqueue_exact(s, x_dev, CHAIN_DEBUG, nullptr, nullptr, nullptr, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(prefix_kernel, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part, s.off, s.runS, s.runBad, s.runEnd, prefix_dev);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  destroy(&s);
+  return e;
 }
 
 hipError_t create(Sampler* s, int V) {
   if (V <= 0 || V > MAX_VOCAB) return hipErrorInvalidValue;
   s->V = V;
+  s->G = (V + TILE - 1) / TILE;
   hipError_t e;
 #define L2S(x) do { e = (x); if (e != hipSuccess) { destroy(s); return e; } } while (0)
   L2S(hipMalloc(&s->probs, (size_t)V * 4));
-  L2S(hipMalloc(&s->probs_sorted, (size_t)V * 4));
-  L2S(hipMalloc(&s->idx, (size_t)V * 4));
-  L2S(hipMalloc(&s->idx_sorted, (size_t)V * 4));
+  L2S(hipMalloc(&s->probs_sorted, (size_t)s->G * TILE * 4));
+  L2S(hipMalloc(&s->idx, (size_t)s->G * TILE * 4));
+  L2S(hipMalloc(&s->idx_sorted, (size_t)s->G * TILE * 4));
+  L2S(hipMalloc(&s->run_p, (size_t)s->G * TILE * 4));
   L2S(hipMalloc(&s->params, 2 * sizeof(double)));
   L2S(hipMalloc(&s->rng, sizeof(unsigned long long)));
-  L2S(hipMalloc(&s->prefix, (size_t)V * sizeof(double)));
+  L2S(hipMalloc(&s->part, (size_t)s->G * sizeof(double)));
+  L2S(hipMalloc(&s->recs, (size_t)s->G * (TILE + 1) * sizeof(Run)));
+  L2S(hipMalloc(&s->cnt, (size_t)s->G * sizeof(int)));
+  L2S(hipMalloc(&s->off, (size_t)(s->G + 1) * sizeof(int)));
+  const size_t max_runs = (size_t)s->G * (TILE + 1);
+  L2S(hipMalloc(&s->runS, max_runs * sizeof(double)));
+  L2S(hipMalloc(&s->runEnd, max_runs * sizeof(int)));
+  L2S(hipMalloc(&s->runBad, max_runs * sizeof(int)));
+  L2S(hipMalloc(&s->cq, (size_t)s->G * TILE * sizeof(unsigned long long)));
+  L2S(hipMalloc(&s->cm, (size_t)s->G * TILE * sizeof(int)));
+  L2S(hipMalloc(&s->sum, sizeof(double)));
+  L2S(hipMalloc(&s->mxkey, sizeof(unsigned)));
+  L2S(hipMemset(s->mxkey, 0, sizeof(unsigned)));
   { const char* e_ = getenv("L2_SAMPLER_SERIAL"); s->serial = e_ && atoi(e_) != 0; }
+  // the rank merge holds every tile in LDS: 4 bytes per (padded) element of the 160 KB
+  s->own_sort = !s->serial && (size_t)s->G * TILE * 4 <= 160 * 1024;
+  if (s->own_sort) L2S(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->G * TILE * 4));
   s->sort_temp_bytes = 0;
-  L2S(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, s->sort_temp_bytes, s->probs, s->probs_sorted, s->idx, s->idx_sorted, V, 0, 32, nullptr));
-  L2S(hipMalloc(&s->sort_temp, s->sort_temp_bytes ? s->sort_temp_bytes : 16));
+  if (!s->own_sort) {
+    L2S(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, s->sort_temp_bytes, s->probs, s->probs_sorted, s->idx, s->idx_sorted, V, 0, 32, nullptr));
+    L2S(hipMalloc(&s->sort_temp, s->sort_temp_bytes ? s->sort_temp_bytes : 16));
+  }
 #undef L2S
   return hipSuccess;
 }
 
 void destroy(Sampler* s) {
-  void* bufs[] = {s->probs, s->probs_sorted, s->idx, s->idx_sorted, s->params, s->rng, s->sort_temp, s->prefix};
+  void* bufs[] = {s->probs, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->sort_temp, s->part, s->recs, s->cnt, s->off,
+                  s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->sum, s->mxkey};
   for (void* b : bufs) if (b) (void)hipFree(b);
   *s = Sampler();
 }
 
+__global__ void iota_kernel(int* idx, int V) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < V) idx[i] = i;
+}
+
 hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, hipStream_t st) {
-  if (!topp_mode) {
-    if (s.serial) hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.rng, tokpos, tokens_out);
-    else hipLaunchKernelGGL(sample_par_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.prefix, s.rng, tokpos, tokens_out);
+  hipError_t e;
+  if (s.serial) {
+    if (!topp_mode) {
+      hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.rng, tokpos, tokens_out);
+      return hipGetLastError();
+    }
+    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.idx);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    size_t bytes = s.sort_temp_bytes;
+    e = hipcub::DeviceRadixSort::SortPairsDescending(s.sort_temp, bytes, s.probs, s.probs_sorted, s.idx, s.idx_sorted, s.V, 0, 32, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(topp_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.rng, tokpos, tokens_out);
     return hipGetLastError();
   }
-  if (s.serial) hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.idx);
-  else hipLaunchKernelGGL(softmax_par_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.idx);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  size_t bytes = s.sort_temp_bytes;
-  e = hipcub::DeviceRadixSort::SortPairsDescending(s.sort_temp, bytes, s.probs, s.probs_sorted, s.idx, s.idx_sorted, s.V, 0, 32, st);
-  if (e != hipSuccess) return e;
-  if (s.serial) hipLaunchKernelGGL(topp_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.rng, tokpos, tokens_out);
-  else hipLaunchKernelGGL(topp_par_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.prefix, s.rng, tokpos, tokens_out);
-  return hipGetLastError();
+  // temperature + softmax (:481-485, :181-194)
+  hipLaunchKernelGGL(scaled_max_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey);
+  hipLaunchKernelGGL(exp_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey, s.probs, s.part);
+  if ((e = enqueue_exact(s, s.probs, CHAIN_SUM, nullptr, nullptr, nullptr, st)) != hipSuccess) return e;
+  if (!topp_mode) {                                                             // sample (:368-376)
+    hipLaunchKernelGGL(normalise_kernel, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.sum, s.part);
+    return enqueue_exact(s, s.probs, CHAIN_SAMPLE, tokpos, tokens_out, nullptr, st);
+  }
+  // sample_topp (:378-394)
+  if (s.own_sort) {                                                             // the division by the sum happens on the way into the sort
+    hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.sum, s.run_p, s.idx);
+    const int n = s.G * TILE;
+    hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT), dim3(RT), (size_t)n * 4, st, s.run_p, s.idx, s.G, s.probs_sorted, s.idx_sorted);
+  } else {
+    hipLaunchKernelGGL(normalise_kernel, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.sum, s.part);
+    hipLaunchKernelGGL(iota_kernel, dim3((s.V + 255) / 256), dim3(256), 0, st, s.idx, s.V);
+    size_t bytes = s.sort_temp_bytes;
+    e = hipcub::DeviceRadixSort::SortPairsDescending(s.sort_temp, bytes, s.probs, s.probs_sorted, s.idx, s.idx_sorted, s.V, 0, 32, st);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(tile_sums_kernel, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return enqueue_exact(s, s.probs_sorted, CHAIN_TOPP, tokpos, tokens_out, s.idx_sorted, st);
 }
 
 }  // namespace l2s
