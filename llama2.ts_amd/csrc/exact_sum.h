@@ -11,7 +11,8 @@
 //     Comp {q0, d}: the increment is q0 for even M, q0 + d for odd M, d in {-1, 0, +1}.
 // Which grid an element sits on is predicted from an APPROXIMATE prefix sum A (any parallel summation order): the
 // exact S differs from A by < 2^-36 relative, so whenever [A_{i-1}, A_i] lies inside one binade with a 2^-32 margin the
-// exponent of S_{i-1} is known and the add cannot leave the binade ("regular" element).  Every other element --
+// exponent of S_{i-1} is known and the add cannot leave the binade ("regular" element; classify()'s `mb` widens the margin
+// for a cruder A).  Every other element --
 // a power of two crossed, reached or nearly reached, the first non-zero value -- is "serial": it ends a run, and one
 // lane adds it the ordinary way when it walks the runs in order (chain_step).  That walk re-derives M and E from the
 // exact S at the start of each run and CHECKS them against the prediction (exponent equal, no carry out of 2^53); a
@@ -72,18 +73,20 @@ XS_HD Comp on_grid(float x, int E) {
   return c;
 }
 
-// Binade of a(1 - 2^-32) and of a(1 + 2^-32), a > 0 finite.
-XS_HD int low_e(double a) { return expo(a) - ((bits_of(a) & (TWO52 - 1)) < (1ull << 20) ? 1 : 0); }
-XS_HD int high_e(double a) { return expo(a) + ((bits_of(a) & (TWO52 - 1)) >= TWO52 - (1ull << 21) ? 1 : 0); }
+// Binade of a(1 - 2^-mb) and of a(1 + 2^-mb), a > 0 finite.  mb: how good the approximate prefix is -- 32 when it is a
+// sum of the very values being accumulated, 20 when it was derived (tile sums of the exps divided by their total
+// standing in for the tile sums of the fp32-rounded quotients: 2^-24 relative).
+XS_HD int low_e(double a, int mb) { return expo(a) - ((bits_of(a) & (TWO52 - 1)) < (1ull << (52 - mb)) ? 1 : 0); }
+XS_HD int high_e(double a, int mb) { return expo(a) + ((bits_of(a) & (TWO52 - 1)) >= TWO52 - (1ull << (53 - mb)) ? 1 : 0); }
 
 // Element x with approximate prefix `aprev` in front of it and `acur` including it.  Returns true for a serial element;
 // otherwise *E is its grid (E_NONE for a zero, which changes nothing on any grid -- also the padding of the last tile).
-XS_HD bool classify(double aprev, double acur, float x, int* E) {
+XS_HD bool classify(double aprev, double acur, float x, int* E, int mb = 32) {
   *E = E_NONE;
   if (x == 0.0f) return false;                                                // S + 0 = S
   if (aprev == 0.0) return true;                                              // first non-zero value: 0 + x = x
   if (!(acur <= 1.7976931348623157e308)) return true;                          // inf / nan: ordinary adds all the way
-  const int lo = low_e(aprev), hi = high_e(acur);
+  const int lo = low_e(aprev, mb), hi = high_e(acur, mb);
   if (lo != hi) return true;
   *E = lo;
   return false;

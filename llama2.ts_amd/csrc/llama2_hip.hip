@@ -162,7 +162,8 @@ struct l2_ctx {
   unsigned flags = 0;
   nccl_comm comm = nullptr;
   l2s::Sampler samp;                 // device sampler (l2_decode_sample), created on first use
-  hipGraphExec_t g_sample[NLEV][2] = {};  // [attention split level][plain sample / top-p]
+  hipGraphExec_t g_sample[NLEV][4] = {};  // [attention split level][plain sample / top-p, + 2: maximum taken from the classifier's argmax keys]
+  bool samp_amax = false;
   int samp_mode = 0;
   std::shared_ptr<LoopGroup> loop;   // L2_TP_LOOPBACK test hook (see LoopGroup)
   double* loop_tmp = nullptr;
@@ -257,7 +258,7 @@ static void destroy_graphs(l2_ctx* c) {
   for (int i = 0; i < NLEV; ++i) {
     if (c->g_step[i]) { hipGraphExecDestroy(c->g_step[i]); c->g_step[i] = nullptr; }
     if (c->g_greedy[i]) { hipGraphExecDestroy(c->g_greedy[i]); c->g_greedy[i] = nullptr; }
-    for (int m = 0; m < 2; ++m) if (c->g_sample[i][m]) { hipGraphExecDestroy(c->g_sample[i][m]); c->g_sample[i][m] = nullptr; }
+    for (int m = 0; m < 4; ++m) if (c->g_sample[i][m]) { hipGraphExecDestroy(c->g_sample[i][m]); c->g_sample[i][m] = nullptr; }
   }
 }
 
@@ -1295,7 +1296,6 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
   return L2_OK;
 }
 
-static int enqueue_forward(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, false); }
 static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
 
 static int ensure_ready(l2_ctx* c) {
@@ -1334,9 +1334,9 @@ static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step:
 }
 
 static int enqueue_sample(l2_ctx* c, hipStream_t st) {  // device-resident sampled step: forward, temperature/softmax/sample(_topp), advance
-  int rc = enqueue_forward(c, st);
+  int rc = enqueue_forward_impl(c, st, false, c->samp_amax);
   if (rc) return rc;
-  LCHK(l2s::enqueue(c->samp, c->logits, c->samp_mode == 1, c->tokpos, c->d_tokens, st));
+  LCHK(l2s::enqueue(c->samp, c->logits, c->samp_mode == 1, c->tokpos, c->d_tokens, c->samp_amax ? c->amax : nullptr, st));
   return L2_OK;
 }
 
@@ -1559,6 +1559,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   }
   const double params[2] = {temperature, topp};
   c->samp_mode = (topp <= 0 || topp >= 1) ? 0 : 1;        // llama2.ts:486: plain sample unless 0 < topp < 1
+  c->samp_amax = !c->tp_path && temperature > 0 && c->amax;   // the classifier's argmax keys give the softmax its maximum
   c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->samp.params, params, sizeof(params), hipMemcpyHostToDevice, c->stream));
@@ -1569,7 +1570,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
     const int lvl = split_level(c, pos0 + s);
     c->cur_splits = splits_of(c, lvl);
     if (graph) {
-      hipGraphExec_t& g = c->g_sample[lvl][c->samp_mode];
+      hipGraphExec_t& g = c->g_sample[lvl][c->samp_mode + (c->samp_amax ? 2 : 0)];
       if (!g) { rc = capture(c, enqueue_sample, &g); if (rc) return rc; }
       HIPCHK(hipGraphLaunch(g, c->stream));
     } else {

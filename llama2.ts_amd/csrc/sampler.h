@@ -10,7 +10,8 @@ namespace l2s {
 
 struct Sampler {
   int V = 0;
-  float* probs = nullptr;        // (V) scaled logits -> exps -> probabilities, in place like state.logits
+  float* probs = nullptr;        // (V) exps of the scaled logits (the serial form: -> probabilities, in place like state.logits)
+  float* probs_n = nullptr;      // (V) probabilities
   float* probs_sorted = nullptr; // (V) descending (top-p)
   int* idx = nullptr;            // (V) 0..V-1
   int* idx_sorted = nullptr;     // (V) token ids in descending-probability order, ties by id (stable sort)
@@ -22,15 +23,17 @@ struct Sampler {
   int G = 0;                     // tiles
   float* run_p = nullptr;        // (G * 1024) tiles sorted one by one (top-p)
   double* part = nullptr;        // (G) approximate tile sums
-  void* recs = nullptr;          // (G * 1025) xs::Run records
+  double* part_sorted = nullptr; // (G) the same for the sorted order (accumulated by the rank merge, zero between tokens)
+  void* recs = nullptr;          // (G * 1025) xs::Run records of the exps' running sum
   int* cnt = nullptr;            // (G) records per tile
+  void* recs2 = nullptr;         // the same for the probabilities (in index or sorted order)
+  int* cnt2 = nullptr;
   int* off = nullptr;            // (G + 1)
   double* runS = nullptr;        // per run: exact running sum after it
   int* runEnd = nullptr;
   int* runBad = nullptr;
   unsigned long long* cq = nullptr;   // (G * 1024) per element: grid composite since the start of its run
   int* cm = nullptr;
-  double* sum = nullptr;         // softmax denominator
   unsigned* mxkey = nullptr;     // max of the scaled logits (order-preserving key), zero between tokens
   bool own_sort = false;         // top-p order by tile sort + rank merge (vocabularies up to 40 960); else rocPRIM radix sort
   bool serial = false;           // L2_SAMPLER_SERIAL=1: one lane accumulates (the straightforward form, kept for A/B)
@@ -43,8 +46,10 @@ void destroy(Sampler* s);
 // Enqueue one sampled step after the classifier: reads `logits` (V floats, left untouched), picks the next token
 // exactly as llama2.ts:480-493 does, then advances {token, pos, step} in `tokpos` and stores the token in
 // tokens_out[step] -- the same protocol as argmax_advance_kernel.  `topp_mode`: the sample_topp branch
-// (0 < topp < 1); temperature and topp themselves are read from s.params at run time.
-hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, hipStream_t st);
+// (0 < topp < 1); temperature and topp themselves are read from s.params at run time.  `amax` (may be null): the 8
+// argmax keys the classifier folded max(logits) into (one per 128-byte line); usable only for temperature > 0, saves
+// the sampler's own maximum pass; the sampler zeroes them for the next token.
+hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, unsigned long long* amax, hipStream_t st);
 
 // Diagnostic: running sums S_i = fl(S_{i-1} + x_i) of n <= MAX_VOCAB non-negative fp32 values, by the exact parallel
 // algorithm (synchronous).

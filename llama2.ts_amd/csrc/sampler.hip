@@ -5,13 +5,16 @@
 // (softmax :189, sample :369/:373, sample_topp :385/:391) and the chosen index depends on comparing a random
 // threshold against those running sums, so a tree sum (different in the last bits) can flip a token.
 //
-// Default form (whole chip, ~10 short launches per token):
-//   max -> exp + tile sums -> runs -> chain (exact sum) -> normalise + tile sums -> [top-p: tile sort -> rank merge ->
-//   tile sums] -> runs -> chain (exact running sums, threshold, search, advance)
+// Default form (whole chip; 4 launches per token for sample, 6 for top-p; +31 / +59 us per token at stories110M):
+//   exp + tile sums (the maximum comes from the classifier's argmax keys) -> runs of the exps
+//   sample:  [exact total -> probabilities -> their runs] -> chain: exact running sums, threshold, search, advance
+//   top-p:   [exact total -> probabilities -> sorted tiles] -> rank merge (+ tile sums) -> runs -> chain
 // "runs" / "chain" are exact_sum.h: every 1024-element tile turns its elements into integer increments on the grid its
-// approximate prefix predicts, one lane walks the ~50 runs of a 32 000-element vector with exact fp64 state, checking
-// every prediction, and the searched index is evaluated inside the one run that contains it.  Bit-identical to the
-// serial loop by construction (tests/test_exact_sum_cpu.py on the host, l2_debug_running_sums on the GPU).
+// approximate prefix predicts, one wave walks the ~50 runs of a 32 000-element vector with exact fp64 state (stretches of
+// runs on one grid composed by a scan first), every prediction is checked, and the searched index is evaluated inside
+// the one run that contains it.  The bracketed steps share a launch: each of their workgroups repeats the walk for the
+// total instead of waiting for a launch that would hand it over.  Bit-identical to the serial loop by construction
+// (tests/test_exact_sum_cpu.py on the host, l2_debug_running_sums on the GPU).
 // The descending stable sort of sample_topp (Array.prototype.sort is stable in V8 >= 7.0) is a bitonic sort of
 // (probability, id) keys per tile followed by one rank-by-binary-search merge of the 32 sorted tiles out of LDS.
 //
@@ -331,7 +334,7 @@ struct Elems {
 };
 
 // Classify the tile's elements (exact_sum.h) and scan their grid composites run by run.
-__device__ __forceinline__ void tile_scan(const float (&v)[IT], double base, TileShared& sh, Elems& o) {
+__device__ __forceinline__ void tile_scan(const float (&v)[IT], double base, TileShared& sh, Elems& o, int mb = 32) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double a[IT];
   a[0] = (double)v[0];
@@ -349,11 +352,11 @@ __device__ __forceinline__ void tile_scan(const float (&v)[IT], double base, Til
   int eE[IT];
   // the common case first: the whole thread sits in one binade, nothing to decide per element
   int Eq;
-  const bool quiet = !xs::classify(tb, tb + a[IT - 1], 1.0f, &Eq);
+  const bool quiet = !xs::classify(tb, tb + a[IT - 1], 1.0f, &Eq, mb);
 #pragma unroll
   for (int k = 0; k < IT; ++k) {
     if (quiet) { ser[k] = false; eE[k] = (v[k] == 0.0f) ? E_NONE : Eq; }
-    else ser[k] = xs::classify(k ? tb + a[k - 1] : tb, tb + a[k], v[k], &eE[k]);
+    else ser[k] = xs::classify(k ? tb + a[k - 1] : tb, tb + a[k], v[k], &eE[k], mb);
   }
   const int last = ser[IT - 1] ? 1 : 0;
   if (lane == 63) sh.wser[wave] = last;
@@ -398,33 +401,28 @@ __global__ void __launch_bounds__(TN) scaled_max_kernel(const float* logits, int
 }
 
 // probs[i] = (float)exp(x_i - max)  (:187) and the tile sums for the approximate prefix
-__global__ void __launch_bounds__(TN) exp_kernel(const float* logits, int V, const double* params, const unsigned* mxkey, float* probs, double* part) {
+// (amax != null, temperature > 0: the classifier already folded max(logits) into its argmax keys -- kernels.hip.h
+// argmax_key -- and x -> (float)(x / T) is monotone, so the maximum of the scaled logits is the scaled maximum)
+__global__ void __launch_bounds__(TN) exp_kernel(const float* logits, int V, const double* params, const unsigned* mxkey, const unsigned long long* amax,
+                                                  float* probs, double* part) {
   __shared__ double wsum[NWV];
   float v[IT];
   load_tile(logits, V, blockIdx.x, v);
   const double T = params[0];
-  const float mx = order_value(*mxkey);
+  float mx;
+  if (amax) {
+    unsigned long long k = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const unsigned long long kj = amax[(size_t)j * 16]; k = kj > k ? kj : k; }
+    mx = (float)((double)order_value((unsigned)(k >> 32)) / T);
+  } else {
+    mx = order_value(*mxkey);
+  }
   const int i0 = blockIdx.x * TILE + threadIdx.x * IT;
 #pragma unroll
   for (int k = 0; k < IT; ++k) {
     const float x = (float)((double)v[k] / T);
     v[k] = (i0 + k < V) ? (float)exp((double)x - (double)mx) : 0.0f;
-    if (i0 + k < V) probs[i0 + k] = v[k];
-  }
-  const double t = tile_total(v, wsum);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
-}
-
-// probs[i] /= sum  (:192) and the tile sums of the result
-__global__ void __launch_bounds__(TN) normalise_kernel(float* probs, int V, const double* sum, double* part) {
-  __shared__ double wsum[NWV];
-  float v[IT];
-  load_tile(probs, V, blockIdx.x, v);
-  const double s = *sum;
-  const int i0 = blockIdx.x * TILE + threadIdx.x * IT;
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {
-    v[k] = (i0 + k < V) ? (float)((double)v[k] / s) : 0.0f;
     if (i0 + k < V) probs[i0 + k] = v[k];
   }
   const double t = tile_total(v, wsum);
@@ -439,30 +437,36 @@ __global__ void __launch_bounds__(TN) tile_sums_kernel(const float* x, int V, do
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-// One record per run of the tile: recs[tile * (TILE + 1) + r], cnt[tile] of them; and per element its composite since the
-// start of its run (cq) with {d + 1, serial, grid} packed into cm, which is what the search needs to turn the exact
-// sum in front of a run into the exact running sum at any element of it.
+// One record per run of the tile: recs[tile * (TILE + 1) + r], cnt[tile] of them; and (COMP) per element its composite
+// since the start of its run (cq) with {d + 1, serial, grid} packed into cm, which is what the search needs to turn the
+// exact sum in front of a run into the exact running sum at any element of it.
 __device__ __forceinline__ int pack_meta(const Seg& s, bool serial) { return (s.meta & 3) | (serial ? 4 : 0) | (s.meta & (int)0xffff0000); }
+
+template <bool COMP>
+__device__ __forceinline__ void emit_runs(const Elems& el, const float (&v)[IT], int V, int tile, Run* recs, int* cnt, unsigned long long* cq, int* cm) {
+  Run* out = recs + (size_t)tile * (TILE + 1);
+  const int i0 = tile * TILE + threadIdx.x * IT;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const Seg& s = el.inc[k];
+    if (COMP) { cq[i0 + k] = s.q0; cm[i0 + k] = pack_meta(s, el.serial[k]); }
+    const bool tile_end = threadIdx.x == TN - 1 && k == IT - 1;
+    if (el.serial[k] || tile_end) {
+      Run r; r.q0 = s.q0; r.d = seg_d(s); r.E = seg_E(s); r.x = el.serial[k] ? v[k] : 0.0f; r.end = min(i0 + k, V - 1);
+      out[el.serial[k] ? seg_cnt(s) - 1 : seg_cnt(s)] = r;
+      if (tile_end) cnt[tile] = seg_cnt(s) + (el.serial[k] ? 0 : 1);
+    }
+  }
+}
+
+template <bool COMP>
 __global__ void __launch_bounds__(TN) runs_kernel(const float* x, int V, const double* part, Run* recs, int* cnt, unsigned long long* cq, int* cm) {
   __shared__ TileShared sh;
   float v[IT];
   load_tile(x, V, blockIdx.x, v);
   Elems el;
   tile_scan(v, tile_base(part, blockIdx.x), sh, el);
-  Run* out = recs + (size_t)blockIdx.x * (TILE + 1);
-  const int i0 = blockIdx.x * TILE + threadIdx.x * IT;
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {
-    const Seg& s = el.inc[k];
-    cq[i0 + k] = s.q0;
-    cm[i0 + k] = pack_meta(s, el.serial[k]);
-    const bool tile_end = threadIdx.x == TN - 1 && k == IT - 1;
-    if (el.serial[k] || tile_end) {
-      Run r; r.q0 = s.q0; r.d = seg_d(s); r.E = seg_E(s); r.x = el.serial[k] ? v[k] : 0.0f; r.end = min(i0 + k, V - 1);
-      out[el.serial[k] ? seg_cnt(s) - 1 : seg_cnt(s)] = r;
-      if (tile_end) cnt[blockIdx.x] = seg_cnt(s) + (el.serial[k] ? 0 : 1);
-    }
-  }
+  emit_runs<COMP>(el, v, V, blockIdx.x, recs, cnt, cq, cm);
 }
 
 struct ChainArgs {
@@ -475,7 +479,6 @@ struct ChainArgs {
   double* S;                 // per run: exact sum after it
   int* End;                  // per run: index of its last element
   int* Bad;                  // per run: prediction failed, its elements were added one by one
-  double* sum_out;
   const double* params;
   unsigned long long* rng;
   int* tokpos;
@@ -484,6 +487,8 @@ struct ChainArgs {
   const int* cm;
   const int* ids;            // top-p: token ids in sorted order
   unsigned* mxkey;           // reset for the next token
+  unsigned long long* amax;  // or: the classifier's 8 argmax keys (llama2_hip.hip) supplied the maximum; reset those
+  double* part_sorted;       // top-p: tile sums the rank merge accumulates, zero between tokens
 };
 
 struct ChainShared {
@@ -558,22 +563,21 @@ __device__ __forceinline__ int find_first(const ChainArgs& a, ChainShared& sh, c
   return (hit != 0x7fffffff && hit < limit) ? hit : -1;
 }
 
-enum { CHAIN_SUM = 0, CHAIN_SAMPLE = 1, CHAIN_TOPP = 2, CHAIN_DEBUG = 3 };
+enum { CHAIN_SAMPLE = 1, CHAIN_TOPP = 2, CHAIN_DEBUG = 3 };
 
-// One workgroup: order the runs, walk them with the exact fp64 state, then whatever the caller wants from the sums.
-template <int MODE, bool IN_LDS>
-__device__ __forceinline__ void chain_body(const ChainArgs& a, ChainShared& sh, int T) {
+// Walk the runs in order with the exact fp64 state; leaves the total in sh.val (read it after a barrier).
+template <bool IN_LDS>
+__device__ __forceinline__ void chain_walk(const ChainArgs& a, ChainShared& sh, int T) {
   const int tid = threadIdx.x;
-
   const RunState<IN_LDS> rs{sh, a};
-  // Fast walk (runs staged in LDS): lane l of wave 0 holds run l's increments, the state S is uniform, and one step is
-  // "add the increment picked by the parity of S to the BIT PATTERN of S" (that many grid steps inside the binade)
-  // followed by the ordinary add of the run's serial element: ~5 dependent instructions.  The checks ride along; if any
-  // fails (never observed) the generic loop below redoes the walk run by run with the element-wise fallback.
+  // Fast walk (runs staged in LDS), 64 runs at a time, lane l of wave 0 holding run l.  Runs that merely end with their tile
+  // sit on the grid of the run behind them, so a segmented scan first composes every stretch of runs up to the next serial
+  // element (~3 stretches per binade crossing instead of one step per tile); then the state S (uniform) takes one step per
+  // stretch: "add the increment picked by the parity of S to the BIT PATTERN of S" (that many grid steps inside the binade),
+  // then the ordinary add of the serial element -- ~5 dependent instructions.  Every lane then derives the exact sum after
+  // its own run from the sum in front of its stretch and checks the prediction it rested on; if any check fails (never
+  // observed) the generic loop below redoes the walk run by run with the element-wise fallback.
   bool fast_ok = false;
-#ifdef L2_SAMPLER_TRACE
-  const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-#endif
   if (IN_LDS && tid < 64) {
     double S = 0.0;
     bool allok = true;
@@ -581,36 +585,41 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, ChainShared& sh, 
       const int k = c0 + tid;
       Run r; r.q0 = 0; r.d = 0; r.E = E_NONE; r.x = 0.0f; r.end = 0;
       if (k < T) r = sh.rec[k];
-      const bool has = (r.q0 | (unsigned long long)(unsigned)r.d) != 0;
-      const unsigned long long inc0 = r.q0, inc1 = r.q0 + (unsigned long long)(long long)r.d;
-      const int eb = has ? r.E + 1023 : -1;
+      const bool ender = k < T && (r.x != 0.0f || k == T - 1 || tid == 63);
+      int prev_ender = dpp_i32<0x138, 0xf>(1, ender ? 1 : 0);            // wave_shr:1; a stretch starts at lane 0
+      Comp rc; rc.q0 = r.q0; rc.d = r.d;
+      const bool own = (r.q0 | (unsigned long long)(unsigned)r.d) != 0;
+      const Seg me = seg_make(rc, own ? r.E : E_NONE, prev_ender != 0, false);
+      const Seg inc = wave_scan_seg(me);
+      const Seg before = dpp_seg<0x138, 0xf>(inc);
+      // one grid per stretch: a run on another grid than the runs composed in front of it would be a wrong prediction
+      allok = allok && r.q0 < xs::TWO53 && (!own || prev_ender || seg_E(before) == E_NONE || seg_E(before) == r.E);
+      const unsigned long long inc0 = inc.q0, inc1 = inc.q0 + (unsigned long long)(long long)seg_d(inc);
+      const bool has = (inc.q0 | (unsigned long long)(unsigned)seg_d(inc)) != 0;
+      const int eb = has ? seg_E(inc) + 1023 : -1;
       const double x = (double)r.x;
-      allok = allok && r.q0 < xs::TWO53;
-      double Sk = 0.0;
-      const int n = min(64, T - c0);
-      int bad = 0;
-      for (int j = 0; j < n; ++j) {
+      double Sfront = 0.0;
+      int prev = -1;
+      for (unsigned long long todo = __ballot(ender); todo; todo &= todo - 1) {
+        const int j = __builtin_ctzll(todo);
         const unsigned long long i0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(inc0 >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)inc0, j);
         const unsigned long long i1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(inc1 >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)inc1, j);
-        const int e = __builtin_amdgcn_readlane(eb, j);
         const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), j), __builtin_amdgcn_readlane(__double2loint(x), j));
         asm volatile("" : "+v"(S));                           // keep the state in vector registers: no scalar round trip per step
+        Sfront = (tid > prev && tid <= j) ? S : Sfront;       // the lanes of this stretch start from here
         const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
-        const unsigned long long sb2 = sb + ((sb & 1) ? i1 : i0);
-        bad |= (e >= 0) & (((int)(sb >> 52) != e) | ((int)(sb2 >> 52) != e));
-        S = __longlong_as_double((long long)sb2) + xj;
-        Sk = (tid == j) ? S : Sk;
+        S = __longlong_as_double((long long)(sb + ((sb & 1) ? i1 : i0))) + xj;
+        prev = j;
       }
-      allok = allok && bad == 0;
+      const unsigned long long fb = (unsigned long long)__double_as_longlong(Sfront);
+      const unsigned long long fb2 = fb + ((fb & 1) ? inc1 : inc0);
+      const double Sk = __longlong_as_double((long long)fb2) + x;   // x = 0 unless the run ends with a serial element
+      allok = allok && (k >= T || eb < 0 || ((int)(fb >> 52) == eb && (int)(fb2 >> 52) == eb));
       if (k < T) { rs.S(k) = Sk; rs.End(k) = r.end; rs.Bad(k) = 0; }
     }
     fast_ok = __all(allok);
-#ifdef L2_SAMPLER_TRACE
-    if (tid == 0) printf("mode %d: %d runs, fast walk ok %d, %llu clocks\n", MODE, T, (int)fast_ok, __builtin_amdgcn_s_memtime() - t2);
-#endif
     if (tid == 0 && fast_ok) {
       sh.val = S;
-      if (MODE == CHAIN_SUM) *a.sum_out = S;
     }
   }
   if (tid == 0 && !fast_ok) {
@@ -634,35 +643,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& a, ChainShared& sh, 
         for (int r = 0, n = sh.off[t + 1] - sh.off[t]; r < n; ++r, ++k) step(k, a.recs[(size_t)t * (TILE + 1) + r]);
     }
     sh.val = S;
-    if (MODE == CHAIN_SUM) *a.sum_out = S;
-  }
-  __syncthreads();
-  if (MODE == CHAIN_SUM || MODE == CHAIN_DEBUG) return;
-  const double total = sh.val;
-  __syncthreads();
-  double at = 0.0;
-  if (MODE == CHAIN_SAMPLE) {
-    if (tid == 0) sh.val = (double)random_f32(a.rng) * total;                    // randValue = random_f32() * sum (:370)
-    __syncthreads();
-    const double r = sh.val;
-    const int hit = find_first(a, sh, rs, T, [r](double S) { return r < S; }, a.V, &at);   // :373
-    if (tid == 0) { advance(a.tokpos, a.tokens_out, hit < 0 ? 0 : hit); *a.mxkey = 0; }   // fall-through returns 0 (:375)
-  } else {
-    const double topp = a.params[1];
-    const int cross = find_first(a, sh, rs, T, [topp](double S) { return S > topp; }, a.V, &at);   // :385
-    const int last = cross < 0 ? 0 : cross;                                      // never crossed: lastIdx stays 0 (:383)
-    __syncthreads();
-    if (tid == 0) sh.val = (double)random_f32(a.rng) * (cross < 0 ? total : at);  // cumProb as the loop left it (:388)
-    __syncthreads();
-    const double r = sh.val;
-    const int hit = find_first(a, sh, rs, T, [r](double S) { return r < S; }, last, &at);   // i < lastIdx only (:390)
-    if (tid == 0) { advance(a.tokpos, a.tokens_out, hit < 0 ? 0 : a.ids[hit]); *a.mxkey = 0; }
   }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(TN) chain_kernel(ChainArgs a) {
-  __shared__ ChainShared sh;
+// Order the tiles' runs (first run of every tile in sh.off, records staged in LDS when they fit) and walk them.
+// Returns the number of runs; *in_lds says where the per-run state went.  Every thread of the workgroup calls it.
+__device__ __forceinline__ int chain_total(const ChainArgs& a, ChainShared& sh, bool* in_lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = tid < a.G ? a.cnt[tid] : 0;
   Run r0, r1;                                              // nearly every tile has one or two runs: fetched together with the count
@@ -677,20 +663,91 @@ __global__ void __launch_bounds__(TN) chain_kernel(ChainArgs a) {
   const int first = wb + incl - c;
   sh.off[tid] = first;
   if (tid == TN - 1) sh.off[TN] = first + c;
-  if (MODE == CHAIN_DEBUG) { if (tid < a.G) a.off[tid] = first; if (tid == TN - 1) a.off[a.G] = first + c; }
   __syncthreads();
   const int T = sh.off[TN];
-  if (MODE != CHAIN_DEBUG && T <= RUN_CAP) {
+  *in_lds = T <= RUN_CAP;
+  if (*in_lds) {
     if (tid < a.G) {
       if (c > 0) sh.rec[first] = r0;
       if (c > 1) sh.rec[first + 1] = r1;
       for (int r = 2; r < c; ++r) sh.rec[first + r] = a.recs[(size_t)tid * (TILE + 1) + r];
     }
     __syncthreads();
-    chain_body<MODE, true>(a, sh, T);
+    chain_walk<true>(a, sh, T);
   } else {
-    chain_body<MODE, false>(a, sh, T);
+    chain_walk<false>(a, sh, T);
   }
+  __syncthreads();
+  return T;
+}
+
+// What sample() / sample_topp() do with the running sums (llama2.ts:368-394).
+template <int MODE, bool IN_LDS>
+__device__ __forceinline__ void chain_pick(const ChainArgs& a, ChainShared& sh, int T) {
+  const int tid = threadIdx.x;
+  const RunState<IN_LDS> rs{sh, a};
+  const double total = sh.val;
+  __syncthreads();
+  double at = 0.0;
+  if (MODE == CHAIN_SAMPLE) {
+    if (tid == 0) sh.val = (double)random_f32(a.rng) * total;                    // randValue = random_f32() * sum (:370)
+    __syncthreads();
+    const double r = sh.val;
+    const int hit = find_first(a, sh, rs, T, [r](double S) { return r < S; }, a.V, &at);   // :373
+    if (tid == 0) { advance(a.tokpos, a.tokens_out, hit < 0 ? 0 : hit); *a.mxkey = 0; }   // fall-through returns 0 (:375)
+    if (a.amax && tid < 8) a.amax[(size_t)tid * 16] = 0ull;
+  } else {
+    const double topp = a.params[1];
+    const int cross = find_first(a, sh, rs, T, [topp](double S) { return S > topp; }, a.V, &at);   // :385
+    const int last = cross < 0 ? 0 : cross;                                      // never crossed: lastIdx stays 0 (:383)
+    __syncthreads();
+    if (tid == 0) sh.val = (double)random_f32(a.rng) * (cross < 0 ? total : at);  // cumProb as the loop left it (:388)
+    __syncthreads();
+    const double r = sh.val;
+    const int hit = find_first(a, sh, rs, T, [r](double S) { return r < S; }, last, &at);   // i < lastIdx only (:390)
+    if (tid == 0) { advance(a.tokpos, a.tokens_out, hit < 0 ? 0 : a.ids[hit]); *a.mxkey = 0; }
+    if (a.amax && tid < 8) a.amax[(size_t)tid * 16] = 0ull;
+    if (a.part_sorted && tid < a.G) a.part_sorted[tid] = 0.0;
+  }
+}
+
+
+// One workgroup: every run's state for the diagnostic (CHAIN_DEBUG), or the sampled token.
+template <int MODE>
+__global__ void __launch_bounds__(TN) chain_kernel(ChainArgs a) {
+  __shared__ ChainShared sh;
+  bool in_lds;
+  const int T = chain_total(a, sh, &in_lds);
+  if (MODE == CHAIN_DEBUG) {                                   // everything prefix_kernel needs, in global memory
+    const int tid = threadIdx.x;
+    if (tid < a.G) a.off[tid] = sh.off[tid];
+    if (tid == 0) a.off[a.G] = T;
+    if (in_lds) for (int k = tid; k < T; k += TN) { a.S[k] = sh.S[k]; a.End[k] = sh.End[k]; a.Bad[k] = sh.Bad[k]; }
+    return;
+  }
+  if (in_lds) chain_pick<MODE, true>(a, sh, T); else chain_pick<MODE, false>(a, sh, T);
+}
+
+// The exact softmax denominator, recomputed by every workgroup of the kernel that needs it next (a walk over ~50 runs is
+// cheaper than a launch boundary): probabilities = exps / total (:192), then straight into their own tile scan.  The
+// approximate prefix in front of a tile is the exps' prefix over the same total -- within 2^-24 relative of the sum of the
+// rounded quotients, hence the 20-bit margin (exact_sum.h).  Writes the probabilities and the runs of THEIR running sums.
+__global__ void __launch_bounds__(TN) normalise_runs_kernel(ChainArgs a, float* probs_n, Run* recs_n, int* cnt_n, unsigned long long* cq, int* cm) {
+  __shared__ ChainShared sh;
+  bool in_lds;
+  chain_total(a, sh, &in_lds);
+  const double total = sh.val;
+  float v[IT];
+  load_tile(a.x, a.V, blockIdx.x, v);
+  const int i0 = blockIdx.x * TILE + threadIdx.x * IT;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    v[k] = (i0 + k < a.V) ? (float)((double)v[k] / total) : 0.0f;
+    if (i0 + k < a.V) probs_n[i0 + k] = v[k];
+  }
+  Elems el;
+  tile_scan(v, tile_base(a.part, blockIdx.x) / total, sh.tile, el, 20);
+  emit_runs<true>(el, v, a.V, blockIdx.x, recs_n, cnt_n, cq, cm);
 }
 
 // Diagnostic (l2_debug_running_sums): every running sum, from the chain's per-run state.
@@ -729,53 +786,58 @@ __device__ __forceinline__ void order_pair(u64& a, u64& b, bool up) {
   a = lo; b = hi;
 }
 
-// Bitonic sort of one tile's 1024 keys: 4 consecutive positions per thread, so strides 1 and 2 stay inside a thread,
-// strides 4..128 are lane exchanges inside a wave, and only strides 256 / 512 (3 of the 55 stages) go through LDS.
+// Bitonic sort of one sort tile: SIT consecutive positions per thread, so the small strides stay inside a thread, the
+// middle ones are lane exchanges inside a wave, and only the strides >= 64 * SIT go through LDS.  Measured: 8 keys per
+// thread (2048-key tiles, half as many for the rank merge to search) take 12 us longer here and save 4 us there.
+constexpr int SIT = 4, STILE = TN * SIT;
 template <bool FUSED>
-__global__ void __launch_bounds__(TN) sort_tile_kernel(const float* probs, int V, const double* sum, float* run_p, int* run_id) {
-  __shared__ u64 xch[TILE];
-  const int tid = threadIdx.x, base = blockIdx.x * TILE, p0 = tid * IT;
-  float pv[IT];
-  load_tile(probs, V, blockIdx.x, pv);
-  u64 v[IT];
-  const double s = FUSED ? *sum : 1.0;
+__global__ void __launch_bounds__(TN) sort_tile_kernel(ChainArgs a, const float* probs, int V, float* run_p, int* run_id) {
+  __shared__ union { ChainShared sh; u64 xch[STILE]; } lds;      // the chain is over before the first exchange (a barrier in between)
+  ChainShared& sh = lds.sh;
+  u64* xch = lds.xch;
+  const int tid = threadIdx.x, base = blockIdx.x * STILE, p0 = tid * SIT;
+  double s = 1.0;
+  if (FUSED) {                                                 // probs holds the exps: every workgroup derives their exact total itself
+    bool in_lds;
+    chain_total(a, sh, &in_lds);
+    s = sh.val;
+  }
+  u64 v[SIT];
 #pragma unroll
-  for (int k = 0; k < IT; ++k) {
+  for (int k = 0; k < SIT; ++k) {
     const int i = base + p0 + k;
-    const float p = FUSED ? (float)((double)pv[k] / s) : pv[k];              // FUSED: probs still holds the exps (:192)
+    const float e = (i < V) ? probs[i] : 0.0f;
+    const float p = FUSED ? (float)((double)e / s) : e;                      // :192
     v[k] = (i < V) ? (((u64)(0xffffffffu - __float_as_uint(p)) << 32) | (unsigned)i) : ~0ull;
   }
 #pragma unroll
-  for (int k2 = 2; k2 <= TILE; k2 <<= 1) {
+  for (int k2 = 2; k2 <= STILE; k2 <<= 1) {
 #pragma unroll
     for (int j = k2 >> 1; j > 0; j >>= 1) {
-      if (j == 1) {
-        order_pair(v[0], v[1], ((p0 + 0) & k2) == 0);
-        order_pair(v[2], v[3], ((p0 + 2) & k2) == 0);
-      } else if (j == 2) {
-        order_pair(v[0], v[2], ((p0 + 0) & k2) == 0);
-        order_pair(v[1], v[3], ((p0 + 1) & k2) == 0);
+      if (j < SIT) {
+#pragma unroll
+        for (int k = 0; k < SIT; ++k) if ((k & j) == 0) order_pair(v[k], v[k | j], ((p0 + k) & k2) == 0);
       } else {
         const bool keep_min = ((p0 & j) == 0) == ((p0 & k2) == 0);
-        u64 o[IT];
-        if (j < 64 * IT) {
+        u64 o[SIT];
+        if (j < 64 * SIT) {
 #pragma unroll
-          for (int k = 0; k < IT; ++k) o[k] = __shfl_xor(v[k], j / IT, 64);
+          for (int k = 0; k < SIT; ++k) o[k] = __shfl_xor(v[k], j / SIT, 64);
         } else {
           __syncthreads();
 #pragma unroll
-          for (int k = 0; k < IT; ++k) xch[p0 + k] = v[k];
+          for (int k = 0; k < SIT; ++k) xch[p0 + k] = v[k];
           __syncthreads();
 #pragma unroll
-          for (int k = 0; k < IT; ++k) o[k] = xch[(p0 ^ j) + k];
+          for (int k = 0; k < SIT; ++k) o[k] = xch[(p0 ^ j) + k];
         }
 #pragma unroll
-        for (int k = 0; k < IT; ++k) v[k] = keep_min ? (v[k] < o[k] ? v[k] : o[k]) : (v[k] > o[k] ? v[k] : o[k]);
+        for (int k = 0; k < SIT; ++k) v[k] = keep_min ? (v[k] < o[k] ? v[k] : o[k]) : (v[k] > o[k] ? v[k] : o[k]);
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < IT; ++k) {
+  for (int k = 0; k < SIT; ++k) {
     const bool pad = v[k] == ~0ull;
     run_p[base + p0 + k] = pad ? -1.0f : __uint_as_float(0xffffffffu - (unsigned)(v[k] >> 32));
     run_id[base + p0 + k] = pad ? -1 : (int)(unsigned)v[k];
@@ -784,59 +846,67 @@ __global__ void __launch_bounds__(TN) sort_tile_kernel(const float* probs, int V
 
 // Every element's place in the merged order: its place in its own tile + the number of elements of every other tile
 // in front of it (ties: the tile with the smaller ids first), by binary search in the G sorted tiles held in LDS.
-constexpr int RT = 512;                                           // threads = elements per workgroup of the rank merge
-__global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const int* run_id, int G, float* sorted, int* ids) {
-  extern __shared__ int lds_p[];                                // G * TILE probability bit patterns (pads: negative)
-  const int tid = threadIdx.x, n = G * TILE;
-  constexpr int B = 8;                                          // 16-byte loads in flight per thread
-  for (int j0 = tid * 4; j0 < n; j0 += RT * 4 * B) {
-    int4 q[B];
-#pragma unroll
-    for (int u = 0; u < B; ++u) q[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(run_p) + min(j0 + u * RT * 4, n - 4));
-#pragma unroll
-    for (int u = 0; u < B; ++u) if (j0 + u * RT * 4 < n) *reinterpret_cast<int4*>(lds_p + j0 + u * RT * 4) = q[u];
-  }
+constexpr int RT = 512;                                           // threads = elements per workgroup of the rank merge (256 and 1024: the same time)
+// Also adds every element to the sum of the tile of the merged order it lands in (part[], zero on entry): the approximate
+// prefix of the next stage.  fp64 atomics in no fixed order -- the prefix only has to be approximate (exact_sum.h).
+__global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const int* run_id, int GS, int G, float* sorted, int* ids, double* part) {
+  extern __shared__ int lds_p[];                                // GS * STILE probability bit patterns (pads: negative), then G tile sums
+  const int tid = threadIdx.x, n = GS * STILE;
+  double* lpart = reinterpret_cast<double*>(lds_p + n);
+  if (tid < G) lpart[tid] = 0.0;
+  // every workgroup pulls all G tiles; measured: one 16-byte load in flight per thread (8 KB per workgroup) beats 4, 8 and 16
+  // (+5 / +5 / +8 us) -- the same lines are wanted by every CU at once and deeper queues only lengthen the wait behind them
+  for (int j = tid * 4; j < n; j += RT * 4) *reinterpret_cast<int4*>(lds_p + j) = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(run_p) + j);
   const int e = blockIdx.x * RT + tid;
   const int my_id = e < n ? run_id[e] : -1;
   __syncthreads();
-  if (e >= n) return;
-  const int mine = lds_p[e];
-  if (mine < 0) return;                                         // pad
-  const int own = e / TILE;
-  int rank = e - own * TILE;
+  const int mine = e < n ? lds_p[e] : -1;
+  if (mine >= 0) {                                              // not a pad
+  const int own = e / STILE;
+  int rank = e - own * STILE;
   constexpr int U = 8;                                          // searches in flight per thread
-  for (int b0 = 0; b0 < G; b0 += U) {
+  for (int b0 = 0; b0 < GS; b0 += U) {
     int lo[U], thr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int b = min(b0 + u, G - 1);
-      lo[u] = b * TILE;
+      const int b = min(b0 + u, GS - 1);
+      lo[u] = b * STILE;
       thr[u] = mine - (b < own ? 1 : 0);                        // earlier tile: elements >= mine come first; later tile: only > mine
     }
 #pragma unroll
-    for (int s = TILE / 2; s > 0; s >>= 1) {
+    for (int s = STILE / 2; s > 0; s >>= 1) {
 #pragma unroll
       for (int u = 0; u < U; ++u) if (lds_p[lo[u] + s - 1] > thr[u]) lo[u] += s;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int b = min(b0 + u, G - 1);
-      int cnt = lo[u] - b * TILE;
-      if (cnt == TILE - 1 && lds_p[lo[u]] > thr[u]) cnt = TILE;
-      if (b0 + u < G && b != own) rank += cnt;
+      const int b = min(b0 + u, GS - 1);
+      int cnt = lo[u] - b * STILE;
+      if (cnt == STILE - 1 && lds_p[lo[u]] > thr[u]) cnt = STILE;
+      if (b0 + u < GS && b != own) rank += cnt;
     }
   }
   sorted[rank] = __int_as_float(mine);
   ids[rank] = my_id;
+  atomicAdd(lpart + rank / TILE, (double)__int_as_float(mine));
+  }
+  __syncthreads();
+  if (tid < G && lpart[tid] != 0.0) atomicAdd(part + tid, lpart[tid]);
 }
 
-static hipError_t enqueue_exact(const Sampler& s, const float* x, int mode, int* tokpos, int* tokens_out, const int* ids, hipStream_t st) {
-  hipLaunchKernelGGL(runs_kernel, dim3(s.G), dim3(TN), 0, st, x, s.V, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
-  ChainArgs a;
-  a.x = x; a.V = s.V; a.G = s.G; a.part = s.part; a.recs = (const Run*)s.recs; a.cnt = s.cnt; a.off = s.off; a.S = s.runS; a.End = s.runEnd;
-  a.Bad = s.runBad; a.cq = s.cq; a.cm = s.cm; a.sum_out = s.sum; a.params = s.params; a.rng = s.rng; a.tokpos = tokpos; a.tokens_out = tokens_out; a.ids = ids; a.mxkey = s.mxkey;
-  if (mode == CHAIN_SUM) hipLaunchKernelGGL(chain_kernel<CHAIN_SUM>, dim3(1), dim3(TN), 0, st, a);
-  else if (mode == CHAIN_SAMPLE) hipLaunchKernelGGL(chain_kernel<CHAIN_SAMPLE>, dim3(1), dim3(TN), 0, st, a);
+// Stage 1 = the exps (recs / cnt), stage 2 = the probabilities, in index or in sorted order (recs2 / cnt2, cq / cm): two
+// sets of run records because the fused kernels write stage 2 while other workgroups still read stage 1.
+static ChainArgs chain_args(const Sampler& s, const float* x, const double* part, bool stage2) {
+  ChainArgs a = {};
+  a.x = x; a.V = s.V; a.G = s.G; a.part = part;
+  a.recs = (const Run*)(stage2 ? s.recs2 : s.recs); a.cnt = stage2 ? s.cnt2 : s.cnt;
+  a.off = s.off; a.S = s.runS; a.End = s.runEnd; a.Bad = s.runBad; a.cq = s.cq; a.cm = s.cm;
+  a.params = s.params; a.rng = s.rng; a.mxkey = s.mxkey;
+  return a;
+}
+
+static hipError_t launch_chain(const ChainArgs& a, int mode, hipStream_t st) {
+  if (mode == CHAIN_SAMPLE) hipLaunchKernelGGL(chain_kernel<CHAIN_SAMPLE>, dim3(1), dim3(TN), 0, st, a);
   else if (mode == CHAIN_TOPP) hipLaunchKernelGGL(chain_kernel<CHAIN_TOPP>, dim3(1), dim3(TN), 0, st, a);
   else hipLaunchKernelGGL(chain_kernel<CHAIN_DEBUG>, dim3(1), dim3(TN), 0, st, a);
   return hipGetLastError();
@@ -847,7 +917,8 @@ hipError_t running_sums(const float* x_dev, int n, double* prefix_dev, hipStream
   hipError_t e = create(&s, n);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_sums_kernel, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part);
-  e = enqueue_exact(s, x_dev, CHAIN_DEBUG, nullptr, nullptr, nullptr, st);
+  hipLaunchKernelGGL(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
+  e = launch_chain(chain_args(s, x_dev, s.part, false), CHAIN_DEBUG, st);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(prefix_kernel, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part, s.off, s.runS, s.runBad, s.runEnd, prefix_dev);
     e = hipGetLastError();
@@ -863,33 +934,38 @@ hipError_t create(Sampler* s, int V) {
   s->G = (V + TILE - 1) / TILE;
   hipError_t e;
 #define L2S(x) do { e = (x); if (e != hipSuccess) { destroy(s); return e; } } while (0)
-  L2S(hipMalloc(&s->probs, (size_t)V * 4));
-  L2S(hipMalloc(&s->probs_sorted, (size_t)s->G * TILE * 4));
-  L2S(hipMalloc(&s->idx, (size_t)s->G * TILE * 4));
-  L2S(hipMalloc(&s->idx_sorted, (size_t)s->G * TILE * 4));
-  L2S(hipMalloc(&s->run_p, (size_t)s->G * TILE * 4));
+  const size_t padded = (size_t)((V + STILE - 1) / STILE) * STILE, max_runs = (size_t)s->G * (TILE + 1);
+  L2S(hipMalloc(&s->probs, padded * 4));
+  L2S(hipMalloc(&s->probs_n, padded * 4));
+  L2S(hipMalloc(&s->probs_sorted, padded * 4));
+  L2S(hipMalloc(&s->idx, padded * 4));
+  L2S(hipMalloc(&s->idx_sorted, padded * 4));
+  L2S(hipMalloc(&s->run_p, padded * 4));
   L2S(hipMalloc(&s->params, 2 * sizeof(double)));
   L2S(hipMalloc(&s->rng, sizeof(unsigned long long)));
   L2S(hipMalloc(&s->part, (size_t)s->G * sizeof(double)));
-  L2S(hipMalloc(&s->recs, (size_t)s->G * (TILE + 1) * sizeof(Run)));
+  L2S(hipMalloc(&s->part_sorted, (size_t)s->G * sizeof(double)));
+  L2S(hipMemset(s->part_sorted, 0, (size_t)s->G * sizeof(double)));
+  L2S(hipMalloc(&s->recs, max_runs * sizeof(Run)));
+  L2S(hipMalloc(&s->recs2, max_runs * sizeof(Run)));
   L2S(hipMalloc(&s->cnt, (size_t)s->G * sizeof(int)));
+  L2S(hipMalloc(&s->cnt2, (size_t)s->G * sizeof(int)));
   L2S(hipMalloc(&s->off, (size_t)(s->G + 1) * sizeof(int)));
-  const size_t max_runs = (size_t)s->G * (TILE + 1);
   L2S(hipMalloc(&s->runS, max_runs * sizeof(double)));
   L2S(hipMalloc(&s->runEnd, max_runs * sizeof(int)));
   L2S(hipMalloc(&s->runBad, max_runs * sizeof(int)));
-  L2S(hipMalloc(&s->cq, (size_t)s->G * TILE * sizeof(unsigned long long)));
-  L2S(hipMalloc(&s->cm, (size_t)s->G * TILE * sizeof(int)));
-  L2S(hipMalloc(&s->sum, sizeof(double)));
+  L2S(hipMalloc(&s->cq, padded * sizeof(unsigned long long)));
+  L2S(hipMalloc(&s->cm, padded * sizeof(int)));
   L2S(hipMalloc(&s->mxkey, sizeof(unsigned)));
   L2S(hipMemset(s->mxkey, 0, sizeof(unsigned)));
   { const char* e_ = getenv("L2_SAMPLER_SERIAL"); s->serial = e_ && atoi(e_) != 0; }
   // the rank merge holds every tile in LDS: 4 bytes per (padded) element of the 160 KB
-  s->own_sort = !s->serial && (size_t)s->G * TILE * 4 <= 160 * 1024;
-  if (s->own_sort) L2S(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->G * TILE * 4));
+  const size_t rank_lds = padded * 4 + (size_t)s->G * 8;
+  s->own_sort = !s->serial && rank_lds <= 160 * 1024;
+  if (s->own_sort) L2S(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
   s->sort_temp_bytes = 0;
   if (!s->own_sort) {
-    L2S(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, s->sort_temp_bytes, s->probs, s->probs_sorted, s->idx, s->idx_sorted, V, 0, 32, nullptr));
+    L2S(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, s->sort_temp_bytes, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, V, 0, 32, nullptr));
     L2S(hipMalloc(&s->sort_temp, s->sort_temp_bytes ? s->sort_temp_bytes : 16));
   }
 #undef L2S
@@ -897,8 +973,8 @@ hipError_t create(Sampler* s, int V) {
 }
 
 void destroy(Sampler* s) {
-  void* bufs[] = {s->probs, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->sort_temp, s->part, s->recs, s->cnt, s->off,
-                  s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->sum, s->mxkey};
+  void* bufs[] = {s->probs, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->sort_temp, s->part, s->part_sorted,
+                  s->recs, s->recs2, s->cnt, s->cnt2, s->off, s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->mxkey};
   for (void* b : bufs) if (b) (void)hipFree(b);
   *s = Sampler();
 }
@@ -908,7 +984,7 @@ __global__ void iota_kernel(int* idx, int V) {
   if (i < V) idx[i] = i;
 }
 
-hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, hipStream_t st) {
+hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, unsigned long long* amax, hipStream_t st) {
   hipError_t e;
   if (s.serial) {
     if (!topp_mode) {
@@ -923,29 +999,40 @@ hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* t
     hipLaunchKernelGGL(topp_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.rng, tokpos, tokens_out);
     return hipGetLastError();
   }
-  // temperature + softmax (:481-485, :181-194)
-  hipLaunchKernelGGL(scaled_max_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey);
-  hipLaunchKernelGGL(exp_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey, s.probs, s.part);
-  if ((e = enqueue_exact(s, s.probs, CHAIN_SUM, nullptr, nullptr, nullptr, st)) != hipSuccess) return e;
-  if (!topp_mode) {                                                             // sample (:368-376)
-    hipLaunchKernelGGL(normalise_kernel, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.sum, s.part);
-    return enqueue_exact(s, s.probs, CHAIN_SAMPLE, tokpos, tokens_out, nullptr, st);
-  }
-  // sample_topp (:378-394)
-  if (s.own_sort) {                                                             // the division by the sum happens on the way into the sort
-    hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.sum, s.run_p, s.idx);
-    const int n = s.G * TILE;
-    hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT), dim3(RT), (size_t)n * 4, st, s.run_p, s.idx, s.G, s.probs_sorted, s.idx_sorted);
+  // temperature + exp (:481-483, :183-188), runs of the exps' running sum
+  if (!amax) hipLaunchKernelGGL(scaled_max_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey);
+  hipLaunchKernelGGL(exp_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey, amax, s.probs, s.part);
+  hipLaunchKernelGGL(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
+  const ChainArgs exps = chain_args(s, s.probs, s.part, false);
+  ChainArgs pick;
+  if (!topp_mode) {
+    // exact total -> probabilities -> their runs, in one launch; then sample (:368-376)
+    hipLaunchKernelGGL(normalise_runs_kernel, dim3(s.G), dim3(TN), 0, st, exps, s.probs_n, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
+    pick = chain_args(s, s.probs_n, s.part, true);
+  } else if (s.own_sort) {
+    // sample_topp (:378-394): exact total -> probabilities -> sorted tiles in one launch, rank merge, runs of the sorted order
+    const int gs = (s.V + STILE - 1) / STILE, n = gs * STILE;
+    hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(gs), dim3(TN), 0, st, exps, s.probs, s.V, s.run_p, s.idx);
+    hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT), dim3(RT), (size_t)n * 4 + s.G * sizeof(double), st, s.run_p, s.idx, gs, s.G, s.probs_sorted,
+                       s.idx_sorted, s.part_sorted);
+    hipLaunchKernelGGL(runs_kernel<true>, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part_sorted, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
+    pick = chain_args(s, s.probs_sorted, s.part_sorted, true);
+    pick.part_sorted = s.part_sorted;
   } else {
-    hipLaunchKernelGGL(normalise_kernel, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.sum, s.part);
+    // vocabularies beyond the rank merge's LDS: rocPRIM's radix sort
+    hipLaunchKernelGGL(normalise_runs_kernel, dim3(s.G), dim3(TN), 0, st, exps, s.probs_n, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
     hipLaunchKernelGGL(iota_kernel, dim3((s.V + 255) / 256), dim3(256), 0, st, s.idx, s.V);
     size_t bytes = s.sort_temp_bytes;
-    e = hipcub::DeviceRadixSort::SortPairsDescending(s.sort_temp, bytes, s.probs, s.probs_sorted, s.idx, s.idx_sorted, s.V, 0, 32, st);
+    e = hipcub::DeviceRadixSort::SortPairsDescending(s.sort_temp, bytes, s.probs_n, s.probs_sorted, s.idx, s.idx_sorted, s.V, 0, 32, st);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_sums_kernel, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part);
+    hipLaunchKernelGGL(runs_kernel<true>, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
+    pick = chain_args(s, s.probs_sorted, s.part, true);
   }
-  hipLaunchKernelGGL(tile_sums_kernel, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  return enqueue_exact(s, s.probs_sorted, CHAIN_TOPP, tokpos, tokens_out, s.idx_sorted, st);
+  pick.tokpos = tokpos; pick.tokens_out = tokens_out; pick.amax = amax;
+  pick.ids = topp_mode ? s.idx_sorted : nullptr;
+  return launch_chain(pick, topp_mode ? CHAIN_TOPP : CHAIN_SAMPLE, st);
 }
 
 }  // namespace l2s

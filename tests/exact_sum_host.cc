@@ -1,7 +1,8 @@
 // Host harness for llama2.ts_amd/csrc/exact_sum.h: the run / composite / chain arithmetic of the device sampler,
 // driven by plain loops instead of workgroup scans, so the CPU suite can check it against the serial fp64 loop
-// (tests/test_exact_sum_cpu.py).  usage: exact_sum_host <in.f32> <out.f64> [tile] [noise_seed] [sabotage]
-// `noise_seed` != 0 perturbs the approximate prefix by up to 2^-40 relative, standing in for another summation order;
+// (tests/test_exact_sum_cpu.py).  usage: exact_sum_host <in.f32> <out.f64> [tile] [noise_seed] [sabotage] [margin_bits]
+// `noise_seed` != 0 perturbs the approximate prefix by up to 2^-40 relative (2^-25 when margin_bits = 20, the derived
+// prefix of the fused normalise step), standing in for another summation order;
 // `sabotage` = n falsifies the predicted grid of every n-th run, which the chain's check must catch (element-wise re-add).
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +16,7 @@ int main(int argc, char** argv) {
   const int tile = argc > 3 ? atoi(argv[3]) : 1024;
   uint64_t noise = argc > 4 ? strtoull(argv[4], nullptr, 10) : 0;
   const int sabotage = argc > 5 ? atoi(argv[5]) : 0;
+  const int mb = argc > 6 ? atoi(argv[6]) : 32;
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 2;
   fseek(f, 0, SEEK_END);
@@ -34,7 +36,7 @@ int main(int argc, char** argv) {
       double a = base + run;
       if (noise) {
         noise ^= noise >> 12; noise ^= noise << 25; noise ^= noise >> 27;
-        a *= 1.0 + ((double)(int64_t)(noise >> 40) - 8388608.0) * 0x1p-64;
+        a *= 1.0 + ((double)(int64_t)(noise >> 40) - 8388608.0) * (mb == 32 ? 0x1p-64 : 0x1p-49);
       }
       A[i] = a;
       part = run;
@@ -53,7 +55,7 @@ int main(int argc, char** argv) {
     long start = 0;
     for (long i = 0; i < n; ++i) {
       int E;
-      const bool serial = xs::classify(i ? A[i - 1] : 0.0, A[i], x[i], &E);
+      const bool serial = xs::classify(i ? A[i - 1] : 0.0, A[i], x[i], &E, mb);
       el[i].serial = serial; el[i].E = E;
       if (!serial) { acc = xs::compose(acc, E == xs::E_NONE ? xs::identity() : xs::on_grid(x[i], E)); if (E != xs::E_NONE) accE = E; }
       const bool tile_end = (i + 1) % tile == 0 || i + 1 == n;

@@ -28,12 +28,15 @@ def test_run_chain_arithmetic_is_bit_identical_to_the_serial_loop(harness, tmp_p
     for n, v in enumerate(cases):
         want = sum_cases.serial_sums(v)
         v.tofile(src)
-        for tile, noise, sabotage in ((1024, 0, 0), (1024, 77, 0), (256, 0, 0), (64, 12345, 0), (1024, 0, 3), (256, 9, 2)):
-            out = subprocess.check_output([harness, src, dst, str(tile), str(noise), str(sabotage)]).decode()
+        for tile, noise, sabotage, mb in ((1024, 0, 0, 32), (1024, 77, 0, 32), (256, 0, 0, 32), (64, 12345, 0, 32), (1024, 0, 3, 32), (256, 9, 2, 32),
+                                          (1024, 0, 0, 20), (1024, 4242, 0, 20)):
+            out = subprocess.check_output([harness, src, dst, str(tile), str(noise), str(sabotage), str(mb)]).decode()
             got = np.fromfile(dst, dtype=np.float64)
-            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (n, tile, noise, sabotage, int(np.argmax(got != want)), out)
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (n, tile, noise, sabotage, mb, int(np.argmax(got != want)), out)
+            if mb == 20 and n in (0, 1, 2):
+                assert int(out.split()[6]) == 0, out         # the cruder prefix with its wider margin still predicts every run
             if sabotage and n == 0:
                 assert int(out.split()[6]) > 0, out          # the falsified predictions were caught and re-added
-            if noise == 0 and sabotage == 0 and v.size > 20000 and n in (0, 1, 2):      # softmax-like vectors: nearly everything is on a grid
+            if noise == 0 and sabotage == 0 and mb == 32 and v.size > 20000 and n in (0, 1, 2):      # softmax-like vectors: nearly everything is on a grid
                 fields = out.split()
                 assert int(fields[4]) < 400 and int(fields[6]) == 0, out

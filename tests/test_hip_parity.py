@@ -420,6 +420,30 @@ def test_device_sampler_matches_oracle_on_other_settings():
         ctx.close(); ref.close()
 
 
+@pytest.mark.parametrize("hdr,why", [((64, 176, 1, 4, 4, 50257, 16), "vocabulary beyond the rank merge's LDS: rocPRIM sort"),
+                                     ((64, 176, 1, 4, 4, 1000, 16), "one ragged tile"),
+                                     ((64, 176, 1, 4, 4, 5121, 16), "last tile holds one element")])
+def test_device_sampler_other_vocabularies(hdr, why):
+    """Vocabulary sizes around the sampler's tile and LDS limits, plain and top-p, negative temperature (the reference
+    divides by whatever it is given, llama2.ts:482; the maximum then comes from the sampler's own pass instead of the
+    classifier's argmax keys): tokens and RNG state equal the oracle's sampler fed with the device's own logits."""
+    for temperature, topp, seed in [(0.9, 1.0, 11), (1.1, 0.9, 12), (-0.8, 0.95, 13), (0.6, 0.3, 14)]:
+        ctx = runtime.Context(hdr)
+        ctx.synth_fill(3)
+        toks, rng_after = ctx.decode_sample(1, 0, 8, temperature, topp, seed)
+        ref = runtime.Context(hdr)
+        ref.synth_fill(3)
+        rng = O.Rng(seed)
+        tok, want = 1, []
+        for pos in range(8):
+            lg = np.array(ref.forward(tok, pos), copy=True)
+            tok, _ = O.next_token(lg, temperature, topp, rng)
+            want.append(tok)
+        assert toks.tolist() == want, (why, temperature, topp)
+        assert rng_after == rng.state.value
+        ctx.close(); ref.close()
+
+
 def test_device_sampler_temperature_zero_is_greedy():
     ctx = runtime.Context(configs.header("tiny"))
     ctx.synth_fill(1)
