@@ -30,6 +30,14 @@ names = ["qkv", "wo", "w13", "w2"]
 first = per_tok * (F - 1)
 print("config", name, "pos", F - 1, "(cycles since the wave's stamp 0; 1000 cycles ~ 0.42-0.48 us; w0 = wave 0 (the x wave of the latency form), w1 = wave 1)")
 print("%-10s %-8s " % ("kernel", "wg/wave") + " ".join("%7s" % ("s%d" % k) for k in range(1, 12)))
+if os.environ.get("STAMPS_ABS"):   # start / end of the three stamped workgroups on one clock (s_memtime), relative to the earliest start of the launch
+    print("absolute: start and end (stamp 7) of wave 0 of the first / middle / last workgroup, cycles after the earliest of the three starts")
+    for j in list(range(0, 8)) + [per_tok - 1]:
+        slot = (first + j) % 64
+        nm = "cls" if j == per_tok - 1 else "%s.l%d" % (names[j % 4], j // 4)
+        t0 = min(int(buf[slot, w, 0, 0]) for w in range(3) if buf[slot, w, 0, 0])
+        print("%-8s " % nm + "  ".join("%s start %6d end %7d" % (wn, int(buf[slot, w, 0, 0]) - t0, int(buf[slot, w, 0, 7]) - t0) for w, wn in enumerate(("first", "mid", "last"))))
+    sys.exit(0)
 for j in list(range(0, 8)) + [per_tok - 1]:
     slot = (first + j) % 64
     nm = "cls" if j == per_tok - 1 else "%s.l%d" % (names[j % 4], j // 4)
