@@ -82,6 +82,7 @@ struct PhaseArgs {
   // tensor parallel: column-sharded WO/W2 write fp64 partials instead of x
   double* partial;    // non-null (WO/W2 of a tensor-parallel rank): out[i] is not written, partial[i] = fp64 sum
   double inv_n;       // 1.0 / n, correctly rounded by the host (rmsnorm's mean, llama2.ts:174)
+  int rot;            // streaming form: row group g starts its rows at column batch (g * rot) % batches and wraps (0: every row from column 0)
   unsigned long long* amax;  // CLS of the greedy loop: 8 argmax keys (one per 128-byte line) the workgroups fold their best logit into, or null
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
 };
@@ -438,12 +439,18 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   };
   // the flattened (row group, column batch) sequence of this wave: batch k -> (gk, ck); prefetches past the
   // end are clamped to the last valid batch (unconditional loads keep hipcc's waits counted, never vmcnt(0))
-  auto next = [&](int& gi, int& ci, bool& hv) {
-    if (++ci == nchunks) { ci = 0; gi += wstride; }
+  // Every wave starts its rows at another column batch and wraps around: with all waves marching through their rows in step,
+  // the chip's requests of one moment sit a whole row (a power of two of bytes) apart and crowd the same HBM channels
+  // (tools/microbench_rows.hip: 56.5 -> 54.2 us for the w1/w3 shape).  ci counts batches, col(gi, ci) is where batch ci lies.
+  auto rot_of = [&](int gi) { return a.rot ? (int)((unsigned)(gi * a.rot) % (unsigned)nchunks) : 0; };
+  auto col = [&](int ci, int rg) { const int c = ci + rg; return c >= nchunks ? c - nchunks : c; };
+  auto next = [&](int& gi, int& ci, bool& hv, int& rg) {
+    if (++ci == nchunks) { ci = 0; gi += wstride; rg = rot_of(gi); }
     hv = gi < groups;
   };
   const int g0 = vblock * nwaves + wave, c0 = 0;
   const bool h0 = g0 < groups;
+  const int r0 = rot_of(g0);
 
   // ---- prologue: input vector -> LDS (rmsnorm fused, llama2.ts:172-179).
   // Vector-memory results return in issue order: the activations are requested FIRST and the first weight batch
@@ -483,7 +490,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   {
     f4 xr[PRE], wr[PRE];
     stage_load(xr, wr, 0);
-    issue(bufA, h0 ? g0 : groups - 1, h0 ? c0 : 0);
+    issue(bufA, h0 ? g0 : groups - 1, h0 ? col(c0, r0) : 0);
     STAMP(1);
     stage_store(xr, wr, 0);
     STAMP(2);
@@ -527,24 +534,24 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   };
   // ---- GEMV, double buffered: batch k+1 is issued, then batch k consumed (A holds batch 0 on entry).
   // (Pre-issuing two batches costs ~20 VGPRs and one wave per SIMD of occupancy: measured slower.)
-  int g = g0, ch = c0;
+  int g = g0, ch = c0, rg = r0;
   bool have = h0;
   while (have) {
-    int g2 = g, ch2 = ch;
+    int g2 = g, ch2 = ch, rg2 = rg;
     bool have2 = true;
-    next(g2, ch2, have2);
-    issue(bufB, have2 ? g2 : g, have2 ? ch2 : ch);   // unconditional: keeps the wait counts uniform
-    consume(bufA, ch);
+    next(g2, ch2, have2, rg2);
+    issue(bufB, have2 ? g2 : g, have2 ? col(ch2, rg2) : col(ch, rg));   // unconditional: keeps the wait counts uniform
+    consume(bufA, col(ch, rg));
     STAMP(5);
     if (ch == nchunks - 1) finish(g);
     if (!have2) break;
-    int g3 = g2, ch3 = ch2;
+    int g3 = g2, ch3 = ch2, rg3 = rg2;
     bool have3 = true;
-    next(g3, ch3, have3);
-    issue(bufA, have3 ? g3 : g2, have3 ? ch3 : ch2);
-    consume(bufB, ch2);
+    next(g3, ch3, have3, rg3);
+    issue(bufA, have3 ? g3 : g2, have3 ? col(ch3, rg3) : col(ch2, rg2));
+    consume(bufB, col(ch2, rg2));
     if (ch2 == nchunks - 1) finish(g2);
-    g = g3; ch = ch3; have = have3;
+    g = g3; ch = ch3; rg = rg3; have = have3;
   }
   if (MODE == MODE_CLS && a.amax) {
     // greedy loop: ONE memory-side maximum per workgroup (no value returned, nothing waits for it); the launch

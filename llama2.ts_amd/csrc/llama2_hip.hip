@@ -217,7 +217,7 @@ struct l2_ctx {
   bool ran_forward = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // tuning overrides (env)
-  int tune_R = 0, tune_U = 0, tune_nwaves = 0, tune_gridcap = 0;
+  int tune_R = 0, tune_U = 0, tune_nwaves = 0, tune_gridcap = 0, tune_rot = 5;
 };
 
 static bool is_layered(int kind) { return kind >= L2_T_RMS_ATT && kind <= L2_T_W3; }
@@ -356,6 +356,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->tune_U = env_int("L2_TUNE_U", 0);
   c->tune_nwaves = env_int("L2_TUNE_NWAVES", 0);
   c->tune_gridcap = env_int("L2_TUNE_GRIDCAP", 0);
+  c->tune_rot = env_int("L2_TUNE_ROT", 5);
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !env_int("L2_TP_FORCE_COMM", 0)) ? 1 : 0);
   c->profile_sync = env_int("L2_PROFILE_SYNC", 0);
 
@@ -860,6 +861,7 @@ static hipError_t launch_small(const l2_ctx* c, const PhaseArgs& a, hipStream_t 
 template <int MODE>
 static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream_t st) {
   PhaseArgs a = a_in;
+  a.rot = c->tune_rot;
 #ifdef L2_STAMPS
   a.dbg = c->dbg + (size_t)(g_stamp_slot++ % 64) * 108;
 #endif
