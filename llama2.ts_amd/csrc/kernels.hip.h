@@ -36,7 +36,12 @@ enum { CTR_STRIDE = 32 };
 struct Stamps {
   unsigned long long t[L2_NSTAMP];
   unsigned long long* dst;
-  __device__ __forceinline__ Stamps(unsigned long long* dbg) {
+  unsigned long long* wg;      // every workgroup: {start, end} on the constant 100 MHz clock all XCDs share (s_memrealtime)
+  unsigned long long rt0;
+  __device__ __forceinline__ Stamps(unsigned long long* dbg, unsigned long long* dbg_wg = nullptr) {
+    wg = (dbg_wg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) ? dbg_wg + 2 * blockIdx.x : nullptr;
+    rt0 = __builtin_readcyclecounter();
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0));
 #pragma unroll
     for (int k = 0; k < L2_NSTAMP; ++k) t[k] = 0;
     const int b = blockIdx.x, nb = gridDim.x, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -45,6 +50,14 @@ struct Stamps {
     dst = (dbg && sel >= 0 && ws >= 0 && (threadIdx.x & 63) == 0 && blockIdx.y == 0) ? dbg + (sel * 3 + ws) * L2_NSTAMP : nullptr;
   }
   __device__ __forceinline__ ~Stamps() {
+    if (wg) {
+      unsigned long long rt1;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1));
+      unsigned xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      wg[0] = rt0; wg[1] = (rt1 - rt0) | ((unsigned long long)(xcc & 0xf) << 32) | ((unsigned long long)(hwid & 0xffff00) << 36);
+    }
     if (dst) {
 #pragma unroll
       for (int k = 0; k < L2_NSTAMP; ++k) dst[k] = t[k];
@@ -52,9 +65,11 @@ struct Stamps {
   }
 };
 #define STAMP_INIT(dbg) Stamps st_(dbg)
+#define STAMP_INIT_WG(dbg, wg) Stamps st_(dbg, wg)
 #define STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_.t[k])::"memory")
 #else
 #define STAMP_INIT(dbg) do { } while (0)
+#define STAMP_INIT_WG(dbg, wg) do { } while (0)
 #define STAMP(k) do { } while (0)
 #endif
 
@@ -85,6 +100,7 @@ struct PhaseArgs {
   int rot;            // streaming form: row group g starts its rows at column batch (g * rot) % batches and wraps (0: every row from column 0)
   unsigned long long* amax;  // CLS of the greedy loop: 8 argmax keys (one per 128-byte line) the workgroups fold their best logit into, or null
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
+  unsigned long long* dbg_wg;  // the same: {start, end} of every workgroup
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -407,7 +423,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
   const int wstride = vgrid * nwaves;
 
-  STAMP_INIT(a.dbg);
+  STAMP_INIT_WG(a.dbg, a.dbg_wg);
   STAMP(0);
   f4 bufA[R][U], bufB[R][U];
   auto issue = [&](f4 (&buf)[R][U], int gi, int ci) {
@@ -520,17 +536,27 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
 
   const EpiPre nopre = {0.0f, 0.0f};
   unsigned long long best = 0;      // CLS: this lane's best (logit, index) so far
-  auto finish = [&](int gi) {
-    if (R == 2) wave_sum2(acc[0], acc[R - 1]);
+  // The epilogue of a finished row group (reduction across the lanes, RoPE / SwiGLU / residual, stores) runs AFTER the next
+  // batch has been requested, from a copy of the sums: both register sets stay in flight while it computes (with the
+  // epilogue in front of the request the wave had one batch in flight for ~500 cycles per group, 6 times per wave of w1/w3)
+  double pacc[R];
+  int pend = -1;
+  auto stash = [&](int gi) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { pacc[r] = acc[r]; acc[r] = 0.0; }
+    pend = gi;
+  };
+  auto finish = [&]() {
+    if (pend < 0) return;
+    if (R == 2) wave_sum2(pacc[0], pacc[R - 1]);
     else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+      for (int r = 0; r < R; ++r) pacc[r] = wave_sum(pacc[r]);
     }
     STAMP(6);
-    finish_group<MODE, R, false>(a, gi, acc, lane, token, pos, nopre, best);
+    finish_group<MODE, R, false>(a, pend, pacc, lane, token, pos, nopre, best);
     STAMP(7);
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    pend = -1;
   };
   // ---- GEMV, double buffered: batch k+1 is issued, then batch k consumed (A holds batch 0 on entry).
   // (Pre-issuing two batches costs ~20 VGPRs and one wave per SIMD of occupancy: measured slower.)
@@ -541,18 +567,21 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
     bool have2 = true;
     next(g2, ch2, have2, rg2);
     issue(bufB, have2 ? g2 : g, have2 ? col(ch2, rg2) : col(ch, rg));   // unconditional: keeps the wait counts uniform
+    finish();
     consume(bufA, col(ch, rg));
     STAMP(5);
-    if (ch == nchunks - 1) finish(g);
+    if (ch == nchunks - 1) stash(g);
     if (!have2) break;
     int g3 = g2, ch3 = ch2, rg3 = rg2;
     bool have3 = true;
     next(g3, ch3, have3, rg3);
     issue(bufA, have3 ? g3 : g2, have3 ? col(ch3, rg3) : col(ch2, rg2));
+    finish();
     consume(bufB, col(ch2, rg2));
-    if (ch2 == nchunks - 1) finish(g2);
+    if (ch2 == nchunks - 1) stash(g2);
     g = g3; ch = ch3; rg = rg3; have = have3;
   }
+  finish();
   if (MODE == MODE_CLS && a.amax) {
     // greedy loop: ONE memory-side maximum per workgroup (no value returned, nothing waits for it); the launch
     // boundary orders it before the one-wave kernel that reads the eight keys (argmax_finish_kernel)

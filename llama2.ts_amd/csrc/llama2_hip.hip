@@ -423,8 +423,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipHostGetDevicePointer((void**)&c->h_logits_dev, c->h_logits, 0));
   c->opt_zero_copy = env_int("L2_ZERO_COPY_LOGITS", G == 1 ? 1 : 0);
 #ifdef L2_STAMPS
-  CK(hipMalloc(&c->dbg, 8 * 66 * 108));
-  CK(hipMemset(c->dbg, 0, 8 * 66 * 108));
+  CK(hipMalloc(&c->dbg, 8 * (66 * 108 + 64 * 2048)));
+  CK(hipMemset(c->dbg, 0, 8 * (66 * 108 + 64 * 2048)));
 #endif
   CK(hipStreamSynchronize(c->stream));
 #undef CK
@@ -777,10 +777,13 @@ static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
   int grid = (groups + g.nwaves - 1) / g.nwaves;
   // persistent grid: 2 workgroups (8 waves) per CU, each wave looping over row groups with both register sets
   // full, measured best on the 7B shapes (129.6 us of GEMV per layer vs 134.1 at 6 per CU)
-  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : 256 * 2;
+  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : c->n_cus * 2;
   if (grid > cap) {
     // balanced: every wave gets the same number k of row groups (w1/w3 of 7B: 5504 groups on 2048 waves would
-    // leave a third of the chip idle in the last round; 459 workgroups x 4 waves x 3 groups covers it evenly)
+    // leave a third of the chip idle in the last round; 459 workgroups x 4 waves x 3 groups covers it evenly).
+    // Measured against a full grid that deals the odd groups evenly over the CUs (the 53 CUs with one workgroup are done
+    // after 44 us, the others after 53-57: tools/stamps.py STAMPS_WG=2): the full grid's last round ran as slowly as any
+    // other, 216.5 vs 219.3 tok/s.
     const int waves_cap = cap * g.nwaves;
     const int k = (groups + waves_cap - 1) / waves_cap;
     grid = (groups + g.nwaves * k - 1) / (g.nwaves * k);
@@ -863,6 +866,7 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   PhaseArgs a = a_in;
   a.rot = c->tune_rot;
 #ifdef L2_STAMPS
+  a.dbg_wg = c->dbg + 66 * 108 + (size_t)(g_stamp_slot % 64) * 2048;
   a.dbg = c->dbg + (size_t)(g_stamp_slot++ % 64) * 108;
 #endif
   if (use_small(c, MODE, a.rows, a.n)) return launch_small<MODE>(c, a, st);

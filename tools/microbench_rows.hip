@@ -1,0 +1,142 @@
+// How a GEMV should walk a row-major matrix on MI355X: us per link of a chain of dependent kernels that only stream
+// (float4 non-temporal loads, summed), for the Llama-2-7B phase shapes and several ways of dealing the bytes to the waves.
+//   stream    grid-stride over the whole matrix (what a copy kernel does): the reference point
+//   rows      a wave owns R = 2 rows at a time (adjacent rows, or row i of two matrices as w1 / w3) and reads them front to
+//             back in batches of U x 1 KB per row, two batches in flight -- libllama2hip's streaming form
+//   rows+rot  the same, every row group starting at another batch and wrapping around
+//   +stagger  the second row of the group half a row ahead of the first
+//   +fma      rows+rot with the GEMV's arithmetic (x from LDS, fp64 widening and FMA of every weight)
+// With all waves marching through their rows in step, the requests in flight at one moment sit a whole row (16 / 44 KB)
+// apart; rotating the start spreads them over the HBM channels.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mbr tools/microbench_rows.hip && /tmp/mbr
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ void fill(float* p, size_t n) { for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; p[i] = ((float)(x & 0xffff) - 32768.0f) * 1e-6f; } }
+
+__global__ void __launch_bounds__(256) stream(const f4* w, size_t n4, const float* carry_in, float* carry_out) {
+  const float c = carry_in[0];
+  f4 acc = {c, 0.f, 0.f, 0.f};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    f4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(w + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u];
+  }
+  for (; i < n4; i += stride) acc += w[i];
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) carry_out[1] = 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
+}
+
+// PAIR: the group's two rows are row g of the first and of the second half of the matrix (w1 / w3); else rows 2g, 2g + 1
+template <bool PAIR, int ROT, bool STAGGER, int WORK = 0>
+__global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const float* carry_in, float* carry_out) {
+  constexpr int U = 2;
+  const float c = carry_in[0];
+  f4 acc = {c, 0.f, 0.f, 0.f};
+  // WORK 1: the GEMV's arithmetic as well -- x (n floats) staged in LDS, every weight widened to fp64 and multiplied in
+  __shared__ f4 xs[WORK ? 2752 : 1];
+  double d0 = 0.0, d1 = 0.0;
+  if (WORK) {
+    for (int i = threadIdx.x; i < n / 4; i += 256) { const float v = 1e-3f * (float)(i & 7); xs[i] = f4{v, v, v, v}; }
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = n / 4, batches = (n4 + 64 * U - 1) / (64 * U), groups = rows / 2, tw = gridDim.x * 4;
+  auto load = [&](f4 (&b)[2][U], int g, int ci) {
+    const f4* r0 = w + (size_t)(PAIR ? g : 2 * g) * n4;
+    const f4* r1 = w + (size_t)(PAIR ? groups + g : 2 * g + 1) * n4;
+    const int rot = ROT ? (g * ROT) % batches : 0;
+    int c0 = ci + rot; c0 -= c0 >= batches ? batches : 0;
+    int c1 = c0 + (STAGGER ? batches / 2 : 0); c1 -= c1 >= batches ? batches : 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      b[0][u] = __builtin_nontemporal_load(r0 + min(c0 * 64 * U + u * 64 + lane, n4 - 1));
+      b[1][u] = __builtin_nontemporal_load(r1 + min(c1 * 64 * U + u * 64 + lane, n4 - 1));
+    }
+  };
+  f4 A[2][U], B[2][U];
+  int g = blockIdx.x * 4 + wave, ci = 0;
+  if (g < groups) load(A, g, 0);
+  while (g < groups) {
+    int g2 = g, c2 = ci + 1;
+    if (c2 == batches) { c2 = 0; g2 += tw; }
+    load(B, g2 < groups ? g2 : g, g2 < groups ? c2 : ci);
+    if (WORK) {
+      const int rot = ROT ? (g * ROT) % batches : 0;
+      int c0 = ci + rot; c0 -= c0 >= batches ? batches : 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f4 xv = xs[min(c0 * 64 * U + u * 64 + lane, n4 - 1)];
+        const double x0 = xv.x, x1 = xv.y, x2 = xv.z, x3 = xv.w;
+        d0 += (double)A[0][u].x * x0; d0 += (double)A[0][u].y * x1; d0 += (double)A[0][u].z * x2; d0 += (double)A[0][u].w * x3;
+        d1 += (double)A[1][u].x * x0; d1 += (double)A[1][u].y * x1; d1 += (double)A[1][u].z * x2; d1 += (double)A[1][u].w * x3;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) { acc += A[0][u]; acc += A[1][u]; }
+    }
+    if (g2 >= groups) break;
+    int g3 = g2, c3 = c2 + 1;
+    if (c3 == batches) { c3 = 0; g3 += tw; }
+    load(A, g3 < groups ? g3 : g2, g3 < groups ? c3 : c2);
+    if (WORK) {
+      const int rot = ROT ? (g2 * ROT) % batches : 0;
+      int c0 = c2 + rot; c0 -= c0 >= batches ? batches : 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f4 xv = xs[min(c0 * 64 * U + u * 64 + lane, n4 - 1)];
+        const double x0 = xv.x, x1 = xv.y, x2 = xv.z, x3 = xv.w;
+        d0 += (double)B[0][u].x * x0; d0 += (double)B[0][u].y * x1; d0 += (double)B[0][u].z * x2; d0 += (double)B[0][u].w * x3;
+        d1 += (double)B[1][u].x * x0; d1 += (double)B[1][u].y * x1; d1 += (double)B[1][u].z * x2; d1 += (double)B[1][u].w * x3;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) { acc += B[0][u]; acc += B[1][u]; }
+    }
+    g = g3; ci = c3;
+  }
+  if (acc.x + acc.y + acc.z + acc.w + (float)(d0 + d1) == 12345.678f) carry_out[1] = 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
+}
+
+int main() {
+  const size_t total = (size_t)6 << 30;
+  f4* w; float* carry;
+  (void)hipMalloc(&w, total); (void)hipMalloc(&carry, 1 << 16); (void)hipMemset(carry, 0, 1 << 16);
+  hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, (float*)w, total / 4); (void)hipDeviceSynchronize();
+  hipStream_t sa; (void)hipStreamCreate(&sa);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  printf("us per link of a chain of dependent streaming kernels (launch boundary included), 512 workgroups of 256 threads\n");
+  printf("%-34s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma");
+  struct { const char* name; int rows, n; bool pair; } shapes[] = {{"w1+w3  2 x 11008 x 4096 (361 MB)", 22016, 4096, true}, {"wqkv   12288 x 4096 (201 MB)", 12288, 4096, false},
+                                                                   {"w2     4096 x 11008 (180 MB)", 4096, 11008, false}, {"wo     4096 x 4096 (67 MB)", 4096, 4096, false},
+                                                                   {"wcls   32000 x 4096 (524 MB)", 32000, 4096, false}};
+  for (auto sh : shapes) {
+    const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
+    printf("%-34s", sh.name);
+    for (int var = 0; var < 7; ++var) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 4; ++rep) {
+        (void)hipEventRecord(e0, sa);
+        for (int k = 0; k < nk; ++k) {
+          const f4* wk = w + (size_t)k * link4; const float* ci = carry + 16 * k; float* co = carry + 16 * (k + 1);
+          const dim3 g(512), b(256);
+#define ROWSW(R_, S_) do { if (sh.pair) hipLaunchKernelGGL((rows2<true, R_, S_, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, R_, S_, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); } while (0)
+#define ROWS(R_, S_) do { if (sh.pair) hipLaunchKernelGGL((rows2<true, R_, S_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, R_, S_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); } while (0)
+          if (var == 0) hipLaunchKernelGGL(stream, g, b, 0, sa, wk, link4, ci, co);
+          else if (var == 1) ROWS(0, false); else if (var == 2) ROWS(5, false); else if (var == 3) ROWS(5, true); else if (var == 4) ROWS(3, false); else if (var == 5) ROWS(7, false); else ROWSW(5, false);
+        }
+        (void)hipEventRecord(e1, sa); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+      }
+      printf(" %8.2f", best * 1e3 / nk);
+    }
+    printf("\n");
+  }
+  return 0;
+}

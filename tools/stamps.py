@@ -21,15 +21,43 @@ tok = 1
 for pos in range(F):
     tok = int(np.argmax(ctx.forward(tok, pos)))
 per_tok = 4 * cfg.n_layers + 1            # phase-kernel launches per token (attention stamps: stamps_attn.py)
-buf = np.zeros(66 * 108, dtype=np.uint64)
+buf = np.zeros(66 * 108 + 64 * 2048, dtype=np.uint64)
 L = runtime.lib()
 L.l2_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert L.l2_debug_stamps(ctx._h, buf.ctypes.data, buf.size) == 0
+wg = buf[66 * 108:].reshape(64, 1024, 2).astype(np.int64)
 buf = buf[:64 * 108].reshape(64, 3, 3, 12).astype(np.int64)
 names = ["qkv", "wo", "w13", "w2"]
 first = per_tok * (F - 1)
 print("config", name, "pos", F - 1, "(cycles since the wave's stamp 0; 1000 cycles ~ 0.42-0.48 us; w0 = wave 0 (the x wave of the latency form), w1 = wave 1)")
 print("%-10s %-8s " % ("kernel", "wg/wave") + " ".join("%7s" % ("s%d" % k) for k in range(1, 12)))
+if os.environ.get("STAMPS_WG"):   # when every workgroup of a launch started and ended (100 MHz clock shared by the XCDs; streaming form only)
+    print("per launch: workgroups, then start and end times in us after the first start: min / median / max")
+    for j in list(range(0, 8)) + [per_tok - 1]:
+        slot = (first + j) % 64
+        nm = "cls" if j == per_tok - 1 else "%s.l%d" % (names[j % 4], j // 4)
+        t = wg[slot]; t = t[t[:, 0] > 0]
+        if not len(t):
+            continue
+        t = t[np.abs(t[:, 0] - np.median(t[:, 0])) < 100000]      # a smaller grid leaves an older launch's entries in the slot
+        t0 = t[:, 0].min(); st = (t[:, 0] - t0) / 100.0; life = (t[:, 1] & 0xffffffff) / 100.0; en = st + life
+        xcc = (t[:, 1] >> 32) & 0xf; hw = (t[:, 1] >> 44) & 0xffff      # HW_ID bits 8..: cu_id (4), sh_id (1), se_id (3)
+        print("%-8s %4d wgs  start %5.2f / %5.2f / %5.2f   end %6.2f / %6.2f / %6.2f   lifetime %6.2f / %6.2f / %6.2f" % (
+            nm, len(t), st.min(), np.median(st), st.max(), en.min(), np.median(en), en.max(), life.min(), np.median(life), life.max()))
+        if os.environ.get("STAMPS_WG") == "3" and nm in ("w13.l0", "qkv.l0"):
+            full = wg[slot]
+            for b in list(range(0, 12)) + list(range(250, 262)) + list(range(452, 459)):
+                if full[b, 0]: print("          block %3d -> xcc %d hw_id 0x%04x lifetime %.1f" % (b, (full[b, 1] >> 32) & 0xf, (full[b, 1] >> 44) & 0xffff, (full[b, 1] & 0xffffffff) / 100.0))
+        if os.environ.get("STAMPS_WG") == "2":
+            print("          median lifetime by XCD: " + " ".join("%d:%.1f(%d)" % (x, np.median(life[xcc == x]), (xcc == x).sum()) for x in sorted(set(xcc.tolist()))))
+            cu = hw & 0xff
+            per_cu = {}
+            for k in range(len(t)):
+                per_cu.setdefault((int(xcc[k]), int(cu[k])), []).append(life[k])
+            ones = [v[0] for v in per_cu.values() if len(v) == 1]; twos = [x for v in per_cu.values() if len(v) == 2 for x in v]; more = [x for v in per_cu.values() if len(v) > 2 for x in v]
+            print("          CUs holding 1 / 2 / more workgroups: %d / %d / %d; median lifetime %.1f / %.1f / %.1f" % (
+                len(ones), len(twos) // 2, len(per_cu) - len(ones) - len(twos) // 2, np.median(ones) if ones else 0, np.median(twos) if twos else 0, np.median(more) if more else 0))
+    sys.exit(0)
 if os.environ.get("STAMPS_ABS"):   # start / end of the three stamped workgroups on one clock (s_memtime), relative to the earliest start of the launch
     print("absolute: start and end (stamp 7) of wave 0 of the first / middle / last workgroup, cycles after the earliest of the three starts")
     for j in list(range(0, 8)) + [per_tok - 1]:
