@@ -24,8 +24,12 @@ for c in stories15M stories110M llama2_7b_L2; do python tools/stamps_attn.py $c 
 hipcc --offload-arch=gfx950 -O3 -o /tmp/mbp tools/microbench_phase.hip 2>/dev/null && /tmp/mbp > $out/microbench_phase_floor.txt
 hipcc --offload-arch=gfx950 -O3 -o /tmp/mbl tools/microbench_launch.hip 2>/dev/null && /tmp/mbl > $out/microbench_launch.txt
 hipcc --offload-arch=gfx950 -O3 -o /tmp/mbi tools/microbench_icache.hip 2>/dev/null && /tmp/mbi > $out/microbench_icache.txt
+hipcc --offload-arch=gfx950 -O3 -o /tmp/mbr tools/microbench_rows.hip 2>/dev/null && timeout 300 /tmp/mbr > $out/microbench_rows_run.txt
+STAMPS_WG=2 python tools/stamps.py llama2_7b_L2 20 > $out/stamps_workgroups_7b_width_run.txt 2>&1
+for r in 0 5 0 5; do bash tools/kernel_times.sh llama2_7b L2_TUNE_ROT=$r; done > $out/kernel_times_rot_ab.txt 2>&1
 # context curves (attention split levels) and the prefill / sampler extras
 for c in llama2_7b stories110M; do for s in 1 8; do L2_ATTN_SPLITS=$s python tools/ctx_curve.py $c | tail -1; done; python tools/ctx_curve.py $c | tail -1; done > $out/ctx_curve.txt 2>&1
 bash tools/prefill_pmc.sh > /dev/null 2>&1; cp gpurun_out/pfpmc_r02/summary.json $out/prefill_mfma_pmc_7b_width_64tok.json
-python tools/sampler_bench.py > $out/sampler_bench.txt 2>&1
+for c in stories110M stories110M stories15M llama2_7b_L2; do python tools/sampler_bench.py $c; done > $out/sampler_bench_run.txt 2>&1
+bash tools/sampler_profile.sh > $out/sampler_kernels.txt 2>&1
 cat $out/pytest_gpu.txt
