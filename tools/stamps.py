@@ -57,6 +57,13 @@ if os.environ.get("STAMPS_WG"):   # when every workgroup of a launch started and
             ones = [v[0] for v in per_cu.values() if len(v) == 1]; twos = [x for v in per_cu.values() if len(v) == 2 for x in v]; more = [x for v in per_cu.values() if len(v) > 2 for x in v]
             print("          CUs holding 1 / 2 / more workgroups: %d / %d / %d; median lifetime %.1f / %.1f / %.1f" % (
                 len(ones), len(twos) // 2, len(per_cu) - len(ones) - len(twos) // 2, np.median(ones) if ones else 0, np.median(twos) if twos else 0, np.median(more) if more else 0))
+    if os.environ.get("STAMPS_WG") == "4":   # is a workgroup that is slow in one launch slow in the next launch of the same kind?
+        for a_, b_ in ((0, 4), (1, 5), (2, 6), (3, 7)):
+            la = (wg[(first + a_) % 64][:, 1] & 0xffffffff) / 100.0; lb = (wg[(first + b_) % 64][:, 1] & 0xffffffff) / 100.0
+            ok = (wg[(first + a_) % 64][:, 0] > 0) & (wg[(first + b_) % 64][:, 0] > 0) & (la > 0.5 * np.median(la[la > 0])) & (lb > 0.5 * np.median(lb[lb > 0])) & (la < 2 * np.median(la[la > 0])) & (lb < 2 * np.median(lb[lb > 0]))
+            nb = 459 if a_ == 2 else 512
+            ok[nb:] = False
+            print("%s layer 0 vs layer 1: correlation of the workgroups' lifetimes %.2f (n = %d, std %.2f / %.2f us)" % (names[a_], np.corrcoef(la[ok], lb[ok])[0, 1], ok.sum(), la[ok].std(), lb[ok].std()))
     sys.exit(0)
 if os.environ.get("STAMPS_ABS"):   # start / end of the three stamped workgroups on one clock (s_memtime), relative to the earliest start of the launch
     print("absolute: start and end (stamp 7) of wave 0 of the first / middle / last workgroup, cycles after the earliest of the three starts")
