@@ -5,6 +5,7 @@
 //             back in batches of U x 1 KB per row, two batches in flight -- libllama2hip's streaming form
 //   rows+rot  the same, every row group starting at another batch and wrapping around
 //   +stagger  the second row of the group half a row ahead of the first
+//   cols      one 512-thread workgroup per CU owns a block of row groups, wave w streams column batch w of each of them
 //   +fma      rows+rot with the GEMV's arithmetic (x from LDS, fp64 widening and FMA of every weight)
 // With all waves marching through their rows in step, the requests in flight at one moment sit a whole row (16 / 44 KB)
 // apart; rotating the start spreads them over the HBM channels.
@@ -104,6 +105,39 @@ __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const
   if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
 }
 
+// cols: one 512-thread workgroup per CU owns a contiguous block of row groups; wave w streams column batch w (2 KB per row)
+// of every group of the block -- every wave moves the same number of bytes, nothing is left to a last round
+template <bool PAIR>
+__global__ void __launch_bounds__(512) cols8(const f4* w, int rows, int n, const float* carry_in, float* carry_out) {
+  constexpr int U = 2;
+  const float c = carry_in[0];
+  f4 acc = {c, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = n / 4, groups = rows / 2;
+  const int per = (groups + gridDim.x - 1) / gridDim.x, g0 = blockIdx.x * per, g1 = min(groups, g0 + per);
+  auto load = [&](f4 (&b)[2][U], int g) {
+    const f4* r0 = w + (size_t)(PAIR ? g : 2 * g) * n4 + wave * 64 * U;
+    const f4* r1 = w + (size_t)(PAIR ? groups + g : 2 * g + 1) * n4 + wave * 64 * U;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { b[0][u] = __builtin_nontemporal_load(r0 + u * 64 + lane); b[1][u] = __builtin_nontemporal_load(r1 + u * 64 + lane); }
+  };
+  f4 A[2][U], B[2][U];
+  int g = g0;
+  if (g < g1) load(A, g);
+  while (g < g1) {
+    load(B, g + 1 < g1 ? g + 1 : g);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { acc += A[0][u]; acc += A[1][u]; }
+    if (g + 1 >= g1) break;
+    load(A, g + 2 < g1 ? g + 2 : g + 1);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { acc += B[0][u]; acc += B[1][u]; }
+    g += 2;
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) carry_out[1] = 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
+}
+
 int main() {
   const size_t total = (size_t)6 << 30;
   f4* w; float* carry;
@@ -112,14 +146,15 @@ int main() {
   hipStream_t sa; (void)hipStreamCreate(&sa);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   printf("us per link of a chain of dependent streaming kernels (launch boundary included), 512 workgroups of 256 threads\n");
-  printf("%-34s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma");
+  printf("%-34s %8s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma", "cols");
   struct { const char* name; int rows, n; bool pair; } shapes[] = {{"w1+w3  2 x 11008 x 4096 (361 MB)", 22016, 4096, true}, {"wqkv   12288 x 4096 (201 MB)", 12288, 4096, false},
                                                                    {"w2     4096 x 11008 (180 MB)", 4096, 11008, false}, {"wo     4096 x 4096 (67 MB)", 4096, 4096, false},
                                                                    {"wcls   32000 x 4096 (524 MB)", 32000, 4096, false}};
   for (auto sh : shapes) {
     const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
     printf("%-34s", sh.name);
-    for (int var = 0; var < 7; ++var) {
+    for (int var = 0; var < 8; ++var) {
+      if (var == 7 && sh.n != 4096) continue;            // eight column batches of 2 KB: 4096 columns
       float best = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0, sa);
@@ -129,7 +164,8 @@ int main() {
 #define ROWSW(R_, S_) do { if (sh.pair) hipLaunchKernelGGL((rows2<true, R_, S_, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, R_, S_, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); } while (0)
 #define ROWS(R_, S_) do { if (sh.pair) hipLaunchKernelGGL((rows2<true, R_, S_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, R_, S_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); } while (0)
           if (var == 0) hipLaunchKernelGGL(stream, g, b, 0, sa, wk, link4, ci, co);
-          else if (var == 1) ROWS(0, false); else if (var == 2) ROWS(5, false); else if (var == 3) ROWS(5, true); else if (var == 4) ROWS(3, false); else if (var == 5) ROWS(7, false); else ROWSW(5, false);
+          else if (var == 1) ROWS(0, false); else if (var == 2) ROWS(5, false); else if (var == 3) ROWS(5, true); else if (var == 4) ROWS(3, false); else if (var == 5) ROWS(7, false); else if (var == 6) ROWSW(5, false);
+          else { if (sh.pair) hipLaunchKernelGGL((cols8<true>), dim3(256), dim3(512), 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((cols8<false>), dim3(256), dim3(512), 0, sa, wk, sh.rows, sh.n, ci, co); }
         }
         (void)hipEventRecord(e1, sa); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
