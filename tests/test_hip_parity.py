@@ -481,11 +481,13 @@ def test_sampler_serial_and_parallel_forms_agree(monkeypatch):
 
 
 @pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_ATTN_NW": "4"}), ("stories110M", {"L2_ATTN_NW": "8"}), ("stories15M", {"L2_ATTN_NW": "8"}),
-                                      ("stories110M", {"L2_SMALL_MAX": "0"}), ("stories15M", {"L2_SMALL_MAX": "0"})])
+                                      ("stories110M", {"L2_SMALL_MAX": "0"}), ("stories15M", {"L2_SMALL_MAX": "0"}),
+                                      ("llama2_7b_L2", {"L2_TUNE_ROT": "0"}), ("llama2_7b_L2", {"L2_TUNE_ROT": "3"}),
+                                      ("stories110M", {"L2_SMALL_MAX": "0", "L2_TUNE_ROT": "7"})])
 def test_launch_geometry_variants_match_reference(monkeypatch, name, env):
-    """The other geometry of the attention tile kernel (4 waves x 16 tiles / 8 waves x 8 tiles per round) and the
-    streaming form of the GEMV phases on shapes that default to the latency form: same goldens, same tolerance,
-    tokens exact."""
+    """The other geometry of the attention tile kernel (4 waves x 16 tiles / 8 waves x 8 tiles per round), the
+    streaming form of the GEMV phases on shapes that default to the latency form, and other starting columns of its rows:
+    same goldens, same tolerance, tokens exact."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     meta, g = load_gold(name)
