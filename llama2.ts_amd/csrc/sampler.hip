@@ -855,7 +855,8 @@ __global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const
   double* lpart = reinterpret_cast<double*>(lds_p + n);
   if (tid < G) lpart[tid] = 0.0;
   // every workgroup pulls all G tiles; measured: one 16-byte load in flight per thread (8 KB per workgroup) beats 4, 8 and 16
-  // (+5 / +5 / +8 us) -- the same lines are wanted by every CU at once and deeper queues only lengthen the wait behind them
+  // (+5 / +5 / +8 us) -- the same lines are wanted by every CU at once and deeper queues only lengthen the wait behind them;
+  // an LDS-DMA fill (global_load_lds_dwordx4, every 1 KB chunk in flight at once) takes the same time as this loop
   for (int j = tid * 4; j < n; j += RT * 4) *reinterpret_cast<int4*>(lds_p + j) = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(run_p) + j);
   const int e = blockIdx.x * RT + tid;
   const int my_id = e < n ? run_id[e] : -1;
