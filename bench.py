@@ -264,9 +264,25 @@ def main():
 
     device = int(os.environ.get("L2_BENCH_FORCE_DEVICE", local_rank))   # test hook: several ranks on one GPU (replicas only)
     cfg = runtime.Config(hdr)
+    tp_note = None
+    ctx = None
     if tp:
-        ctx = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=tp["id"])
-    else:
+        # the tensor-parallel group has never run on more than one GPU (no multi-GPU box in development): if any rank cannot
+        # join it, every rank says so over gloo and the job measures independent replicas instead of dying without a line
+        err = ""
+        try:
+            ctx = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=tp["id"])
+        except Exception as e:      # noqa: BLE001 -- whatever it is, the other ranks have to hear about it
+            err = "%s: %s" % (type(e).__name__, e)
+        import torch
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            if ctx is not None:
+                ctx.close()
+            ctx, tp, shards = None, None, False
+            tp_note = "tensor-parallel group could not be created (%s); measured %d independent replicas instead" % (err or "another rank failed", world)
+    if ctx is None:
         ctx = runtime.Context(hdr, device=device)
     ctx.synth_fill(args.seed)
 
@@ -319,6 +335,8 @@ def main():
         "hbm_frac_end_to_end": round(bpt * value / 1e9 / per_gpu_streams / HBM_PEAK_GBS / (world if shards else 1), 4),
     }
 
+    if tp_note:
+        out["note"] = tp_note
     if extras:
         if not args.no_dropin:   # the same K steps through the blocking drop-in boundary (logits to the host every token)
             tok = 1
