@@ -25,6 +25,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "kernels.hip.h"
@@ -196,6 +197,7 @@ struct l2_ctx {
   int attn_nw = 0;                  // L2_ATTN_NW: waves per attention workgroup (0: by head size)
   int small_max = 0;                // L2_SMALL_MAX: largest matrix (floats) that takes the latency-form GEMV
   int n_cus = 256;
+  std::string ipc_dir;              // L2_TP_IPC_DIR: ranks are processes that meet through files (test hook)
   std::vector<hipEvent_t> probe;    // in-situ probe: event pairs around every launch of the dominant kernel
   size_t probe_used = 0;
   bool probe_on = false;
@@ -442,6 +444,10 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     c->loop = grp;
     grp->p2p_base[rank] = c->p2p_base; grp->p2p_logits[rank] = c->logits;
     c->p2p = c->p2p_base != nullptr;          // peers resolved at the first step, once every rank has registered
+  } else if (G > 1 && getenv("L2_TP_IPC_DIR")) {
+    c->ipc_dir = getenv("L2_TP_IPC_DIR");
+    const int rc = p2p_connect_ipc(c);
+    if (rc) { l2_destroy(c); return rc; }
   } else if (c->tp_path) {
     int rc = rccl_bind();
     if (rc) { l2_destroy(c); return rc; }
@@ -1097,21 +1103,71 @@ __global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n, in
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { partial[i] = (double)((rank + 1) * (k + 1)) + 0.5 * (double)i; x[i] = 0.0f; }
 }
+// Test hook (L2_TP_IPC_DIR=<directory>): the ranks are separate PROCESSES that meet through files instead of an RCCL
+// communicator, so the IPC mapping, the self-test and the peer-to-peer exchange run between processes on a box with one GPU
+// (RCCL refuses two ranks on one device).  No fallback in this mode: the exchange works or creation fails.
+static bool file_exchange(const char* dir, const char* tag, int rank, int G, const void* mine, void* all, size_t bytes) {
+  char path[512];
+  snprintf(path, sizeof(path), "%s/%s.%d.tmp", dir, tag, rank);
+  FILE* f = fopen(path, "wb");
+  if (!f) return false;
+  const bool wrote = fwrite(mine, 1, bytes, f) == bytes;
+  fclose(f);
+  char final_path[512];
+  snprintf(final_path, sizeof(final_path), "%s/%s.%d", dir, tag, rank);
+  if (!wrote || rename(path, final_path) != 0) return false;
+  for (int r = 0; r < G; ++r) {
+    snprintf(path, sizeof(path), "%s/%s.%d", dir, tag, r);
+    bool got = false;
+    for (int tries = 0; tries < 6000 && !got; ++tries) {            // 60 s
+      f = fopen(path, "rb");
+      if (f) { got = fread((char*)all + (size_t)r * bytes, 1, bytes, f) == bytes; fclose(f); }
+      if (!got) usleep(10000);
+    }
+    if (!got) return false;
+  }
+  return true;
+}
+
 static int p2p_connect_ipc(l2_ctx* c) {
-  if (!c->p2p_base) return L2_OK;
+  if (!c->p2p_base) return c->ipc_dir.empty() ? L2_OK : fail(L2_E_COMM, "L2_TP_IPC_DIR: no peer-to-peer inbox was allocated");
   const int G = c->G;
+  const char* dir = c->ipc_dir.empty() ? nullptr : c->ipc_dir.c_str();
+  int round = 0;
+  auto all_min = [&](int v, int* out) -> int {                      // every rank learns the minimum of v
+    if (dir) {
+      std::vector<int> vs(G, 0);
+      char tag[32]; snprintf(tag, sizeof(tag), "min%d", round++);
+      if (!file_exchange(dir, tag, c->rank, G, &v, vs.data(), sizeof(int))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive");
+      *out = *std::min_element(vs.begin(), vs.end());
+      return L2_OK;
+    }
+    int* d_v = nullptr;
+    HIPCHK(hipMalloc(&d_v, sizeof(int)));
+    HIPCHK(hipMemcpy(d_v, &v, 4, hipMemcpyHostToDevice));
+    NCCLCHK(g_rccl.AllReduce(d_v, d_v, 1, NCCL_INT32, NCCL_MIN, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d_v, 4, hipMemcpyDeviceToHost));
+    hipFree(d_v);
+    return L2_OK;
+  };
   struct Rec { hipIpcMemHandle_t base, logits; };
   static_assert(sizeof(Rec) == 128, "two 64-byte IPC handles");
   Rec mine;
   bool ok = hipIpcGetMemHandle(&mine.base, c->p2p_base) == hipSuccess && hipIpcGetMemHandle(&mine.logits, c->logits) == hipSuccess;
   (void)hipGetLastError();
-  Rec* d_all = nullptr;
   std::vector<Rec> all(G);
-  HIPCHK(hipMalloc(&d_all, sizeof(Rec) * (G + 1)));
-  HIPCHK(hipMemcpy(d_all + G, &mine, sizeof(Rec), hipMemcpyHostToDevice));
-  NCCLCHK(g_rccl.AllGather(d_all + G, d_all, sizeof(Rec), NCCL_UINT8, c->comm, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpy(all.data(), d_all, sizeof(Rec) * G, hipMemcpyDeviceToHost));
+  if (dir) {
+    if (!file_exchange(dir, "handles", c->rank, G, &mine, all.data(), sizeof(Rec))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive");
+  } else {
+    Rec* d_all = nullptr;
+    HIPCHK(hipMalloc(&d_all, sizeof(Rec) * (G + 1)));
+    HIPCHK(hipMemcpy(d_all + G, &mine, sizeof(Rec), hipMemcpyHostToDevice));
+    NCCLCHK(g_rccl.AllGather(d_all + G, d_all, sizeof(Rec), NCCL_UINT8, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(all.data(), d_all, sizeof(Rec) * G, hipMemcpyDeviceToHost));
+    hipFree(d_all);
+  }
   for (int r = 0; r < G && ok; ++r) {
     if (r == c->rank) { p2p_set_peer(c, r, c->p2p_base, c->logits); continue; }
     void *pb = nullptr, *pl = nullptr;
@@ -1121,12 +1177,8 @@ static int p2p_connect_ipc(l2_ctx* c) {
     p2p_set_peer(c, r, pb, (float*)pl);
   }
   // every rank learns whether every rank mapped everything BEFORE anybody waits on a peer
-  int* d_ok = (int*)d_all;
   int h_ok = ok ? 1 : 0;
-  HIPCHK(hipMemcpy(d_ok, &h_ok, 4, hipMemcpyHostToDevice));
-  NCCLCHK(g_rccl.AllReduce(d_ok, d_ok, 1, NCCL_INT32, NCCL_MIN, c->comm, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpy(&h_ok, d_ok, 4, hipMemcpyDeviceToHost));
+  { const int rc_ = all_min(h_ok, &h_ok); if (rc_) return rc_; }
   if (h_ok) {   // four exchanges (each inbox slot is reused once) on known vectors: sum over ranks of ((rank + 1)(k + 1) + i / 2)
     const int n = c->d;
     std::vector<float> got(n);
@@ -1140,14 +1192,11 @@ static int p2p_connect_ipc(l2_ctx* c) {
     }
     *c->p2p_err = 0;
     HIPCHK(hipMemset(c->xb2, 0, (size_t)n * 4));
-    HIPCHK(hipMemcpy(d_ok, &h_ok, 4, hipMemcpyHostToDevice));
-    NCCLCHK(g_rccl.AllReduce(d_ok, d_ok, 1, NCCL_INT32, NCCL_MIN, c->comm, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(&h_ok, d_ok, 4, hipMemcpyDeviceToHost));
+    { const int rc_ = all_min(h_ok, &h_ok); if (rc_) return rc_; }
   }
-  hipFree(d_all);
   c->p2p = h_ok != 0;
   c->p2p_peers_ready = true;
+  if (!c->p2p && dir) return fail(L2_E_COMM, "L2_TP_IPC_DIR: the peer-to-peer exchange between the processes failed its self-test");
   if (!c->p2p && getenv("L2_TP_ALLREDUCE") && !strcmp(getenv("L2_TP_ALLREDUCE"), "p2p"))
     return fail(L2_E_COMM, "L2_TP_ALLREDUCE=p2p but the peer-to-peer exchange could not be set up on every rank");
   return L2_OK;
@@ -1305,7 +1354,7 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
 static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
 
 static int ensure_ready(l2_ctx* c) {
-  if (c->tp_path && !c->comm && !c->loop) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
+  if (c->tp_path && !c->comm && !c->loop && !(c->p2p && !c->ipc_dir.empty())) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
   if (c->loop && c->p2p && !c->p2p_peers_ready) {
     if (!c->loop->wait()) return fail(L2_E_COMM, "loopback group: a rank never arrived");
     for (int r = 0; r < c->G; ++r) {

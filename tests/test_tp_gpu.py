@@ -182,6 +182,54 @@ def test_tensor_parallel_group_samples_like_a_single_rank():
         assert out[r][0].tolist() == want.tolist() and out[r][1] == want_rng
 
 
+def test_two_process_group_on_one_gpu_through_ipc(tmp_path):
+    """What one GPU can say about the multi-GPU path: the ranks as separate PROCESSES (started fresh), meeting through files
+    (L2_TP_IPC_DIR -- RCCL refuses two ranks on one device), each mapping the other's uncached inboxes with
+    hipIpcOpenMemHandle, the start-up self-test, then the peer-to-peer all-reduce / gather inside one hipGraph per token
+    between the two processes: logits against the goldens of the TRUE reference on both ranks.  What stays untested is
+    the same mapping ACROSS GPUs (xGMI peer access) and RCCL with more than one rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from llama2_ts_amd import runtime
+rank = int(sys.argv[1])
+meta = json.load(open(os.path.join(%r, "tests", "golden", "llama2_7b_L2.json")))
+g = np.load(os.path.join(%r, "tests", "golden", "llama2_7b_L2.npz"))
+ctx = runtime.Context(meta["header"], device=0, tp_rank=rank, tp_size=2, nccl_id=b"x" * 128)
+print("rank", rank, "mode:", ctx.tp_mode(), flush=True)
+ctx.synth_fill(meta["seed"])
+keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+for pos, tok in enumerate(meta["tokens_fed"][:40]):
+    lg = ctx.forward(tok, pos)
+    assert runtime.argmax(lg) == meta["argmax"][pos], (rank, pos)
+    if pos in keep:
+        assert np.abs(lg - g["logits"][keep[pos]]).max() <= 1e-4, (rank, pos)
+assert ctx.decode_greedy(1, 0, 40).tolist() == meta["argmax"][:40]
+ctx.close()
+print("rank", rank, "ok", flush=True)
+''' % (root, root, root, root))
+    env = dict(os.environ, L2_TP_IPC_DIR=str(meet), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = []
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=600)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (pr, out) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and "rank %d ok" % r in out, out[-3000:]
+        assert "peer-to-peer" in out, out[-3000:]
+
+
 def test_two_gpu_group_over_rccl_and_xgmi(tmp_path):
     """The real thing, on a box with at least two GPUs (skipped on the 1-GPU development boxes): two PROCESSES, one
     per GPU, started fresh (nothing in this process's GPU state is inherited), rendezvous over gloo on 127.0.0.1,
