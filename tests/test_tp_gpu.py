@@ -182,11 +182,12 @@ def test_tensor_parallel_group_samples_like_a_single_rank():
         assert out[r][0].tolist() == want.tolist() and out[r][1] == want_rng
 
 
-def test_two_process_group_on_one_gpu_through_ipc(tmp_path):
-    """What one GPU can say about the multi-GPU path: the ranks as separate PROCESSES (started fresh), meeting through files
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_process_group_on_one_gpu_through_ipc(tmp_path, G):
+    """What one GPU can say about the multi-GPU path: the G ranks as separate PROCESSES (started fresh), meeting through files
     (L2_TP_IPC_DIR -- RCCL refuses two ranks on one device), each mapping the other's uncached inboxes with
     hipIpcOpenMemHandle, the start-up self-test, then the peer-to-peer all-reduce / gather inside one hipGraph per token
-    between the two processes: logits against the goldens of the TRUE reference on both ranks.  What stays untested is
+    between the processes: logits against the goldens of the TRUE reference on every rank.  What stays untested is
     the same mapping ACROSS GPUs (xGMI peer access) and RCCL with more than one rank."""
     import subprocess
     import sys
@@ -199,10 +200,10 @@ import json, os, sys
 import numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 from llama2_ts_amd import runtime
-rank = int(sys.argv[1])
+rank, G = int(sys.argv[1]), int(sys.argv[2])
 meta = json.load(open(os.path.join(%r, "tests", "golden", "llama2_7b_L2.json")))
 g = np.load(os.path.join(%r, "tests", "golden", "llama2_7b_L2.npz"))
-ctx = runtime.Context(meta["header"], device=0, tp_rank=rank, tp_size=2, nccl_id=b"x" * 128)
+ctx = runtime.Context(meta["header"], device=0, tp_rank=rank, tp_size=G, nccl_id=b"x" * 128)
 print("rank", rank, "mode:", ctx.tp_mode(), flush=True)
 ctx.synth_fill(meta["seed"])
 keep = {p: i for i, p in enumerate(meta["logit_positions"])}
@@ -216,7 +217,7 @@ ctx.close()
 print("rank", rank, "ok", flush=True)
 ''' % (root, root, root, root))
     env = dict(os.environ, L2_TP_IPC_DIR=str(meet), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(G)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(G)]
     outs = []
     for pr in procs:
         try:
