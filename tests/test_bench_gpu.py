@@ -42,3 +42,32 @@ def test_bench_two_ranks_replicas_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["parallelism"] == "replicas2"
     assert j["value"] > 0
+
+
+def _two_ranks(extra_env, tmp_path, port):
+    env = dict(os.environ, L2_BENCH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2",
+           "--config", "llama2_7b_L2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_tensor_parallel_flow_with_two_processes_on_one_gpu(tmp_path):
+    """The line `bench.py --gpus 2` prints for the 7B shape, with its two ranks as processes on the one GPU that meet
+    through files (L2_TP_IPC_DIR): strong scaling, the tensor-parallel step named, the peer-to-peer exchange used."""
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    j = _two_ranks({"L2_TP_IPC_DIR": str(meet)}, tmp_path, 29613)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["parallelism"] == "tp2" and j["value"] > 0
+    assert "peer-to-peer" in j["config"]["loop"] and "note" not in j
+
+
+def test_bench_falls_back_to_replicas_when_the_group_cannot_form(tmp_path):
+    """Two ranks on one device over RCCL: ncclCommInitRank refuses the duplicate GPU, every rank hears about it over gloo,
+    the job measures replicas and says why."""
+    j = _two_ranks({}, tmp_path, 29615)
+    assert j["config"]["parallelism"] == "replicas2" and j["scaling"] == "weak" and "could not be created" in j["note"]
