@@ -269,19 +269,38 @@ def main():
     if tp:
         # the tensor-parallel group has never run on more than one GPU (no multi-GPU box in development): if any rank cannot
         # join it, every rank says so over gloo and the job measures independent replicas instead of dying without a line
-        err = ""
-        try:
-            ctx = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=tp["id"])
-        except Exception as e:      # noqa: BLE001 -- whatever it is, the other ranks have to hear about it
-            err = "%s: %s" % (type(e).__name__, e)
+        import tempfile
         import torch
-        flag = torch.tensor([0 if err else 1], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            if ctx is not None:
-                ctx.close()
-            ctx, tp, shards = None, None, False
-            tp_note = "tensor-parallel group could not be created (%s); measured %d independent replicas instead" % (err or "another rank failed", world)
+
+        def join():
+            err = ""
+            c = None
+            try:
+                c = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=tp["id"])
+            except Exception as e:      # noqa: BLE001 -- whatever it is, the other ranks have to hear about it
+                err = "%s: %s" % (type(e).__name__, e)
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0 and c is not None:
+                c.close()
+                c = None
+            return c, (err or "another rank failed") if int(flag[0]) == 0 else ""
+
+        ctx, err = join()                       # 1: RCCL communicator (+ the peer-to-peer exchange if its self-test passes)
+        if ctx is None and "L2_TP_IPC_DIR" not in os.environ:
+            # 2: no RCCL at all -- the ranks meet through files and exchange over IPC-mapped inboxes only
+            meet = [tempfile.mkdtemp(prefix="l2_meet_") if rank == 0 else None]
+            dist.broadcast_object_list(meet, 0)
+            os.environ["L2_TP_IPC_DIR"] = meet[0]
+            ctx, err2 = join()
+            if ctx is None:
+                del os.environ["L2_TP_IPC_DIR"]
+                err = "%s; without RCCL: %s" % (err, err2)
+            else:
+                tp_note = "the RCCL communicator could not be created (%s); the ranks met through files and exchange peer to peer" % err
+        if ctx is None:
+            tp, shards = None, False
+            tp_note = "tensor-parallel group could not be created (%s); measured %d independent replicas instead" % (err, world)
     if ctx is None:
         ctx = runtime.Context(hdr, device=device)
     ctx.synth_fill(args.seed)

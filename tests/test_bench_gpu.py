@@ -66,8 +66,14 @@ def test_bench_tensor_parallel_flow_with_two_processes_on_one_gpu(tmp_path):
     assert "peer-to-peer" in j["config"]["loop"] and "note" not in j
 
 
-def test_bench_falls_back_to_replicas_when_the_group_cannot_form(tmp_path):
+def test_bench_second_chance_without_rccl(tmp_path):
     """Two ranks on one device over RCCL: ncclCommInitRank refuses the duplicate GPU, every rank hears about it over gloo,
-    the job measures replicas and says why."""
+    and the job tries again with the ranks meeting through files (no RCCL): tensor parallel after all, with a note."""
     j = _two_ranks({}, tmp_path, 29615)
+    assert j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong" and "RCCL communicator could not be created" in j["note"]
+
+
+def test_bench_falls_back_to_replicas_when_the_group_cannot_form(tmp_path):
+    """No way to form the group (the meeting directory does not exist): the job measures replicas and says why."""
+    j = _two_ranks({"L2_TP_IPC_DIR": str(tmp_path / "missing" / "dir")}, tmp_path, 29617)
     assert j["config"]["parallelism"] == "replicas2" and j["scaling"] == "weak" and "could not be created" in j["note"]
