@@ -10,7 +10,7 @@
 // function "parity of M at its start -> integer increment", and two such functions compose:
 //     Comp {q0, d}: the increment is q0 for even M, q0 + d for odd M, d in {-1, 0, +1}.
 // Which grid an element sits on is predicted from an APPROXIMATE prefix sum A (any parallel summation order): the
-// exact S differs from A by < 2^-36 relative, so whenever [A_{i-1}, A_i] lies inside one binade with a 2^-32 margin the
+// exact S differs from A by < 2^-34 relative (n <= 2^18 roundings of 2^-53), so whenever [A_{i-1}, A_i] lies inside one binade with a 2^-32 margin the
 // exponent of S_{i-1} is known and the add cannot leave the binade ("regular" element; classify()'s `mb` widens the margin
 // for a cruder A).  Every other element --
 // a power of two crossed, reached or nearly reached, the first non-zero value -- is "serial": it ends a run, and one
