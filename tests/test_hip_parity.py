@@ -444,6 +444,28 @@ def test_device_sampler_other_vocabularies(hdr, why):
         ctx.close(); ref.close()
 
 
+def test_device_sampler_long_runs_against_oracle():
+    """Hundreds of sampled tokens per setting (plain and top-p, several temperatures) against the oracle's sampler fed with the
+    device's own logits: every token's running sums go through the tiled runs / chain / search with whatever ties, binade
+    crossings and nucleus sizes those distributions produce; one flipped index anywhere changes every later token."""
+    hdr = configs.header("stories15M")
+    for temperature, topp, seed, n in [(1.0, 0.95, 2024, 200), (0.7, 1.0, 7, 200), (1.5, 0.6, 99, 120), (0.05, 0.9, 5, 60)]:
+        ctx = runtime.Context(hdr)
+        ctx.synth_fill(2)
+        toks, rng_after = ctx.decode_sample(1, 0, n, temperature, topp, seed)
+        ref = runtime.Context(hdr)
+        ref.synth_fill(2)
+        rng = O.Rng(seed)
+        tok, want = 1, []
+        for pos in range(n):
+            lg = np.array(ref.forward(tok, pos), copy=True)
+            tok, _ = O.next_token(lg, temperature, topp, rng)
+            want.append(tok)
+        assert toks.tolist() == want, (temperature, topp, seed, int(np.argmax(np.array(toks.tolist()) != np.array(want))))
+        assert rng_after == rng.state.value
+        ctx.close(); ref.close()
+
+
 def test_device_sampler_temperature_zero_is_greedy():
     ctx = runtime.Context(configs.header("tiny"))
     ctx.synth_fill(1)
