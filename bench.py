@@ -65,9 +65,30 @@ def pmc_child(name, seed):
     ctx.close()
 
 
+PROFILER_ENV = ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARY")
+
+
+def under_profiler():
+    """This process was itself started by rocprofv3 (its tool library is preloaded): it must not start profiled children."""
+    if any(os.environ.get(k) for k in PROFILER_ENV):
+        return True
+    return "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def clean_child_env(**extra):
+    """Environment for a child process: nothing of a profiler that may wrap THIS process leaks into it."""
+    env = {k: v for k, v in os.environ.items() if k not in PROFILER_ENV and not k.startswith("ROCPROF")}
+    if "rocprof" in env.get("LD_PRELOAD", ""):
+        del env["LD_PRELOAD"]
+    env.update(extra)
+    return env
+
+
 def pmc_traffic(name, seed):
     """FETCH_SIZE and WRITE_SIZE in SEPARATE passes (kernel trace only), corrected as the MI355X guide prescribes:
     both are in KiB and FETCH_SIZE reports exactly half of a 16-byte-per-lane coalesced stream on gfx950."""
+    if under_profiler():
+        return None, "skipped: this run is itself being profiled"
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
@@ -78,7 +99,7 @@ def pmc_traffic(name, seed):
             d = os.path.join(work, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", name, "--seed", str(seed)]
-            env = dict(os.environ, TMPDIR="/tmp", L2_USE_GRAPH="0")
+            env = clean_child_env(TMPDIR="/tmp", L2_USE_GRAPH="0")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -213,6 +234,35 @@ def secondary_config(name, seed, device, with_cpu, traffic):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: THIS process has not touched the GPU (nothing above imports torch or
+    calls HIP) and starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process,
+    one rank per GPU; it relays the child's one JSON line and its exit code.  (Never an exec: the parent stays a plain
+    supervisor.)"""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = clean_child_env(HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in r.stdout.decode("utf8", "replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)      # anything else a rank printed is not the result line
+    if line is not None:
+        print(line)
+    elif r.returncode == 0:
+        print("bench.py: %d ranks finished without a result line" % n, file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,9 +280,14 @@ def main():
         pmc_child(args.config, args.seed)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting the %d that run" % (args.gpus, world, world), file=sys.stderr)
     hdr = configs.header(args.config)
     K = min(args.steps, hdr[6])
     W = min(args.warmup, hdr[6])
@@ -354,6 +409,14 @@ def main():
         "hbm_frac_end_to_end": round(bpt * value / 1e9 / per_gpu_streams / HBM_PEAK_GBS / (world if shards else 1), 4),
     }
 
+    if dist is not None:
+        # what actually ran, rank by rank, so a reader of the line can see the group had N members: l2_tp_mode
+        # (0 single GPU, 1 RCCL eager, 3 peer-to-peer exchange in one hipGraph per token) and the device of every rank
+        mine = {"rank": rank, "device": device, "tp_mode": ctx.tp_mode_id()}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        out["tp"] = {"ranks": world, "sharded": bool(shards), "l2_tp_mode": sorted({r["tp_mode"] for r in ranks}),
+                     "devices": [r["device"] for r in ranks], "step": ctx.tp_mode()}
     if tp_note:
         out["note"] = tp_note
     if extras:

@@ -66,7 +66,8 @@ enum {
   L2_OPT_USE_GRAPH = 2,       /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
   L2_OPT_KEEP_STATE = 3       /* 1: the RunState fields that only transformer() itself reads (llama2.ts:131-146: att, k, v, hb2, xb2,
                                  the xb of the FFN half, the final-normed x) are also written out for l2_read_state (parity
-                                 tests); 0 (default): they stay on chip -- q, xb, hb, logits and the KV caches are always there */
+                                 tests); 0 (default): they stay on chip and reading them AFTER a forward returns L2_E_STATE -- q, hb, logits and
+                                 the KV caches are always there */
 };
 
 typedef struct l2_ctx l2_ctx;

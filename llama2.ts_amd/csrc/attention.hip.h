@@ -141,10 +141,13 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   STAMP(2);
 
   // ---- softmax (llama2.ts:181-194); a split keeps its own max / sum, rescaled at the merge.
-  // Every wave finds the maximum of all n scores itself (one LDS read per 64 rows): no barrier for it.
+  // Every wave finds the maximum of all n scores itself (one LDS read per 64 rows): no cross-wave reduction for it.
   float mx = -INFINITY;
   for (int t = lane; t < n; t += 64) mx = fmaxf(mx, sc[t]);
   mx = wave_max(mx);
+  // the exps below overwrite sc[] in place whenever a thread has more than one element or a split keeps them for its
+  // value round: no wave may store before EVERY wave has finished its maximum scan of the scores (workgroup-uniform test)
+  if (n > NTH || NS != 1) __syncthreads();
   double lsum = 0.0;
   float e_own = 0.0f;                                           // n <= NTH (the usual case): the thread's one element stays in a register
   for (int t = tid; t < n; t += NTH) {

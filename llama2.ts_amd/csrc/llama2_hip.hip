@@ -147,6 +147,7 @@ struct P2PArgs {
   unsigned* ticket;            // blocks finished in this launch
   int* err;
   int G, rank, n;              // n: elements of this exchange (d, or V_loc)
+  unsigned long long wait_ticks;   // bound of a flag wait, in 100 MHz ticks
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -178,6 +179,9 @@ struct l2_ctx {
   P2PPeers p2p_peers = {};
   std::vector<void*> p2p_opened;     // IPC mappings to close
   bool p2p_peers_ready = false;
+  unsigned long long p2p_wait_ticks = 3000000000ull;   // L2_TP_WAIT_S (default 30 s) on the 100 MHz clock
+  bool p2p_synced = false;           // the ranks have met once (host side) right before the first exchange of a step
+  bool broken = false;               // a peer-to-peer wait gave up: this rank's epochs no longer match its peers'
 
   float* w[L2_T_COUNT] = {};
   size_t layer_elems[L2_T_COUNT] = {};  // LOCAL floats per layer (or whole tensor when unlayered)
@@ -361,6 +365,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->tune_rot = env_int("L2_TUNE_ROT", 5);
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !env_int("L2_TP_FORCE_COMM", 0)) ? 1 : 0);
   c->profile_sync = env_int("L2_PROFILE_SYNC", 0);
+  { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -989,9 +994,17 @@ __device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e,
   if (tid < a.G) {
     const unsigned long long* mine = a.pr.flags[a.rank] + ((size_t)(par * P2P_MAXG + tid) * P2P_FB + b);
     unsigned spins = 0;
+    unsigned long long t0 = 0;
     while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) { *a.err = 1; break; }          // a few seconds: give up, the host reports it
+      __builtin_amdgcn_s_sleep(2);
+      // bounded by WALL time on the constant 100 MHz clock (a.wait_ticks, default 30 s, L2_TP_WAIT_S): ordinary rank skew
+      // -- a peer still capturing its graph, a slower checkpoint read -- must not trip it; a rank that died must.
+      // The host then marks the context broken (check_p2p): epochs and flags no longer match the peers'.
+      if ((++spins & 255u) == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (!t0) t0 = now;
+        else if (now - t0 > a.wait_ticks) { *a.err = 1; break; }
+      }
     }
   }
   __syncthreads();
@@ -1074,7 +1087,7 @@ static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits) {
 static P2PArgs p2p_args(const l2_ctx* c, int n) {
   P2PArgs a;
   a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = (unsigned*)(c->p2p_epoch + 1); a.err = c->p2p_err_dev;
-  a.G = c->G; a.rank = c->rank; a.n = n;
+  a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks;
   return a;
 }
 static int p2p_grid(int n) { const int b = (n + 255) / 256; return b > P2P_FB ? P2P_FB : (b < 1 ? 1 : b); }
@@ -1353,7 +1366,10 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
 
 static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
 
+static int p2p_first_sync(l2_ctx* c);
+
 static int ensure_ready(l2_ctx* c) {
+  if (c->broken) return fail(L2_E_COMM, "tensor-parallel context is unusable: an earlier peer-to-peer exchange timed out");
   if (c->tp_path && !c->comm && !c->loop && !(c->p2p && !c->ipc_dir.empty())) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
   if (c->loop && c->p2p && !c->p2p_peers_ready) {
     if (!c->loop->wait()) return fail(L2_E_COMM, "loopback group: a rank never arrived");
@@ -1368,11 +1384,35 @@ static int ensure_ready(l2_ctx* c) {
     for (size_t l = 0; l < c->uploaded[k].size(); ++l)
       if (!c->uploaded[k][l]) return fail(L2_E_STATE, "tensor kind %d layer %zu was never uploaded", k, l);
   }
+  if (c->p2p && !c->p2p_synced) { const int rc_ = p2p_first_sync(c); if (rc_) return rc_; }
+  return L2_OK;
+}
+
+// The ranks meet once on the HOST right before their first peer-to-peer step: whatever happened between creation and now
+// (per-rank checkpoint I/O, synthetic fill) is skew the in-kernel flag wait should not have to absorb.
+static int p2p_first_sync(l2_ctx* c) {
+  if (c->loop) { if (!c->loop->wait()) return fail(L2_E_COMM, "loopback group: a rank never arrived"); }
+  else if (!c->ipc_dir.empty()) {
+    int mine = 1; std::vector<int> all(c->G, 0);
+    if (!file_exchange(c->ipc_dir.c_str(), "first", c->rank, c->G, &mine, all.data(), sizeof(int))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive for the first step");
+  } else if (c->comm) {
+    int* d_v = nullptr;
+    HIPCHK(hipMalloc(&d_v, sizeof(int)));
+    HIPCHK(hipMemsetAsync(d_v, 0, sizeof(int), c->stream));
+    NCCLCHK(g_rccl.AllReduce(d_v, d_v, 1, NCCL_INT32, NCCL_SUM, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(d_v);
+  }
+  c->p2p_synced = true;
   return L2_OK;
 }
 
 static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer wait give up?
-  if (c->p2p_err && *c->p2p_err) { *c->p2p_err = 0; return fail(L2_E_COMM, "peer-to-peer exchange: a rank never raised its flag (bounded wait gave up)"); }
+  if (c->p2p_err && *c->p2p_err) {
+    *c->p2p_err = 0;
+    c->broken = true;   // the device-side epoch / flag state is out of step with the peers for good: fail fast from now on
+    return fail(L2_E_COMM, "peer-to-peer exchange: a rank never raised its flag (wait of %.0f s gave up); the context is unusable", (double)c->p2p_wait_ticks / 1e8);
+  }
   return L2_OK;
 }
 
@@ -1571,6 +1611,7 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   HIPCHK(hipSetDevice(c->device));
   c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->amax, 0, 8 * 16 * 8, c->stream));   // argmax keys: zero at the start of every run (an aborted sampled step may have left some)
   if (c->opt_graph) {   // capture what this run needs before the timed region
     for (int s = 0; s < steps; ++s) {
       const int lvl = split_level(c, pos0 + s);
@@ -1614,7 +1655,9 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   }
   const double params[2] = {temperature, topp};
   c->samp_mode = (topp <= 0 || topp >= 1) ? 0 : 1;        // llama2.ts:486: plain sample unless 0 < topp < 1
-  c->samp_amax = !c->tp_path && temperature > 0 && c->amax;   // the classifier's argmax keys give the softmax its maximum
+  // the classifier's argmax keys give the softmax its maximum; the serial A/B form takes its own and would leave them stale
+  c->samp_amax = !c->tp_path && temperature > 0 && c->amax && !c->samp.serial;
+  HIPCHK(hipMemsetAsync(c->amax, 0, 8 * 16 * 8, c->stream));   // "zero between tokens" holds whatever an earlier (aborted) run left
   c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->samp.params, params, sizeof(params), hipMemcpyHostToDevice, c->stream));
@@ -1700,7 +1743,11 @@ extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t
   const float* src = nullptr;
   size_t n = 0;
   const size_t slab = (size_t)c->S * c->kvd_loc;
-  if (!c->opt_keep_state && ((which == L2_S_X && c->ran_forward) || which == L2_S_XB2 || which == L2_S_HB2 || which == L2_S_K || which == L2_S_V || which == L2_S_ATT))
+  // xb after transformer() holds the w2 result in the reference (llama2.ts:292); on chip it is the attention output
+  // unless the state is kept (and never on a tensor-parallel rank, whose w2 emits fp64 partials)
+  if (which == L2_S_XB && c->ran_forward && c->tp_path)
+    return fail(L2_E_STATE, "RunState.xb (the w2 result, llama2.ts:292) is not materialised on a tensor-parallel rank");
+  if (!c->opt_keep_state && (((which == L2_S_X || which == L2_S_XB) && c->ran_forward) || which == L2_S_XB2 || which == L2_S_HB2 || which == L2_S_K || which == L2_S_V || which == L2_S_ATT))
     return fail(L2_E_STATE, "this RunState field is only read by transformer() itself and stays on chip: set L2_OPT_KEEP_STATE before the forward");
   switch (which) {
     case L2_S_X: src = c->ran_forward ? c->xn : c->x; n = c->d; break;   // after a forward: the final-normed x (kept state)

@@ -142,6 +142,8 @@ class Context:
         hdr = (C.c_int32 * 7)(*self.cfg.header)
         h = C.c_void_p()
         self.flags = flags
+        if flags and tp_size > 1:
+            raise ValueError("l2_create_ex flags (F_GQA / F_GENERATE_ROPE) cannot be combined with tp_size > 1: use l2_load_checkpoint for sharded version-1 files")
         if flags:
             _check(lib().l2_create_ex(hdr, device, int(flags), C.byref(h)))
         elif tp_size > 1:
@@ -260,6 +262,9 @@ class Context:
         us, n = C.c_float(), C.c_int()
         _check(lib().l2_bench_dominant_in_situ(self._h, first_token, pos0, steps, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def tp_mode_id(self):
+        return int(lib().l2_tp_mode(self._h))
 
     def tp_mode(self):
         """How the tensor-parallel step runs (l2_tp_mode): none / RCCL eager / RCCL in a graph / peer-to-peer in a graph."""

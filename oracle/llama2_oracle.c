@@ -151,6 +151,21 @@ void orc_synth_freq(const orc_config* c, float* real, float* imag) {
   }
 }
 
+/* SURVEY.md 8(f4), beyond the reference: RoPE tables as newer llama2.c exports imply them (such files carry none; the
+ * reference reads them from the file, llama2.ts:125-126).  llama2.c's run.c evaluates, per position and per pair, in fp32:
+ * freq = 1 / powf(10000, head_dim / head_size) with head_dim = 2j, val = pos * freq, (cosf(val), sinf(val)).
+ * Used to WRITE such tables into a v0 file the reference can run (oracle/make_goldens.py, the gqa_rope fixtures). */
+void orc_rope_runc(const orc_config* c, float* real, float* imag) {
+  const int hs2 = c->head_size / 2;
+  for (int t = 0; t < c->seq_len; ++t)
+    for (int j = 0; j < hs2; ++j) {
+      const float freq = 1.0f / powf(10000.0f, (float)(2 * j) / (float)c->head_size);
+      const float val = (float)t * freq;
+      real[(size_t)t * hs2 + j] = cosf(val);
+      imag[(size_t)t * hs2 + j] = sinf(val);
+    }
+}
+
 void orc_synth_tensor(const orc_config* c, uint32_t seed, int kind, int layer, float* out) {
   const uint64_t total = orc_tensor_count(c, kind);
   if (total == 0) return;

@@ -76,6 +76,7 @@ uint64_t orc_checkpoint_floats(const orc_config* c);                  /* total f
 void orc_synth_fill(float* out, uint64_t g0, uint64_t n, uint32_t seed, float scale, float bias);
 void orc_synth_params(const orc_config* c, int kind, float* scale, float* bias); /* per-tensor law */
 void orc_synth_freq(const orc_config* c, float* real, float* imag);             /* (S, hs/2) tables */
+void orc_rope_runc(const orc_config* c, float* real, float* imag);              /* (S, hs/2) tables by llama2.c's run.c formula (8(f4)) */
 /* Fill one tensor (layer >= 0: that layer's slice; -1: whole tensor) exactly as the file has it. */
 void orc_synth_tensor(const orc_config* c, uint32_t seed, int kind, int layer, float* out);
 /* Write a whole llama2.c-v0 checkpoint. Returns 0 or -1. */

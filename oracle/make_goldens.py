@@ -53,6 +53,11 @@ PLAN = {
     "cli_prompt": (40, [], False, "wetds oyn fra uynia", ["-t", "0", "-s", "1"], True),
     "cli_temp": (40, [], False, None, ["-t", "0.9", "-s", "42"], True),
     "cli_topp": (24, [], False, "once", ["-t", "1.0", "-p", "0.9", "-s", "7"], True),
+    # the multi-head expansion of a grouped-query model is a checkpoint the reference CAN run (it reads wk / wv as
+    # (d, d), llama2.ts:117-118); its outputs pin the L2_F_GQA path.  "_rope": freq_cis_* hold the tables llama2.c's run.c would
+    # compute (what L2_F_GENERATE_ROPE generates, llama2.ts:125-126 reads them from the file) -- pins version-1 checkpoints.
+    "wide_gqa_mha": (320, [0, 1, 2, 23, 143, 144, 145, 159, 160, 319], False, None),
+    "tiny_gqa_rope_mha": (64, "all", False, None),
 }
 
 DUMP_STMT = (
@@ -92,6 +97,16 @@ fs.writeFileSync(process.argv[3],
     return inst
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -102,11 +117,24 @@ def run_one(inst, name):
     extra = plan[4] if len(plan) > 4 else ["-t", "0", "-s", "1"]
     synth_tok = plan[5] if len(plan) > 5 else False
     shape = "stories15M" if name.startswith("cli_") else name.replace("_prompt", "")
-    hdr = configs.header(shape)
-    seed = configs.DEFAULT_SEED
-    ckpt = os.path.join(WORK, shape + ".bin")
-    if not os.path.exists(ckpt):
-        subprocess.run([CLI, "synth", *map(str, hdr), str(seed), ckpt], check=True)
+    gqa_hdr = None
+    if name.endswith("_mha"):      # grouped-query model, expanded to the multi-head checkpoint the reference can read
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import gqa_cases
+        shape = name[:-4]
+        base = shape.replace("_rope", "")
+        gqa_hdr = gqa_cases.GQA_SHAPES[base]
+        seed = gqa_cases.GQA_SEEDS[base]
+        d, h, L, H, KVH, V, S = gqa_hdr
+        hdr = (d, h, L, H, H, V, S)
+        ckpt = os.path.join(WORK, name + ".bin")
+        gqa_cases.expanded_mha_file(gqa_hdr, seed, ckpt, runc_rope="_rope" in shape)
+    else:
+        hdr = configs.header(shape)
+        seed = configs.DEFAULT_SEED
+        ckpt = os.path.join(WORK, shape + ".bin")
+        if not os.path.exists(ckpt):
+            subprocess.run([CLI, "synth", *map(str, hdr), str(seed), ckpt], check=True)
     assert os.path.getsize(ckpt) == configs.checkpoint_bytes(hdr)
     dump = os.path.join(WORK, name + ".dump")
     for f in os.listdir(WORK):
@@ -125,7 +153,10 @@ def run_one(inst, name):
     cmd = ["node", inst, ckpt, *extra, "-n", str(steps)]
     if prompt is not None:
         cmd += ["-i", prompt]
+    import time
+    t_run = time.perf_counter()
     r = subprocess.run(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    t_run = time.perf_counter() - t_run
     V = abs(hdr[5])
     logits = np.fromfile(dump + ".logits", dtype="<f4").reshape(-1, V)
     tokens = np.fromfile(dump + ".tokens", dtype="<i4")
@@ -142,6 +173,16 @@ def run_one(inst, name):
         "stdout_tail": r.stdout.decode("utf8", "replace")[-80:],
         "tokenizer": "synthetic (tests/synth_tokenizer.py)" if synth_tok else "reference tokenizer.bin",
     }
+    if gqa_hdr is not None:
+        meta["gqa_header"] = list(gqa_hdr)
+        meta["what"] = ("the reference ran the MULTI-HEAD expansion of the grouped-query model (gqa_header, seed): wk / wv rows of each cache "
+                        "head repeated for its query heads" + ("; freq_cis_* = llama2.c run.c's per-position tables" if "_rope" in shape else ""))
+    # the reference's own throughput figure (llama2.ts:507-511 prints "achieved tok/s" to stderr), with where it was measured
+    tail = r.stderr.decode("utf8", "replace")
+    import re
+    m = re.search(r"achieved tok/s:\s*([0-9.eE+-]+)", tail + r.stdout.decode("utf8", "replace"))
+    meta["reference_run"] = {"tok_s_printed": float(m.group(1)) if m else None, "wall_s": round(t_run, 3), "steps": int(n),
+                             "threads": 1, "cpu": cpu_model(), "node": meta["node"], "includes_dump_overhead": True}
     if synth_tok:
         meta["stdout"] = r.stdout.decode("utf8")
     arrays = {}

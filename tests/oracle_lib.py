@@ -188,6 +188,19 @@ def set_gqa(on):
     lib().orc_set_gqa(int(bool(on)))
 
 
+def rope_runc(hdr):
+    """(freq_cis_real, freq_cis_imag) as llama2.c's run.c computes them per position (fp32 powf / cosf / sinf), each (S * hs/2)."""
+    L = lib()
+    cfg = OrcConfig()
+    h = _hdr(hdr)
+    L.orc_read_config(h.ctypes.data, C.byref(cfg))
+    n = cfg.seq_len * (cfg.head_size // 2)
+    re, im = np.empty(n, dtype=np.float32), np.empty(n, dtype=np.float32)
+    L.orc_rope_runc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_rope_runc(C.byref(cfg), re.ctypes.data, im.ctypes.data)
+    return re, im
+
+
 def synth_write(hdr, seed, path):
     h = _hdr(hdr)
     if lib().orc_synth_write(h.ctypes.data, seed, path.encode()) != 0:

@@ -77,3 +77,30 @@ def test_bench_falls_back_to_replicas_when_the_group_cannot_form(tmp_path):
     """No way to form the group (the meeting directory does not exist): the job measures replicas and says why."""
     j = _two_ranks({"L2_TP_IPC_DIR": str(tmp_path / "missing" / "dir")}, tmp_path, 29617)
     assert j["config"]["parallelism"] == "replicas2" and j["scaling"] == "weak" and "could not be created" in j["note"]
+
+
+def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
+    """What the driver runs is plain `python bench.py --gpus N ...` -- no launcher around it.  The script, which has not
+    touched the GPU, starts N ranks as a child `torch.distributed.run`, relays the one JSON line and the exit code.  Here
+    N = 2 on the one GPU (L2_BENCH_FORCE_DEVICE=0), so the ranks end up meeting through files; the line must say 2 GPUs,
+    tp2, name the tensor-parallel step (l2_tp_mode of every rank) and carry the note (llama2.ts:270, 292 are the reduce points)."""
+    env = dict(os.environ, L2_BENCH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "llama2_7b_L2", "--steps", "16",
+                        "--warmup", "2", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong" and j["value"] > 0
+    assert "note" in j and "RCCL communicator could not be created" in j["note"]
+    assert j["tp"]["ranks"] == 2 and j["tp"]["sharded"] and j["tp"]["l2_tp_mode"] == [3] and j["tp"]["devices"] == [0, 0]
+
+
+def test_bench_gpus_one_stays_in_process():
+    """--gpus 1 never spawns: same line as no flag at all (checked on the cheap shape)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "stories15M", "--steps", "16", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-pmc", "--no-extra"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["config"]["parallelism"] == "single" and "tp" not in j

@@ -1,13 +1,18 @@
-"""grouped-query checkpoints and checkpoints without RoPE tables -- PARITY UNPINNED BY THE REFERENCE.
+"""grouped-query checkpoints and checkpoints without RoPE tables.
 
 llama2.ts parses n_kv_heads and ignores it (llama2.ts:86, 117-118) and reads freq_cis from the file (:125-126): it cannot
-run such checkpoints, so there is no reference output to record.  What pins the behaviour instead:
+run such checkpoints directly.  It CAN run the multi-head expansion of a grouped-query model (wk / wv rows of each cache head
+repeated for its query heads) and a v0 file whose freq_cis_* hold the tables a version-1 export implies -- oracle/make_goldens.py
+recorded both runs (tests/golden/wide_gqa_mha, tiny_gqa_rope_mha); the first group of tests below compares the oracle (bit for
+bit) and the HIP path (<= 1e-4, argmax exact) with those reference outputs.  The older, transitive checks remain:
   * the oracle's grouped-query switch (oracle/llama2_oracle.c: orc_set_gqa) changes NOTHING when n_kv_heads == n_heads,
     and a grouped-query model equals -- bit for bit -- the multi-head model whose wk / wv rows repeat each cache head
     for its group of query heads; that multi-head model runs on the restatement that IS pinned to the reference;
   * the HIP path (l2_create_ex with L2_F_GQA) is then compared with that oracle, with the same expanded multi-head
     model on the ordinary HIP path, and through the version-1 checkpoint loader.
 """
+import hashlib
+import json
 import os
 import struct
 
@@ -16,41 +21,92 @@ import pytest
 
 import oracle_lib as O
 
-GQA_SHAPES = {
-    "tiny_gqa": (64, 176, 2, 4, 2, 512, 64),          # head_size 16, two query heads per cache head
-    "wide_gqa": (256, 704, 2, 4, 1, -512, 320),        # head_size 64 (multi-query), unshared classifier, 320 positions
-}
+from gqa_cases import GQA_SEEDS, GQA_SHAPES, expanded_mha_file, gqa_tensors, write_v0, write_v1
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def expanded_mha_file(hdr, seed, path):
-    """v0 checkpoint of the multi-head model equivalent to the grouped-query model (hdr, seed): same tensors, with the
-    rows of every cache head of wk / wv repeated for each query head of its group."""
-    d, h, L, H, KVH, V, S = hdr
-    hs, mul = d // H, H // KVH
+def load_gold(name):
+    return json.load(open(os.path.join(GOLD, name + ".json"))), np.load(os.path.join(GOLD, name + ".npz"))
+
+
+# ---- the reference-held pin: the TRUE reference ran the multi-head expansion (oracle/make_goldens.py, *_mha fixtures) ----------
+
+@pytest.mark.parametrize("name", ["wide_gqa_mha", "tiny_gqa_rope_mha"])
+def test_oracle_gqa_is_bit_identical_to_the_reference_run_of_the_expanded_model(name, tmp_path):
+    """The grouped-query restatement (orc_set_gqa) on the GROUPED-QUERY tensors reproduces, bit for bit and step by step, what
+    the real reference computed on the expanded multi-head file (llama2.ts:117-118 reads wk / wv as (d, d)); for `_rope` the
+    file's freq_cis_* are llama2.c run.c's tables (llama2.ts:125-126 reads whatever the file holds)."""
+    meta, g = load_gold(name)
+    hdr = tuple(meta["gqa_header"])
+    p = str(tmp_path / "gqa.bin")
+    write_v0(p, hdr, gqa_tensors(hdr, meta["seed"], runc_rope="_rope" in name))
     O.set_gqa(1)
     try:
-        g = O.Oracle(hdr, seed)
-        tensors = {}
-        for kind in range(14):
-            if kind == 13 and V > 0:
-                continue
-            tensors[kind] = np.array(g.weights(kind), copy=True)
-        g.close()
+        orc = O.Oracle(hdr, path=p)
+        for pos, tok in enumerate(meta["tokens_fed"]):
+            lg = orc.forward(tok, pos)
+            assert hashlib.sha256(lg.tobytes()).hexdigest() == meta["logits_sha256"][pos], (name, pos)
+        orc.close()
     finally:
         O.set_gqa(0)
-    for kind in (3, 4):
-        w = tensors[kind].reshape(L, KVH, hs, d)
-        tensors[kind] = np.repeat(w, mul, axis=1).reshape(-1)
-    with open(path, "wb") as f:
-        f.write(struct.pack("<7i", d, h, L, H, H, V, S))
-        for kind in range(14):
-            if kind in tensors:
-                f.write(tensors[kind].astype("<f4").tobytes())
-    return tensors
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"L2_ATTN_SPLITS": "4"}, {"L2_SMALL_MAX": "0"}])
+def test_hip_gqa_matches_the_reference_run_of_the_expanded_model(env, monkeypatch):
+    """L2_F_GQA on the grouped-query tensors vs the TRUE reference's logits / argmax for the expanded model: every step of the
+    320-position context (both attention split levels), logits <= 1e-4 at the kept positions, then the device greedy loop."""
+    from llama2_ts_amd import runtime
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    meta, g = load_gold("wide_gqa_mha")
+    hdr = tuple(meta["gqa_header"])
+    t = gqa_tensors(hdr, meta["seed"])
+    ctx = runtime.Context(hdr, flags=runtime.F_GQA)
+    for kind, layers, count in runtime.tensor_shapes(ctx.cfg, gqa=True):
+        per = t[kind].size // max(layers, 1)
+        assert per == count
+        for layer in range(max(layers, 1)):
+            ctx.upload(kind, layer if layers else -1, t[kind][layer * per:(layer + 1) * per])
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    worst = 0.0
+    for pos, tok in enumerate(meta["tokens_fed"]):
+        got = ctx.forward(tok, pos)
+        assert runtime.argmax(got) == meta["argmax"][pos], pos
+        if pos in keep:
+            worst = max(worst, float(np.abs(got - g["logits"][keep[pos]]).max()))
+    assert worst <= 1e-4, worst
+    assert ctx.decode_greedy(1, 0, len(meta["argmax"])).tolist() == meta["argmax"]
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_version_1_checkpoint_matches_the_reference_run_with_run_c_tables(tmp_path):
+    """A version-1 export (no freq_cis, grouped wk / wv) through l2_load_checkpoint (L2_F_GQA | L2_F_GENERATE_ROPE) vs the TRUE
+    reference on the expanded v0 file whose freq_cis_* hold run.c's tables: every logit of all 64 positions <= 1e-4, argmax
+    identical; the generated tables themselves equal the file's (same libm formula) within 1 ulp."""
+    from llama2_ts_amd import runtime
+    meta, g = load_gold("tiny_gqa_rope_mha")
+    hdr = tuple(meta["gqa_header"])
+    t = gqa_tensors(hdr, meta["seed"], runc_rope=True)
+    p = str(tmp_path / "v1.bin")
+    write_v1(p, hdr, t)
+    cfg, state, weights, nbytes = runtime.load_checkpoint_native(p)
+    assert nbytes == os.path.getsize(p) and cfg.header == hdr
+    ctx = weights.ctx
+    S, hs2 = hdr[6], (hdr[0] // hdr[3]) // 2
+    assert np.abs(ctx.read_tensor(runtime.T_FREQ_REAL, 0, 0, S * hs2) - t[11]).max() <= 1.2e-7
+    assert np.abs(ctx.read_tensor(runtime.T_FREQ_IMAG, 0, 0, S * hs2) - t[12]).max() <= 1.2e-7
+    for pos, tok in enumerate(meta["tokens_fed"]):
+        got = ctx.forward(tok, pos)
+        assert runtime.argmax(got) == meta["argmax"][pos], pos
+        assert np.abs(got - g["logits"][pos]).max() <= 1e-4, pos
+    ctx.close()
 
 
 @pytest.mark.parametrize("name", sorted(GQA_SHAPES))

@@ -347,6 +347,48 @@ def test_prefill_equals_token_by_token(built, name, n):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("pf_lds", ["0", "1"])
+@pytest.mark.parametrize("name,n", [("stories110M", 128), ("stories110M", 256), ("llama2_7b_L2", 64), ("llama2_7b_L2", 128), ("llama2_7b_L2", 256)])
+def test_prefill_at_the_widths_the_bench_times(built, name, n, pf_lds, monkeypatch):
+    """Prompt ingestion where bench.py reports `prefill_tok_s` (d = 4096 / h = 11008, and the 110M width): the first n
+    tokens the TRUE reference fed itself (llama2.ts:471-473 teacher-forces a prompt one transformer() call per token) go
+    through l2_prefill in one call; the logits of position n - 1 must be the reference's own (kept positions 63 / 127 /
+    255, <= 1e-4), the KV cache must equal the token-by-token path's, and the greedy continuation must follow the
+    reference's tokens through the next kept position.  Both weight-load forms of the GEMMs (L2_PF_LDS 0 / 1)."""
+    monkeypatch.setenv("L2_PF_LDS", pf_lds)
+    meta, g = load_gold(name)
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    assert n - 1 in keep, "fixture keeps no logits at %d" % (n - 1)
+    toks = meta["tokens_fed"][:n]
+    b = runtime.Context(meta["header"]); b.synth_fill(meta["seed"])
+    lb = np.array(b.prefill(toks, 0), copy=True)
+    err = float(np.abs(lb - g["logits"][keep[n - 1]]).max())
+    assert err <= TOL, (name, n, err)
+    assert runtime.argmax(lb) == meta["argmax"][n - 1]
+    a = runtime.Context(meta["header"]); a.synth_fill(meta["seed"])
+    for pos, t in enumerate(toks):
+        a.forward(t, pos)
+    d, S, L = b.cfg.dim, b.cfg.seq_len, b.cfg.n_layers
+    for nm in ("key_cache", "value_cache"):
+        ca = a.read_state(nm).reshape(L, S, d)[:, :n]
+        cb = b.read_state(nm).reshape(L, S, d)[:, :n]
+        assert np.abs(ca - cb).max() <= 1e-6, nm
+    a.close()
+    nxt = min(p for p in keep if p >= n)                      # the next kept position: n itself (128 -> 128, 256 -> 256) or 64 -> 64
+    tok = runtime.argmax(lb)
+    for pos in range(n, nxt + 1):
+        assert tok == meta["tokens_fed"][pos], (name, pos)
+        lg = b.forward(tok, pos)
+        tok = runtime.argmax(lg)
+        assert tok == meta["argmax"][pos]
+    assert np.abs(lg - g["logits"][keep[nxt]]).max() <= TOL
+    # and on from there with the device loop: token-exact for 32 more positions
+    cont = b.decode_greedy(tok, nxt + 1, 32)
+    assert cont.tolist() == meta["argmax"][nxt + 1:nxt + 33]
+    print("\n[prefill %s n=%d L2_PF_LDS=%s] max|dlogit| vs reference %.3g" % (name, n, pf_lds, err))
+    b.close()
+
+
 def test_prefill_prompt_golden_and_errors(built):
     meta, g = load_gold("stories15M_prompt")          # -i "Once upon a time": BOS + 4 prompt ids are teacher-forced
     ctx = runtime.Context(meta["header"]); ctx.synth_fill(meta["seed"])
