@@ -69,10 +69,10 @@ DUMP_STMT = (
 )
 
 
-def build_reference():
+def strip_types(src, out):
+    """Type-strip a TypeScript file with the sucrase bundle the reference ships inside its own t348.mjs (lines 898-9042):
+    line-preserving, so llama2.ts:468 is still line 468 of the output, and Node 12 can run it."""
     os.makedirs(WORK, exist_ok=True)
-    for f in ("tokenizer.bin",):
-        shutil.copy(os.path.join(REF, f), WORK)
     with open(os.path.join(REF, "t348.mjs")) as f:
         lines = f.readlines()
     assert lines[897].startswith("const transform=(()=>{"), lines[897][:40]
@@ -85,8 +85,15 @@ fs.writeFileSync(process.argv[3],
 """
     with open(os.path.join(WORK, "strip.cjs"), "w") as f:
         f.write(strip)
+    subprocess.run(["node", os.path.join(WORK, "strip.cjs"), src, out], check=True)
+
+
+def build_reference():
+    os.makedirs(WORK, exist_ok=True)
+    for f in ("tokenizer.bin",):
+        shutil.copy(os.path.join(REF, f), WORK)
     out = os.path.join(WORK, "llama2.stripped.mjs")
-    subprocess.run(["node", os.path.join(WORK, "strip.cjs"), os.path.join(REF, "llama2.ts"), out], check=True)
+    strip_types(os.path.join(REF, "llama2.ts"), out)
     with open(out) as f:
         js = f.readlines()
     assert "transformer(token, pos, config, state, weights);" in js[467], js[467]
@@ -206,7 +213,42 @@ def run_one(inst, name):
           os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024)
 
 
+# config -> steps for the clean timing runs of the reference (no dump statement): the figure the reference prints itself
+SPEED_PLAN = {"stories15M": 256, "stories110M": 48, "llama2_7b_L2": 8, "llama2_7b": 4}
+
+
+def time_reference(names):
+    """the reference's OWN CPU figure -- the unmodified (type-stripped) llama2.ts timed in the build container,
+    one JS thread, the tok/s it prints itself (llama2.ts:507-511: timer starts after the first token).  Stored in
+    tests/golden/reference_speed.json; bench.py quotes it next to the C port's number as cpu_baseline.reference_js_tok_s."""
+    import re
+    import time
+    build_reference()
+    plain = os.path.join(WORK, "llama2.stripped.mjs")
+    path = os.path.join(GOLD, "reference_speed.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    node = subprocess.run(["node", "--version"], stdout=subprocess.PIPE).stdout.decode().strip()
+    for name in names:
+        hdr = configs.header(name)
+        ckpt = os.path.join(WORK, name + ".bin")
+        if not os.path.exists(ckpt):
+            subprocess.run([CLI, "synth", *map(str, hdr), str(configs.DEFAULT_SEED), ckpt], check=True)
+        steps = SPEED_PLAN[name]
+        t0 = time.perf_counter()
+        r = subprocess.run(["node", plain, ckpt, "-t", "0", "-s", "1", "-n", str(steps)], cwd=WORK, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        wall = time.perf_counter() - t0
+        m = re.search(r"achieved tok/s:\s*([0-9.eE+-]+)", r.stdout.decode("utf8", "replace"))
+        out[name] = {"tok_s": float(m.group(1)), "steps": steps, "wall_s_incl_load": round(wall, 2), "threads": 1, "cpu": cpu_model(), "node": node,
+                     "argv": "-t 0 -s 1 -n %d" % steps, "what": "unmodified reference llama2.ts (types stripped by its bundled sucrase), figure printed by llama2.ts:511"}
+        print(name, out[name])
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--speed":
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+        return time_reference(sys.argv[2:] or ["stories15M", "stories110M", "llama2_7b_L2"])
     names = sys.argv[1:] or list(PLAN)
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
     os.makedirs(GOLD, exist_ok=True)
