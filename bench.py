@@ -176,7 +176,34 @@ def cpu_baseline(name, hdr, seed):
         sec = sec_total / steps
         sample = "oracle, %d greedy tokens from BOS on the full %s shape" % (steps, name)
         o.close(); o2.close()
-    return {"value": round(1.0 / sec, 4), "unit": "tokens/s", "cores": 1, "kind": "port", "sample": sample, "extrapolated": extrapolated}
+    out = {"value": round(1.0 / sec, 4), "unit": "tokens/s", "cores": 1, "kind": "port", "sample": sample, "extrapolated": extrapolated,
+           "host_cpu": host_cpu_model()}
+    out.update(reference_js_figure(name))
+    return out
+
+
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def reference_js_figure(name):
+    """The reference ITSELF (unmodified llama2.ts under Node, one JS thread) cannot run on the GPU box -- its source does not travel.
+    oracle/make_goldens.py --speed timed it in the build container on this same synthetic checkpoint and stored the tok/s it prints
+    (llama2.ts:511) in tests/golden/reference_speed.json; quoted here next to the C port's figure, with where it was measured."""
+    try:
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_speed.json"))).get(name)
+    except (OSError, ValueError):
+        ref = None
+    if not ref:
+        return {"reference_js_tok_s": None}
+    return {"reference_js_tok_s": round(ref["tok_s"], 4),
+            "reference_js_measured": "build container (not this box): %s, node %s, %d thread, %s, %d steps" % (ref["cpu"], ref["node"], ref["threads"], ref["argv"], ref["steps"])}
 
 
 # ---- one config on one GPU: decode loop + roofline + CPU baseline ------------------------------------------------
@@ -225,6 +252,7 @@ def secondary_config(name, seed, device, with_cpu, traffic):
            "hbm_gbs_end_to_end": round(bpt * K / wall / 1e9, 2),
            "hbm_frac_end_to_end": round(bpt * K / wall / 1e9 / HBM_PEAK_GBS, 4),
            "roofline": roofline_block(ctx, cfg, K, traffic[0], traffic[1])}
+    out["per_kernel"] = per_kernel_block(ctx, cfg)      # back-to-back launches of each GEMV phase: us and GB/s of its matrix bytes
     S = hdr[6]
     ms = ctx.bench_decode(1, 0, S)
     out["whole_context_tok_s"] = round(S / (ms * 1e-3), 2)
