@@ -775,7 +775,8 @@ static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
   (void)dim;
   int U = (n4 <= 64) ? 1 : 2;                    // a short row is a single batch
   if (n4 > 128 && n4 <= 256) U = 4;
-  if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4) U = c->tune_U;
+  if (mode == MODE_CLS && n4 > 128 && n4 <= 192) U = 3;   // 768 columns (stories110M): three float4 per lane cover a row exactly; with U = 4 a quarter of the lanes re-read the last one (16.8 -> 16.5 us)
+  if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4 || (c->tune_U == 3 && mode == MODE_CLS)) U = c->tune_U;
   g.U = U;
   const int groups = (rows * pair + g.R - 1) / g.R;
   g.nwaves = groups >= 1024 ? 4 : (groups >= 512 ? 2 : 1);
@@ -899,7 +900,8 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
 #define L2_LAUNCH(UU, PP) do { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \
                                launch_probed(c, phase_kernel<MODE, 2, UU, PP>, grid, block, lds, st, a, MODE == MODE_W13); } while (0)
 #define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else if (g.pre == 4) L2_LAUNCH(UU, 4); else L2_LAUNCH(UU, 12); } while (0)
-  if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
+  if (g.U == 3) { if constexpr (MODE == MODE_CLS) { L2_LAUNCH_U(3); } }
+  else if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
 #undef L2_LAUNCH_U
 #undef L2_LAUNCH
   return hipGetLastError();

@@ -24,8 +24,10 @@ __global__ void fill(float* p, size_t n) { for (size_t i = (size_t)blockIdx.x * 
 
 enum { MAXWG = 512 };
 struct Flag { unsigned arrive; unsigned pad0[31]; unsigned done; unsigned pad1[31]; unsigned per_wg[MAXWG * 32]; };   // counters on their own 128-byte lines; per_wg[b * 32]: the consumer workgroup b's private copy of `done`
-__device__ int g_sleep = 1, g_private = 0;
+__device__ int g_sleep = 1, g_private = 0, g_fences = 1;   // g_fences 0: outputs stored write-through (sc1), x read with sc1 loads, no release / acquire fence
 
+__device__ __forceinline__ void st1(float* p, float v) { __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld1(const float* p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
@@ -43,8 +45,7 @@ __device__ __forceinline__ void wait_prev(const Flag* prev, const Flag* mine, in
         if (slp <= 1) __builtin_amdgcn_s_sleep(1); else if (slp <= 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
         if ((++spins & 255u) == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (!t0) t0 = now; else if (now - t0 > 20000000ull) { atomicAdd(err, 1); break; } }   // 0.2 s
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (g_fences) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     }
     __syncthreads();
   }
@@ -56,8 +57,7 @@ __device__ __forceinline__ void signal_done(Flag* mine) {
     __syncthreads();
     __shared__ unsigned s_last;
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (g_fences) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       const unsigned t = __hip_atomic_fetch_add(&mine->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = 0;
       if (t == gridDim.x - 1) {
@@ -107,7 +107,10 @@ __global__ void __launch_bounds__(256) phase(const f4* w, int rows, int n, const
   };
   auto finish = [&](int g) {
     const double s0 = wave_sum(d0), s1 = wave_sum(d1);
-    if (lane == 0) { if (PAIR) xout[g] = (float)(s0 * 0.5 + s1 * 0.25); else { xout[2 * g] = (float)s0; xout[2 * g + 1] = (float)s1; } }
+    if (lane == 0) {
+      if (g_fences) { if (PAIR) xout[g] = (float)(s0 * 0.5 + s1 * 0.25); else { xout[2 * g] = (float)s0; xout[2 * g + 1] = (float)s1; } }
+      else { if (PAIR) st1(xout + g, (float)(s0 * 0.5 + s1 * 0.25)); else { st1(xout + 2 * g, (float)s0); st1(xout + 2 * g + 1, (float)s1); } }
+    }
     d0 = 0.0; d1 = 0.0;
   };
   const int g0 = blockIdx.x * 4 + wave;
@@ -116,7 +119,8 @@ __global__ void __launch_bounds__(256) phase(const f4* w, int rows, int n, const
 #pragma unroll
   for (int b = 0; b < PRE; ++b) load(P[b], have ? g0 : groups - 1, b);
   wait_prev(prev, mine, err, lead);
-  for (int i = threadIdx.x; i < NB * 64 * U; i += 256) xs[i] = i < n4 ? reinterpret_cast<const f4*>(xin)[i] : f4{0.f, 0.f, 0.f, 0.f};
+  if (g_fences) { for (int i = threadIdx.x; i < NB * 64 * U; i += 256) xs[i] = i < n4 ? reinterpret_cast<const f4*>(xin)[i] : f4{0.f, 0.f, 0.f, 0.f}; }
+  else { for (int i = threadIdx.x; i < NB * 64 * U * 4; i += 256) reinterpret_cast<float*>(xs)[i] = i < n ? ld1(xin + i) : 0.f; }
   __syncthreads();
   if (have) {
     // first group: the preloaded batches, each replaced by a later batch of the stream as it is consumed
@@ -160,14 +164,14 @@ __global__ void __launch_bounds__(256) attn_like(const float* cache, const float
 #pragma unroll
   for (int j = 0; j < 8; ++j) kv[j] = rows[j * 256 + t];           // 64 rows x 128 floats = 2048 float4
   wait_prev(prev, mine, err, lead);
-  if (t < 128) qs[t] = q[h * 128 + t];
+  if (t < 128) qs[t] = g_fences ? q[h * 128 + t] : ld1(q + h * 128 + t);
   __syncthreads();
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { const int c = ((j * 256 + t) & 31) * 4; s += kv[j].x * qs[c] + kv[j].y * qs[c + 1] + kv[j].z * qs[c + 2] + kv[j].w * qs[c + 3]; }
   red[t] = s;
   __syncthreads();
-  if (t < 128) out[h * 128 + t] = red[t] + red[t + 128] * 0.5f;
+  if (t < 128) { if (g_fences) out[h * 128 + t] = red[t] + red[t + 128] * 0.5f; else st1(out + h * 128 + t, red[t] + red[t + 128] * 0.5f); }
   signal_done(mine);
 }
 
@@ -188,22 +192,24 @@ int main(int argc, char** argv) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&phase<22, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&phase<22, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   printf("us per Llama-2-7B-shaped layer (qkv, attention stand-in, wo, w1/w3, w2), %d layers, best of 5\n", LAYERS);
-  const int variants[][3] = {{0, 1, 0}, {1, 1, 0}, {2, 1, 0}, {1, 8, 0}, {1, 32, 0}, {1, 1, 1}, {1, 8, 1}, {2, 8, 1}, {1, 32, 1}};   // {mode, sleep, private flags}
+  const int variants[][4] = {{0, 8, 0, 1}, {1, 8, 0, 1}, {1, 8, 0, 0}, {2, 8, 0, 0}, {1, 8, 1, 0}, {3, 8, 0, 1}, {3, 8, 0, 0}};   // {mode, sleep, private flags, fences}; mode 3: ONE stream, but with the completion signal / wait protocol
   for (auto& var : variants) {
     const int mode = var[0];
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sleep), &var[1], 4); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_private), &var[2], 4);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sleep), &var[1], 4); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_private), &var[2], 4); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fences), &var[3], 4);
+    (void)hipMemset(x, 0, d * 4); hipLaunchKernelGGL(fill, dim3(64), dim3(256), 0, 0, x, (size_t)d); (void)hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
       (void)hipMemset(flags, 0, sizeof(Flag) * 5);
       (void)hipDeviceSynchronize();
       (void)hipEventRecord(e0, sa);
-      if (mode) { (void)hipEventRecord(ej, sa); (void)hipStreamWaitEvent(sb, ej, 0); }
+      const bool two = mode == 1 || mode == 2;
+      if (two) { (void)hipEventRecord(ej, sa); (void)hipStreamWaitEvent(sb, ej, 0); }
       int k = 0;      // launch index: even -> stream a, odd -> stream b (modes 1, 2)
       for (int l = 0; l < LAYERS; ++l) {
         const float* wl = w + per_layer * (size_t)(l % LAYERS_MEM);
         const f4* wqkv = (const f4*)wl; const f4* wo = (const f4*)(wl + (size_t)3 * d * d); const f4* w13 = (const f4*)(wl + (size_t)4 * d * d);
         const f4* w2 = (const f4*)(wl + (size_t)4 * d * d + (size_t)2 * hd * d);
-        auto st = [&]() { hipStream_t s = (mode && (k & 1)) ? sb : sa; ++k; return s; };
+        auto st = [&]() { hipStream_t s = (two && (k & 1)) ? sb : sa; ++k; return s; };
         Flag* F = mode ? flags : nullptr;
         auto fl = [&](int i) -> Flag* { return F ? F + i : nullptr; };
 #define PH(NB, PAIR, grid, lds, W, rows, n, xin, xout, prev, mine, lead) do { hipStream_t s_ = st(); \
@@ -215,14 +221,14 @@ int main(int argc, char** argv) {
         PH(8, true, 459, lds4096, w13, 2 * hd, d, x, hb, fl(2), fl(3), 1);
         PH(22, false, 512, lds11008, w2, d, hd, hb, x, fl(3), fl(4), 1);
       }
-      if (mode) { (void)hipEventRecord(ej, sb); (void)hipStreamWaitEvent(sa, ej, 0); }
+      if (two) { (void)hipEventRecord(ej, sb); (void)hipStreamWaitEvent(sa, ej, 0); }
       (void)hipEventRecord(e1, sa); (void)hipEventSynchronize(e1);
       float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
     int herr = 0; (void)hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost);
-    float hx[4]; (void)hipMemcpy(hx, x, 16, hipMemcpyDeviceToHost);
-    printf("mode %d sleep %2d private %d  %s  %8.2f us per layer   (%.3f ms per 32 layers; bounded waits that gave up: %d; x[0..1] = %g %g)\n", mode, var[1], var[2],
-           mode == 0 ? "one stream, plain launches          " : mode == 1 ? "two streams, hand-off, 2 batches pre" : "two streams, hand-off, 6 batches pre", best * 1e3 / LAYERS, best, herr, hx[0], hx[1]);
+    float hx[4]; (void)hipMemcpy(hx, x + 100, 16, hipMemcpyDeviceToHost);
+    printf("mode %d sleep %2d private %d fences %d  %s  %8.2f us per layer   (%.3f ms per 32 layers; bounded waits that gave up: %d; x[0..1] = %g %g)\n", mode, var[1], var[2], var[3],
+           mode == 0 ? "one stream, plain launches          " : mode == 1 ? "two streams, hand-off, 2 batches pre" : mode == 2 ? "two streams, hand-off, 6 batches pre" : "ONE stream + the hand-off protocol   ", best * 1e3 / LAYERS, best, herr, hx[0], hx[1]);
   }
   return 0;
 }
