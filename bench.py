@@ -480,13 +480,13 @@ def main():
                 ctx.decode_sample(1, 0, n_s, t, p, 42)
                 samp[nm] = round(n_s / (time.perf_counter() - t0), 3)
             out["sampled_decode_tok_s"] = samp
-            # prompt ingestion (l2_prefill: chunks of up to 64 tokens on the fp64 MFMA path) next to the token-by-token loop it replaces
-            n_p = min(128, S)
-            ptoks = (np.arange(n_p, dtype=np.int32) * 7919 + 2) % cfg.vocab_size
-            ctx.prefill(ptoks[:64], 0)
-            t0 = time.perf_counter()
-            ctx.prefill(ptoks, 0)
-            out["prefill_tok_s"] = round(n_p / (time.perf_counter() - t0), 1)
+            # prompt ingestion (l2_prefill: 64-token chunks on the fp64 MFMA path, up to four chunks per launch) next to the token-by-token loop it replaces
+            for key, n_p in (("prefill_tok_s", min(128, S)), ("prefill_256_tok_s", min(256, S))):
+                ptoks = (np.arange(n_p, dtype=np.int32) * 7919 + 2) % cfg.vocab_size
+                ctx.prefill(ptoks, 0)
+                t0 = time.perf_counter()
+                ctx.prefill(ptoks, 0)
+                out[key] = round(n_p / (time.perf_counter() - t0), 1)
     ctx.close()
 
     if extras and not args.no_cpu_baseline:

@@ -195,6 +195,8 @@ struct l2_ctx {
   unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
   unsigned long long* amax = nullptr;   // greedy loop: 8 argmax keys, one per 128-byte line, zero between tokens
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
+  int pf3 = 1;                      // L2_PF3: 1 (default) register-blocked prefill GEMMs where the shape allows, 0: the 16-row-tile kernels everywhere (A/B, tests)
+  int pf_nw[4] = {4, 4, 4, 4};      // L2_PF_NW_QKV / _WO / _W13 / _W2: waves per 16-row tile in the older prefill GEMMs (4 or 8)
   int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int cur_splits = 1;               // split count of the step being enqueued / captured
   int split_rows = 144;             // L2_ATTN_SPLIT_ROWS: cached rows of a head beyond which attention runs 8 workgroups per head
@@ -411,6 +413,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->small_max = env_int("L2_SMALL_MAX", 8 << 20);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->pf_lds = env_int("L2_PF_LDS", 1);
+  c->pf3 = env_int("L2_PF3", 1);
+  c->pf_nw[0] = env_int("L2_PF_NW_QKV", 4); c->pf_nw[1] = env_int("L2_PF_NW_WO", 4); c->pf_nw[2] = env_int("L2_PF_NW_W13", 4); c->pf_nw[3] = env_int("L2_PF_NW_W2", 4);
   if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;
   {
     const size_t rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;
@@ -1489,8 +1493,32 @@ static bool can_prefill(const l2_ctx* c) {
 
 // One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1, 2 or 4).  QKV / WO / W2 take their weights through an LDS
 // tile by default (L2_PF_LDS: 0 never, 1 default, 2 W13 too -- its two tiles per wave measured slower).
+// register-blocked form (prefill.hip.h: pf_gemm3_kernel): RT row tiles per wave, 4 waves split K, `chunks` 64-token chunks per launch
+template <int MODE, int RT>
+static void launch_pf3(const PfArgs& a, int chunks, hipStream_t st) {
+  constexpr int NW = 4;
+  const size_t lds = (size_t)4 * NW * 4 * 64 * 8;
+  hipLaunchKernelGGL((pf_gemm3_kernel<MODE, NW, RT, 4>), dim3(a.rows / (16 * RT), chunks), dim3(64 * NW), lds, st, a);
+}
+
+// Shapes the register-blocked GEMMs cover: whole 64-column batches (n % 64) of both input widths and qkv's 3 d / 16 row tiles in threes.
+static bool pf3_ok(const l2_ctx* c) { return c->pf3 && c->d % 64 == 0 && c->h % 64 == 0 && (3 * c->d / 16) % 3 == 0; }
+
 template <int MODE>
-static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, hipStream_t st) {
+static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int chunks, hipStream_t st) {
+  if (pf3_ok(c) && tt == 4) {
+    // row tiles per wave: conversions per MFMA are 16 (R + 64) / (64 R) for R rows per workgroup, so as many as still leave >= 256
+    // workgroups: qkv 3 (3 d / 16 tiles), w1 / w3 one pair (688 pairs at 7B), wo / w2 (d / 16 tiles) 1, 2 or 4 with the chunk count
+    if constexpr (MODE == MODE_QKV) { launch_pf3<MODE, 3>(a, chunks, st); return; }
+    else if constexpr (MODE == MODE_W13) { launch_pf3<MODE, 1>(a, chunks, st); return; }
+    else {
+      const int tiles = a.rows / 16;
+      if (chunks == 4 && tiles % 4 == 0) launch_pf3<MODE, 4>(a, chunks, st);
+      else if (chunks == 2 && tiles % 2 == 0) launch_pf3<MODE, 2>(a, chunks, st);
+      else launch_pf3<MODE, 1>(a, chunks, st);
+      return;
+    }
+  }
   const dim3 grid(a.rows / 16);
   // four token tiles: the LDS form's 8-block register sets (32 activation fragments) leave one spilled wave per SIMD: 3200 vs 3490 tok/s
   if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && (tt < 4 || c->pf_lds >= 3)) {
@@ -1516,17 +1544,20 @@ static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, hip
 #undef L2_PFG
 }
 
+// One launch sequence for up to PF_S chunks of PF_T prompt positions (n tokens at pos0 ...): every GEMM sees all of them.
 static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
   hipStream_t st = c->stream;
   const size_t d = c->d, h = c->h;
+  constexpr size_t ROWS = (size_t)PF_S * PF_T;
   if (!c->pf_x) {
-    HIPCHK(hipMalloc(&c->pf_x, PF_T * d * 4)); HIPCHK(hipMalloc(&c->pf_xn, PF_T * (d > h ? d : h) * 4));
-    HIPCHK(hipMalloc(&c->pf_q, PF_T * d * 4)); HIPCHK(hipMalloc(&c->pf_xb, PF_T * d * 4)); HIPCHK(hipMalloc(&c->pf_hb, PF_T * h * 4));
-    HIPCHK(hipMalloc(&c->pf_tok, PF_T * sizeof(int)));
-    HIPCHK(hipMemset(c->pf_xb, 0, PF_T * d * 4)); HIPCHK(hipMemset(c->pf_q, 0, PF_T * d * 4));
+    HIPCHK(hipMalloc(&c->pf_x, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_xn, ROWS * (d > h ? d : h) * 4));
+    HIPCHK(hipMalloc(&c->pf_q, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_xb, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_hb, ROWS * h * 4));
+    HIPCHK(hipMalloc(&c->pf_tok, ROWS * sizeof(int)));
+    HIPCHK(hipMemset(c->pf_xb, 0, ROWS * d * 4)); HIPCHK(hipMemset(c->pf_q, 0, ROWS * d * 4));
   }
-  const int tt = (n > 32) ? 4 : (n > 16) ? 2 : 1, nt = 16 * tt;        // 16-token MFMA tiles in this chunk
-  int32_t tk[PF_T] = {0};
+  const int chunks = (n + PF_T - 1) / PF_T;                              // > 1 only on the register-blocked path (l2_prefill)
+  const int tt = (n > 32) ? 4 : (n > 16) ? 2 : 1, nt = (chunks > 1) ? chunks * PF_T : 16 * tt;   // token rows the kernels see (whole 16-token MFMA tiles)
+  int32_t tk[ROWS] = {0};
   for (int i = 0; i < n; ++i) tk[i] = tokens[i];
   HIPCHK(hipMemcpyAsync(c->pf_tok, tk, sizeof(tk), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));   // tk is on the stack
@@ -1543,7 +1574,7 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
     a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
     a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
-    launch_pf_gemm<MODE_QKV>(c, a, env_int("L2_PF_NW_QKV", 4), tt, st);
+    launch_pf_gemm<MODE_QKV>(c, a, c->pf_nw[0], tt, chunks, st);
     LCHK(hipGetLastError());
     // attention, one workgroup per (head, query) (llama2.ts:244-267)
     {
@@ -1555,15 +1586,15 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     }
     // wo + residual (llama2.ts:270-273)
     a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
-    launch_pf_gemm<MODE_WO>(c, a, env_int("L2_PF_NW_WO", 4), tt, st);
+    launch_pf_gemm<MODE_WO>(c, a, c->pf_nw[1], tt, chunks, st);
     // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
     hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
     a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
     a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
-    launch_pf_gemm<MODE_W13>(c, a, env_int("L2_PF_NW_W13", 4), tt, st);
+    launch_pf_gemm<MODE_W13>(c, a, c->pf_nw[2], tt, chunks, st);
     // w2 + residual (llama2.ts:292-295)
     a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
-    launch_pf_gemm<MODE_W2>(c, a, env_int("L2_PF_NW_W2", 4), tt, st);
+    launch_pf_gemm<MODE_W2>(c, a, c->pf_nw[3], tt, chunks, st);
     LCHK(hipGetLastError());
   }
   return L2_OK;
@@ -1580,15 +1611,16 @@ extern "C" int l2_prefill(l2_ctx* c, const int32_t* tokens, int n_tokens, int po
     return L2_OK;
   }
   HIPCHK(hipSetDevice(c->device));
+  const int step = pf3_ok(c) ? PF_S * PF_T : PF_T;      // positions per launch sequence: several 64-token chunks where the register-blocked GEMMs apply
   int done = 0;
   while (done < n_tokens) {
-    const int n = (n_tokens - done < PF_T) ? n_tokens - done : PF_T;
+    const int n = (n_tokens - done < step) ? n_tokens - done : step;
     rc = prefill_chunk(c, tokens + done, n, pos0 + done);
     if (rc) return rc;
     done += n;
   }
   // logits of the last position only (llama2.ts:299-302): the decode classifier on the last row of the chunk
-  const int last = (n_tokens - 1) % PF_T;
+  const int last = (n_tokens - 1) % step;
   c->h_tokpos[0] = tokens[n_tokens - 1]; c->h_tokpos[1] = pos0 + n_tokens - 1; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   PhaseArgs a = cls_args(c, true);

@@ -22,7 +22,7 @@ namespace l2k {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-enum { PF_T = 64 };   // tokens per chunk: one, two or four MFMA tiles of 16
+enum { PF_T = 64, PF_S = 4 };   // tokens per chunk: one, two or four MFMA tiles of 16; chunks per launch of the register-blocked GEMMs (blockIdx.y)
 
 struct PfArgs {
   const float* w0;     // QKV: wq  W13: w1  else the matrix
@@ -306,6 +306,196 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
   if (!acc.template combine<NW>(reinterpret_cast<double*>(lds), wave, lane)) return;
 #pragma unroll
   for (int t = 0; t < TT; ++t) pf_emit<MODE>(a, acc.a[t][0], acc.c[t][0], m, i0 + j, j, kq, 16 * t);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Register-blocked form.  On gfx950 v_mfma_f64_16x16x4_f64 IS the fp64 vector pipe (fp64 matrix peak = fp64 vector peak, 64
+// cycles per instruction and SIMD), so nothing a wave issues on the vector ALU overlaps it: every v_cvt_f64_f32 and every
+// address instruction adds to the 64 cycles of each MFMA, and the operand-shaped activation fragments (16 rows x 64 B per load
+// instruction, re-read from L2 by every wave) compete for the CU's 64 B / clock vector-memory path.  Per workgroup output block
+// of R rows x T tokens the conversions per MFMA are 16 (R + T) / (R T) -- 1.25 for the 16 x 64 block of pf_gemm_kernel, 0.58 for
+// 48 x 64 -- and the fragment bytes per MFMA fall the same way.  Here a wave holds RT row tiles x TT token tiles (RT (x 2 for
+// w1 / w3) x TT accumulators in AGPRs), takes all operands through buffer loads whose per-block / per-tile offsets are SCALAR
+// (no vector address arithmetic, no exec masks: every wave runs whole batches), and the NW waves of a workgroup split K; their
+// partial tiles are added in wave order through LDS, one weight stream at a time (64 KB at NW = 8), by NW waves in parallel.
+// Requires n % 64 == 0 and (rows / 16) % RT == 0; other shapes take pf_gemm_kernel.
+// One k-step of a wave's NS x 4 output tiles as ONE asm statement: acc[s][t] += x[t] (A operand, 16 tokens) * w[s] (B operand, 16 rows).
+// The accumulators are pinned in AGPRs ("+a"): left to hipcc, the loop-carried tiles live in VGPRs and are copied to AGPRs and
+// back around every iteration (64 - 96 v_accvgpr_write per 128 - 192 MFMAs -- on the very pipe the MFMAs need).  What hipcc does
+// not do for an asm statement (MI355X guide 5.7) is done by hand: `s_nop 1` in front covers the two wait states between a VALU
+// write of an operand (the conversions, the zero-fill of the tiles) and the MFMA that reads it; consecutive MFMAs of a statement
+// touch different tiles, and a tile is next written NS x 4 MFMAs later.
+#define L2_MF "v_mfma_f64_16x16x4_f64 "
+__device__ __forceinline__ void mfma_group(d4 (&c)[1][4], double x0, double x1, double x2, double x3, const double (&w)[1]) {
+  asm volatile("s_nop 1\n\t" L2_MF "%0, %4, %8, %0\n\t" L2_MF "%1, %5, %8, %1\n\t" L2_MF "%2, %6, %8, %2\n\t" L2_MF "%3, %7, %8, %3"
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]));
+}
+__device__ __forceinline__ void mfma_group(d4 (&c)[2][4], double x0, double x1, double x2, double x3, const double (&w)[2]) {
+  asm volatile("s_nop 1\n\t" L2_MF "%0, %8, %12, %0\n\t" L2_MF "%1, %9, %12, %1\n\t" L2_MF "%2, %10, %12, %2\n\t" L2_MF "%3, %11, %12, %3\n\t"
+               L2_MF "%4, %8, %13, %4\n\t" L2_MF "%5, %9, %13, %5\n\t" L2_MF "%6, %10, %13, %6\n\t" L2_MF "%7, %11, %13, %7"
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]), "+a"(c[1][0]), "+a"(c[1][1]), "+a"(c[1][2]), "+a"(c[1][3])
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]), "v"(w[1]));
+}
+__device__ __forceinline__ void mfma_group(d4 (&c)[3][4], double x0, double x1, double x2, double x3, const double (&w)[3]) {
+  asm volatile("s_nop 1\n\t" L2_MF "%0, %12, %16, %0\n\t" L2_MF "%1, %13, %16, %1\n\t" L2_MF "%2, %14, %16, %2\n\t" L2_MF "%3, %15, %16, %3\n\t"
+               L2_MF "%4, %12, %17, %4\n\t" L2_MF "%5, %13, %17, %5\n\t" L2_MF "%6, %14, %17, %6\n\t" L2_MF "%7, %15, %17, %7\n\t"
+               L2_MF "%8, %12, %18, %8\n\t" L2_MF "%9, %13, %18, %9\n\t" L2_MF "%10, %14, %18, %10\n\t" L2_MF "%11, %15, %18, %11"
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]), "+a"(c[1][0]), "+a"(c[1][1]), "+a"(c[1][2]), "+a"(c[1][3]),
+                 "+a"(c[2][0]), "+a"(c[2][1]), "+a"(c[2][2]), "+a"(c[2][3])
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]), "v"(w[1]), "v"(w[2]));
+}
+__device__ __forceinline__ void mfma_group(d4 (&c)[4][4], double x0, double x1, double x2, double x3, const double (&w)[4]) {
+  asm volatile("s_nop 1\n\t" L2_MF "%0, %16, %20, %0\n\t" L2_MF "%1, %17, %20, %1\n\t" L2_MF "%2, %18, %20, %2\n\t" L2_MF "%3, %19, %20, %3\n\t"
+               L2_MF "%4, %16, %21, %4\n\t" L2_MF "%5, %17, %21, %5\n\t" L2_MF "%6, %18, %21, %6\n\t" L2_MF "%7, %19, %21, %7\n\t"
+               L2_MF "%8, %16, %22, %8\n\t" L2_MF "%9, %17, %22, %9\n\t" L2_MF "%10, %18, %22, %10\n\t" L2_MF "%11, %19, %22, %11\n\t"
+               L2_MF "%12, %16, %23, %12\n\t" L2_MF "%13, %17, %23, %13\n\t" L2_MF "%14, %18, %23, %14\n\t" L2_MF "%15, %19, %23, %15"
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]), "+a"(c[1][0]), "+a"(c[1][1]), "+a"(c[1][2]), "+a"(c[1][3]),
+                 "+a"(c[2][0]), "+a"(c[2][1]), "+a"(c[2][2]), "+a"(c[2][3]), "+a"(c[3][0]), "+a"(c[3][1]), "+a"(c[3][2]), "+a"(c[3][3])
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+}
+#undef L2_MF
+// after the last MFMA: its result is read by ordinary vector instructions (v_accvgpr_read) that hipcc pads for its own MFMAs only
+template <int NS>
+__device__ __forceinline__ void mfma_drain(d4 (&c)[NS][4]) {
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(c[s_][0]), "+a"(c[s_][1]), "+a"(c[s_][2]), "+a"(c[s_][3]));
+}
+
+template <int MODE, int NW, int RT, int TT>
+__global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
+  static_assert(TT == 4, "mfma_group is written for four token tiles (a 64-token chunk)");
+  // blockIdx.y: which 64-token chunk of the launch (up to PF_S): the same weight tile against the next 64 activation rows.  More
+  // chunks per launch = more workgroups per launch, which is what lets wo / w2 (256 row tiles) take 2 or 4 row tiles per wave
+  // and still fill 256 CUs, and what evens out w1 / w3's 688 tiles (2.7 per CU in one chunk, 10.75 in four).
+  PfArgs a = a_in;
+  {
+    const int ch = blockIdx.y;
+    a.xin += (size_t)ch * PF_T * a.n;
+    if (a.x) a.x += (size_t)ch * PF_T * a.dim;
+    if (a.out) a.out += (size_t)ch * PF_T * (MODE == MODE_W13 ? a.rows : a.dim);
+    a.pos0 += ch * PF_T;
+    a.nvalid = min(max(a.nvalid - ch * PF_T, 0), (int)PF_T);
+  }
+  constexpr bool DUAL = (MODE == MODE_W13);
+  constexpr int NS = DUAL ? 2 * RT : RT;             // weight streams of the wave: row tiles (w1 tile r, w3 tile r, ... when DUAL)
+#ifndef L2_PF3_UN12
+#define L2_PF3_UN12 2
+#endif
+  constexpr int UN = (NS <= 2) ? L2_PF3_UN12 : 2;    // 16-column blocks per batch (two batches in flight)
+  extern __shared__ __attribute__((aligned(16))) double part3[];     // [TT][NW][4][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = a.n, npair = (n >> 4) / UN;
+  const int j = lane & 15, kq = lane >> 4;
+  const unsigned voff = (unsigned)(((size_t)j * n + 4 * kq) * 4);     // this lane's element of a 16-row tile, bytes
+  // one buffer descriptor per weight stream (a tile never straddles wq / wk / wv: dim % 16 == 0), one for the activations
+  __amdgpu_buffer_rsrc_t wrs[NS];
+  int tm[RT], ti0[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int row0 = (blockIdx.x * RT + r) * 16;
+    int m = 0, i0 = row0;
+    const float* wb = a.w0;
+    if (MODE == MODE_QKV) { m = row0 / a.dim; i0 = row0 - m * a.dim; wb = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2; }
+    tm[r] = m; ti0[r] = i0;
+    const unsigned bytes = (unsigned)16 * (unsigned)n * 4u;
+    if (DUAL) {
+      wrs[2 * r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w0 + (size_t)i0 * n), 0, bytes, 0x00020000);
+      wrs[2 * r + 1] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1 + (size_t)i0 * n), 0, bytes, 0x00020000);
+    } else {
+      wrs[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wb + (size_t)i0 * n), 0, bytes, 0x00020000);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xin), 0, (unsigned)(16 * TT) * (unsigned)n * 4u, 0x00020000);
+  const unsigned tstride = 16u * (unsigned)n * 4u;                    // bytes between token tiles
+  d4 acc[NS][TT];
+  {
+    const d4 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) acc[s_][t] = z;
+  }
+  struct Batch { f4 wv[UN][NS], xv[UN][TT]; };
+  // batch i of this wave is batch wave + i * NW of the row (split K, round-robin); a batch past the wave's last one is requested
+  // OUT OF RANGE of both descriptors and reads as zeros: the loop below then runs whole pairs of batches for every wave, with
+  // one back edge and one exit (with a second exit between the two halves hipcc keeps two copies of the accumulator tiles and
+  // moves 96 AGPRs from one to the other in every iteration)
+  const int nb = (npair - wave + NW - 1) / NW;
+  const unsigned oob = (unsigned)(16 * TT) * (unsigned)n * 4u;
+  auto load = [&](Batch& b, int i) {
+    const unsigned base = (i < nb) ? (unsigned)((wave + i * NW) * UN) * 64u : oob;     // scalar: 16 columns = 64 bytes per block
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const unsigned soff = base + (unsigned)u * 64u;
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) b.wv[u][s_] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs[s_], voff, soff, 2));   // nt: each weight byte is read once
+#pragma unroll
+      for (int t = 0; t < TT; ++t) b.xv[u][t] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, soff + (unsigned)t * tstride, 0));
+    }
+  };
+  auto mma = [&](const Batch& b) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      double wd[NS][4], xd[TT][4];
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) { wd[s_][0] = b.wv[u][s_].x; wd[s_][1] = b.wv[u][s_].y; wd[s_][2] = b.wv[u][s_].z; wd[s_][3] = b.wv[u][s_].w; }
+#pragma unroll
+      for (int t = 0; t < TT; ++t) { xd[t][0] = b.xv[u][t].x; xd[t][1] = b.xv[u][t].y; xd[t][2] = b.xv[u][t].z; xd[t][3] = b.xv[u][t].w; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double wk[NS];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) wk[s_] = wd[s_][k];
+        mfma_group(acc, xd[0][k], xd[1][k], xd[2][k], xd[3][k], wk);
+      }
+    }
+  };
+  Batch A, B;
+  load(A, 0);
+  for (int i = 0; i < nb; i += 2) {
+    load(B, i + 1);                                    // batch i + 1 loads while batch i is on the matrix pipe
+    mma(A);
+    load(A, i + 2);
+    mma(B);
+  }
+  mfma_drain<NS>(acc);
+  // ---- split-K combine, one weight stream at a time: every wave parks its TT partial tiles, wave t (t < TT) adds token tile t
+  // over the waves IN WAVE ORDER (the same sum on every run) and finishes it
+  auto park = [&](int s_) {
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part3[((size_t)(t * NW + wave) * 4 + r) * 64 + lane] = acc[s_][t][r];
+  };
+  auto gather = [&](int t) {
+    d4 v = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double sacc = part3[((size_t)(t * NW + 0) * 4 + r) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) sacc += part3[((size_t)(t * NW + w) * 4 + r) * 64 + lane];
+      v[r] = sacc;
+    }
+    return v;
+  };
+  static_assert(NW >= TT, "one finishing wave per token tile");
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    d4 first = {0.0, 0.0, 0.0, 0.0}, second = {0.0, 0.0, 0.0, 0.0};
+    __syncthreads();                                   // the previous stream's partials have been read
+    park(DUAL ? 2 * r : r);
+    __syncthreads();
+    if (wave < TT) first = gather(wave);
+    if (DUAL) {
+      __syncthreads();
+      park(2 * r + 1);
+      __syncthreads();
+      if (wave < TT) second = gather(wave);
+    }
+    if (wave < TT) pf_emit<MODE>(a, first, second, tm[r], ti0[r] + j, j, kq, 16 * wave);
+  }
 }
 
 }  // namespace l2k
