@@ -332,6 +332,9 @@ def main():
     tp = None
     shards = world > 1 and args.config.startswith("llama2_7b")
     if world > 1:
+        # the second-chance rendezvous below (ranks meeting through files, L2_TP_IPC_DIR) is one of the library's gated hooks;
+        # the gate is read once per process, so it is opened before the first context exists
+        os.environ.setdefault("L2_TEST_HOOKS", "1")
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo")   # rendezvous + barriers only; the data path is inside the library

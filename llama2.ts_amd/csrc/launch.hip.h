@@ -1,0 +1,211 @@
+// launch.hip.h -- launch geometry of the GEMV phases and the attention kernel
+// Part of the one translation unit llama2_hip.hip (included there, in order); not a stand-alone header.
+#pragma once
+
+// Launch geometry.  A wave owns R rows at a time and loads U x 64 float4 per row per batch; see
+// phase_kernel.  (R, U) is picked so one batch is ~16 loads per lane and a short row is one batch; the
+// grid is capped at what is co-resident so every wave loops over several row groups with its two
+// register sets always full (the per-workgroup prologue is then amortised as well).
+struct Geo { int R, U, pre, nwaves, grid; bool vec; };
+
+static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
+  Geo g;
+  g.vec = (n % 4) == 0;
+  const int n4 = n / 4;
+  const int pair = (mode == MODE_W13) ? 2 : 1;  // W13: R covers R/2 rows of w1 + R/2 of w3
+  // Measured on MI355X (tools/sweep_gemv.py, 7B shapes): small batches at high occupancy win -- R = 2 rows,
+  // U = 2..4 (8..16 KiB in flight per wave, <= 64 VGPRs => 8 waves per SIMD) reach 6.0-6.4 TB/s, R = 4 / U = 8
+  // variants (more bytes per wave, fewer waves) stay below 5.5.
+  g.R = 2;
+  (void)dim;
+  int U = (n4 <= 64) ? 1 : 2;                    // a short row is a single batch
+  if (n4 > 128 && n4 <= 256) U = 4;
+  if (mode == MODE_CLS && n4 > 128 && n4 <= 192) U = 3;   // 768 columns (stories110M): three float4 per lane cover a row exactly; with U = 4 a quarter of the lanes re-read the last one (16.8 -> 16.5 us)
+  if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4 || (c->tune_U == 3 && mode == MODE_CLS)) U = c->tune_U;
+  g.U = U;
+  const int groups = (rows * pair + g.R - 1) / g.R;
+  g.nwaves = groups >= 1024 ? 4 : (groups >= 512 ? 2 : 1);
+  if (c->tune_nwaves == 1 || c->tune_nwaves == 2 || c->tune_nwaves == 4) g.nwaves = c->tune_nwaves;
+  // staging: PRE float4 per thread per round, one round if it can cover the (padded) vector
+  const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 64 * g.nwaves;
+  // one staging round whenever 12 float4 per thread cover the vector (w2 of Llama-2-7B: 11008 floats = 2752 float4 on 256
+  // threads): every extra round is one more dependent L2 round trip in front of the first FMA
+  g.pre = (npad4 <= nth) ? 1 : (npad4 <= 2 * nth ? 2 : (npad4 <= 4 * nth ? 4 : 12));
+  int grid = (groups + g.nwaves - 1) / g.nwaves;
+  // persistent grid: 2 workgroups (8 waves) per CU, each wave looping over row groups with both register sets
+  // full, measured best on the 7B shapes (129.6 us of GEMV per layer vs 134.1 at 6 per CU)
+  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : c->n_cus * 2;
+  if (grid > cap) {
+    // balanced: every wave gets the same number k of row groups (w1/w3 of 7B: 5504 groups on 2048 waves would
+    // leave a third of the chip idle in the last round; 459 workgroups x 4 waves x 3 groups covers it evenly).
+    // Measured against a full grid that deals the odd groups evenly over the CUs (the 53 CUs with one workgroup are done
+    // after 44 us, the others after 53-57: tools/stamps.py STAMPS_WG=2): the full grid's last round ran as slowly as any
+    // other, 216.5 vs 219.3 tok/s.
+    const int waves_cap = cap * g.nwaves;
+    const int k = (groups + waves_cap - 1) / waves_cap;
+    grid = (groups + g.nwaves * k - 1) / (g.nwaves * k);
+  }
+  g.grid = grid < 1 ? 1 : grid;
+  return g;
+}
+
+#ifdef L2_STAMPS
+static int g_stamp_slot = 0;   // each launch of the enqueue gets its own 36-stamp slot
+extern "C" int l2_debug_stamps(l2_ctx* c, unsigned long long* out, size_t n) {
+  hipStreamSynchronize(c->stream);
+  return hipMemcpy(out, c->dbg, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
+
+
+// LDS a launch may ask for: 160 KiB per CU on gfx950, opted into per kernel (the default cap is 64 KiB).
+template <class K>
+static hipError_t lds_opt_in(K kernel, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// Launch with optional start / stop events on THE DISPATCH (hipExtLaunchKernelGGL): their elapsed time is the kernel's
+// own execution time, as a kernel trace reports it -- no launch boundary, no event-record latency (the in-situ probe).
+template <class K, class A>
+static void launch_probed(const l2_ctx* c, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const A& a, bool probe) {
+  l2_ctx* m = const_cast<l2_ctx*>(c);
+  if (probe && m->probe_on && m->probe_used + 2 <= m->probe.size()) {
+    hipEvent_t e0 = m->probe[m->probe_used], e1 = m->probe[m->probe_used + 1];
+    m->probe_used += 2;
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0, e1, 0, a);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
+  }
+}
+
+// Latency form (kernels.hip.h: phase_small_kernel) for matrices of at most `small_max` floats whose input vector fits
+// 8 float4 per lane; everything else (Llama-2-7B's phases, every classifier) streams through phase_kernel.
+static bool use_small(const l2_ctx* c, int mode, int rows, int n) {
+  if (n % 4 || n > 2048 || mode == MODE_CLS) return false;
+  const long long elems = (long long)rows * n * (mode == MODE_W13 ? 2 : 1);
+  return elems <= (long long)c->small_max;
+}
+
+template <int MODE, int XV>
+static hipError_t launch_small_xv(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
+  constexpr bool pair = (MODE == MODE_QKV || MODE == MODE_W13);       // row pairs: RoPE neighbours / (w1, w3)
+  const size_t lds = (size_t)XV * 64 * 16;
+  const int waves = c->n_cus * 7;     // seven compute waves per workgroup (kernels.hip.h)
+  // one row per wave while that still leaves waves idle, else two
+  const bool r1 = !pair && a.rows <= waves;
+  const int rpg = (MODE == MODE_W13) ? 1 : (r1 ? 1 : 2);
+  const int groups = (a.rows + rpg - 1) / rpg;
+  int grid = (groups + 6) / 7;
+  if (grid > c->n_cus) grid = c->n_cus;
+  if (grid < 1) grid = 1;
+  if (!pair && r1) launch_probed(c, phase_small_kernel<MODE, XV, pair ? 2 : 1>, dim3(grid), dim3(512), lds, st, a, MODE == MODE_W13);
+  else launch_probed(c, phase_small_kernel<MODE, XV, 2>, dim3(grid), dim3(512), lds, st, a, MODE == MODE_W13);
+  return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_small(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
+  const int xv = (a.n / 4 + 63) / 64;
+  switch (xv) {
+    case 1: return launch_small_xv<MODE, 1>(c, a, st);
+    case 2: return launch_small_xv<MODE, 2>(c, a, st);
+    case 3: return launch_small_xv<MODE, 3>(c, a, st);
+    case 4: return launch_small_xv<MODE, 4>(c, a, st);
+    case 5: case 6: return launch_small_xv<MODE, 6>(c, a, st);
+    default: return launch_small_xv<MODE, 8>(c, a, st);
+  }
+}
+
+template <int MODE>
+static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream_t st) {
+  PhaseArgs a = a_in;
+  a.rot = c->tune_rot;
+#ifdef L2_STAMPS
+  a.dbg_wg = c->dbg + 66 * 108 + (size_t)(g_stamp_slot % 64) * 2048;
+  a.dbg = c->dbg + (size_t)(g_stamp_slot++ % 64) * 108;
+#endif
+  if (use_small(c, MODE, a.rows, a.n)) return launch_small<MODE>(c, a, st);
+  const Geo g = pick_geo(c, MODE, a.rows, a.n, a.dim);
+  const dim3 grid(g.grid), block(64 * g.nwaves);
+  if (!g.vec) {
+    const size_t lds = (((size_t)a.n * 4 + 15) & ~(size_t)15) + 64;
+    hipError_t e = lds_opt_in(&phase_kernel_scalar<MODE>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((phase_kernel_scalar<MODE>), grid, block, lds, st, a);
+    return hipGetLastError();
+  }
+  const int n4 = a.n / 4, cpi = 64 * g.U;
+  const int npad4 = ((n4 + cpi - 1) / cpi) * cpi;
+  const bool norm = (MODE == MODE_QKV || MODE == MODE_W13 || MODE == MODE_CLS);
+  const int round4 = g.pre * 64 * g.nwaves;                   // PRE * nthreads (kernels.hip.h)
+  const int nstage4 = ((npad4 + round4 - 1) / round4) * round4;
+  const size_t lds = (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
+#define L2_LAUNCH(UU, PP) do { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \
+                               launch_probed(c, phase_kernel<MODE, 2, UU, PP>, grid, block, lds, st, a, MODE == MODE_W13); } while (0)
+#define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else if (g.pre == 4) L2_LAUNCH(UU, 4); else L2_LAUNCH(UU, 12); } while (0)
+  if (g.U == 3) { if constexpr (MODE == MODE_CLS) { L2_LAUNCH_U(3); } }
+  else if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
+#undef L2_LAUNCH_U
+#undef L2_LAUNCH
+  return hipGetLastError();
+}
+
+static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4 == 0) && (c->kvd_loc % 4 == 0) && c->hs <= 256; }
+
+static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
+  const size_t loff = (size_t)l * c->S * c->kvd_loc;
+  memset(&a, 0, sizeof(a));
+  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->opt_keep_state ? c->att : nullptr; a.xb = c->xb;
+  a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter;
+  a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
+  a.kv_dim = c->kvd_loc; a.kv_mul = c->H / c->KVH;
+  a.exact = c->opt_exact;
+  a.inv_sqrt_hs = 1.0 / sqrt((double)c->hs);
+#ifdef L2_STAMPS
+  a.dbg = c->dbg + 64 * 108;   // attention stamps live behind the phase-kernel slots (last launch wins)
+#endif
+}
+
+// Lanes per cache row: head_size / 4 rounded up to a power of two (attention.hip.h); waves per workgroup: 8 from
+// 128-wide heads (a round is then 256 rows), else 4.
+static int attn_lr(int hs) { int l = 4; while (l * 4 < hs) l <<= 1; return l; }
+static int attn_nw(const l2_ctx* c) { return (c->attn_nw == 4 || c->attn_nw == 8) ? c->attn_nw : (c->hs > 64 ? 8 : 4); }
+
+// One launch of the tile kernel; ny = splits (decode) or queries of the chunk (prefill, pos0 >= 0).
+static hipError_t launch_attn_tile(const l2_ctx* c, const AttnArgs& a, int ny, int pos0, hipStream_t st) {
+  const int lr = attn_lr(c->hs), nw = attn_nw(c);
+  const size_t lds = attn_tile_lds(c->S, pos0 >= 0 ? 1 : a.nsplit, nw, nw == 8 ? 8 : 16);
+  const dim3 grid(c->H_loc, ny), block(64 * nw);
+  // 4 waves x 16 tiles (one wave per SIMD, ~290 registers) or 8 waves x 8 tiles (two per SIMD, <= 256 registers)
+#define L2_AT(LR, NW, NT) do { if (pos0 >= 0) { hipError_t e_ = lds_opt_in(&pf_attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
+                                            hipLaunchKernelGGL((pf_attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a, pos0); } \
+                           else { hipError_t e_ = lds_opt_in(&attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
+                                  hipLaunchKernelGGL((attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a); } } while (0)
+#define L2_AT_NW(LR) do { if (nw == 8) L2_AT(LR, 8, 8); else L2_AT(LR, 4, 16); } while (0)
+  switch (lr) {
+    case 4: L2_AT_NW(4); break;
+    case 8: L2_AT_NW(8); break;
+    case 16: L2_AT_NW(16); break;
+    case 32: L2_AT_NW(32); break;
+    default: L2_AT_NW(64); break;
+  }
+#undef L2_AT_NW
+#undef L2_AT
+  return hipGetLastError();
+}
+
+static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // attention (llama2.ts:244-267)
+  AttnArgs a;
+  fill_attn_args(c, l, a);
+  if (!attn_vec(c)) {
+    const size_t lds = (size_t)((c->S + 3) & ~3) * 4 + 64;
+    hipError_t e = lds_opt_in(&attn_scalar_kernel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_scalar_kernel, dim3(c->H_loc, 1), dim3(256), lds, st, a, 0);
+    return hipGetLastError();
+  }
+  if (c->opt_exact) a.nsplit = 1;
+  return launch_attn_tile(c, a, a.nsplit, -1, st);
+}

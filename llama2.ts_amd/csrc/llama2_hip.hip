@@ -37,221 +37,8 @@ using namespace l2k;
 
 enum { NLEV = 2 };   // attention split levels: 1 or 8 workgroups per head
 
-// ------------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
+#include "ctx.hip.h"
 
-static int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
-
-#define HIPCHK(expr)                                                                              \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess) return fail(L2_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-// ---- RCCL, bound lazily so the library has no link-time dependency on it ------------------------
-typedef struct { char internal[128]; } nccl_uid;
-typedef void* nccl_comm;
-struct Rccl {
-  void* so = nullptr;
-  int (*GetUniqueId)(nccl_uid*) = nullptr;
-  int (*CommInitRank)(nccl_comm*, int, nccl_uid, int) = nullptr;
-  int (*CommDestroy)(nccl_comm) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, nccl_comm, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-};
-static Rccl g_rccl;
-enum { NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
-
-static int rccl_bind() {
-  if (g_rccl.so) return L2_OK;
-  const char* names[] = {getenv("L2_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  void* so = nullptr;
-  for (const char* n : names) {
-    if (!n) continue;
-    so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (so) break;
-  }
-  if (!so) return fail(L2_E_COMM, "cannot dlopen RCCL: %s", dlerror());
-  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(so, "ncclGetUniqueId");
-  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(so, "ncclCommInitRank");
-  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(so, "ncclCommDestroy");
-  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(so, "ncclAllReduce");
-  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(so, "ncclAllGather");
-  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(so, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy) {
-    dlclose(so);
-    return fail(L2_E_COMM, "RCCL symbols missing");
-  }
-  g_rccl.so = so;
-  return L2_OK;
-}
-
-#define NCCLCHK(expr)                                                                             \
-  do {                                                                                            \
-    int r_ = (expr);                                                                              \
-    if (r_ != 0) return fail(L2_E_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
-  } while (0)
-
-// ---- Loopback communicator (L2_TP_LOOPBACK=1): a TEST HOOK, not a product path ---------------------
-// The driver's multi-GPU node is the only place RCCL runs with more than one rank, and it is not reachable from
-// the 1-GPU development boxes.  With L2_TP_LOOPBACK=1 the G ranks of a tensor-parallel group are G contexts of
-// ONE process on ONE device, each driven by its own host thread (tests/test_tp_gpu.py); the two collectives are
-// then plain device work between host-side thread barriers: every rank sums the G published fp64 partial vectors
-// in rank order (all-reduce) or copies the G logits slices (all-gather).  Everything else -- shard slicing,
-// fp64 partial GEMVs, the single rounding in tp_residual_kernel, the greedy loop on gathered logits -- is the
-// code the RCCL path runs.  Groups are keyed by the 128-byte id the caller passes to l2_create_tp.
-struct LoopGroup {
-  int G = 0;
-  std::mutex mu;
-  std::condition_variable cv;
-  int arrived = 0;
-  unsigned gen = 0;
-  bool broken = false;
-  const void* ptrs[16] = {};
-  void* p2p_base[16] = {};     // peer-to-peer exchange: every rank's inbox / logits, registered at create
-  float* p2p_logits[16] = {};
-  bool wait() {   // generation barrier; false after 60 s (a rank died: fail instead of hanging the box)
-    std::unique_lock<std::mutex> lk(mu);
-    if (broken) return false;
-    const unsigned g = gen;
-    if (++arrived == G) { arrived = 0; ++gen; cv.notify_all(); return true; }
-    if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g || broken; })) { broken = true; cv.notify_all(); return false; }
-    return !broken;
-  }
-};
-static std::mutex g_loop_mu;
-static std::map<std::string, std::shared_ptr<LoopGroup>> g_loop_groups;
-
-struct LoopPtrs { const double* p[16]; };
-__global__ void loop_sum_kernel(double* out, const LoopPtrs in, int G, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = in.p[0][i];
-  for (int r = 1; r < G; ++r) s += in.p[r][i];
-  out[i] = s;
-}
-
-// one-shot peer-to-peer exchange (kernels and protocol: tp_p2p_* below)
-enum { P2P_MAXG = 8, P2P_FB = 64 };   // ranks; flag words per (parity, source): blocks of the widest exchange
-struct P2PPeers { unsigned long long* flags[P2P_MAXG]; double* inbox[P2P_MAXG]; float* logits[P2P_MAXG]; };
-struct P2PArgs {
-  P2PPeers pr;
-  unsigned long long* epoch;   // this rank's exchange counter
-  unsigned* ticket;            // blocks finished in this launch
-  int* err;
-  int G, rank, n;              // n: elements of this exchange (d, or V_loc)
-  unsigned long long wait_ticks;   // bound of a flag wait, in 100 MHz ticks
-};
-
-// ------------------------------------------------------------------------------------------------
-struct l2_ctx {
-  int32_t hdr[7];
-  int d, h, L, H, V, S, hs;
-  bool shared;
-  int device;
-  hipStream_t stream = nullptr;
-  // tensor parallel shard (G == 1: everything local)
-  int G = 1, rank = 0;
-  int d_loc, h_loc, H_loc, V_loc;
-  int KVH, kvd, kvd_loc;             // cache heads honoured (== H unless L2_F_GQA), floats of a cache row, per rank
-  unsigned flags = 0;
-  nccl_comm comm = nullptr;
-  l2s::Sampler samp;                 // device sampler (l2_decode_sample), created on first use
-  hipGraphExec_t g_sample[NLEV][4] = {};  // [attention split level][plain sample / top-p, + 2: maximum taken from the classifier's argmax keys]
-  bool samp_amax = false;
-  int samp_mode = 0;
-  std::shared_ptr<LoopGroup> loop;   // L2_TP_LOOPBACK test hook (see LoopGroup)
-  double* loop_tmp = nullptr;
-  bool tp_path = false;   // WO/W2 write fp64 partials + all-reduce; logits all-gathered (G > 1, or forced for tests)
-  // one-shot peer-to-peer exchange (tp_p2p_*): this rank's inbox + flags, the peers' mappings
-  bool p2p = false;
-  void* p2p_base = nullptr;          // uncached: [2][8][64] flag words, then [2][8][d] doubles
-  unsigned long long* p2p_epoch = nullptr;   // + ticket (device)
-  int* p2p_err = nullptr;            // pinned + mapped
-  int* p2p_err_dev = nullptr;
-  P2PPeers p2p_peers = {};
-  std::vector<void*> p2p_opened;     // IPC mappings to close
-  bool p2p_peers_ready = false;
-  unsigned long long p2p_wait_ticks = 3000000000ull;   // L2_TP_WAIT_S (default 30 s) on the 100 MHz clock
-  bool p2p_synced = false;           // the ranks have met once (host side) right before the first exchange of a step
-  bool broken = false;               // a peer-to-peer wait gave up: this rank's epochs no longer match its peers'
-
-  float* w[L2_T_COUNT] = {};
-  size_t layer_elems[L2_T_COUNT] = {};  // LOCAL floats per layer (or whole tensor when unlayered)
-  int layers_of[L2_T_COUNT] = {};
-  std::vector<uint8_t> uploaded[L2_T_COUNT];
-
-  float *x = nullptr, *xb = nullptr, *xb2 = nullptr, *hb = nullptr, *hb2 = nullptr, *q = nullptr, *k = nullptr,
-        *v = nullptr, *att = nullptr, *logits = nullptr, *logits_loc = nullptr, *kc = nullptr, *vc = nullptr, *xn = nullptr;
-  double* partial = nullptr;
-  double* attn_part = nullptr;      // split attention partials [H][NS][rec]
-  unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
-  unsigned long long* amax = nullptr;   // greedy loop: 8 argmax keys, one per 128-byte line, zero between tokens
-  int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
-  int pf3 = 1;                      // L2_PF3: 1 (default) register-blocked prefill GEMMs where the shape allows, 0: the 16-row-tile kernels everywhere (A/B, tests)
-  int pf_nw[4] = {4, 4, 4, 4};      // L2_PF_NW_QKV / _WO / _W13 / _W2: waves per 16-row tile in the older prefill GEMMs (4 or 8)
-  int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
-  int cur_splits = 1;               // split count of the step being enqueued / captured
-  int split_rows = 144;             // L2_ATTN_SPLIT_ROWS: cached rows of a head beyond which attention runs 8 workgroups per head
-  int attn_nw = 0;                  // L2_ATTN_NW: waves per attention workgroup (0: by head size)
-  int small_max = 0;                // L2_SMALL_MAX: largest matrix (floats) that takes the latency-form GEMV
-  int n_cus = 256;
-  std::string ipc_dir;              // L2_TP_IPC_DIR: ranks are processes that meet through files (test hook)
-  std::vector<hipEvent_t> probe;    // in-situ probe: event pairs around every launch of the dominant kernel
-  size_t probe_used = 0;
-  bool probe_on = false;
-  // prefill (prefill.hip.h): 16-token chunk buffers
-  float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_xb = nullptr, *pf_hb = nullptr;
-  int* pf_tok = nullptr;
-  int* tokpos = nullptr;    // device {token,pos,step,0}
-  int* h_tokpos = nullptr;  // pinned
-  int* d_tokens = nullptr;  // device, S ints
-  float* h_logits = nullptr;      // pinned + mapped: the classifier kernel writes it directly
-  float* h_logits_dev = nullptr;  // device alias of h_logits
-  int opt_zero_copy = 1;
-  int profile_sync = 0;
-  unsigned long long* dbg = nullptr;  // L2_STAMPS builds
-
-  hipGraphExec_t g_step[NLEV] = {}, g_greedy[NLEV] = {};   // one captured graph per attention split level
-  int opt_exact = 0, opt_graph = 1, opt_keep_state = 0;
-  int next_pos = 0;
-  bool ran_forward = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // tuning overrides (env)
-  int tune_R = 0, tune_U = 0, tune_nwaves = 0, tune_gridcap = 0, tune_rot = 5;
-};
-
-static bool is_layered(int kind) { return kind >= L2_T_RMS_ATT && kind <= L2_T_W3; }
-
-// Local (per-rank) shape of one layer of a tensor: rows x cols, plus where the slice sits in the
-// full tensor (row0/col0) so l2_upload can cut it out of the caller's full array.
-struct Slice { size_t rows, cols, full_rows, full_cols, row0, col0; };
-
-static Slice tensor_slice(const l2_ctx* c, int kind) {
-  const size_t d = c->d, h = c->h, V = c->V, S = c->S, hs2 = c->hs / 2;
-  const size_t dl = c->d_loc, hl = c->h_loc, Vl = c->V_loc, r = c->rank;
-  switch (kind) {
-    case L2_T_TOKEN_EMBEDDING: return {V, d, V, d, 0, 0};
-    case L2_T_RMS_ATT: case L2_T_RMS_FFN: case L2_T_RMS_FINAL: return {1, d, 1, d, 0, 0};
-    case L2_T_WQ: return {dl, d, d, d, r * dl, 0};  // whole heads
-    case L2_T_WK: case L2_T_WV: return {(size_t)c->kvd_loc, d, (size_t)c->kvd, d, r * (size_t)c->kvd_loc, 0};
-    case L2_T_WO: return {d, dl, d, d, 0, r * dl};                                 // columns, repacked
-    case L2_T_W1: case L2_T_W3: return {hl, d, h, d, r * hl, 0};
-    case L2_T_W2: return {d, hl, d, h, 0, r * hl};
-    case L2_T_FREQ_REAL: case L2_T_FREQ_IMAG: return {S, hs2, S, hs2, 0, 0};
-    case L2_T_WCLS: return {Vl, d, V, d, r * Vl, 0};
-    default: return {0, 0, 0, 0, 0, 0};
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 extern "C" int l2_abi_version(void) { return L2_ABI_VERSION; }
 extern "C" const char* l2_last_error(void) { return g_err; }
 
@@ -315,11 +102,6 @@ extern "C" void l2_destroy(l2_ctx* c) {
   delete c;
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return s && *s ? atoi(s) : dflt;
-}
-
 static int p2p_alloc(l2_ctx* c);
 static int p2p_connect_ipc(l2_ctx* c);
 
@@ -365,7 +147,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->tune_nwaves = env_int("L2_TUNE_NWAVES", 0);
   c->tune_gridcap = env_int("L2_TUNE_GRIDCAP", 0);
   c->tune_rot = env_int("L2_TUNE_ROT", 5);
-  c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !env_int("L2_TP_FORCE_COMM", 0)) ? 1 : 0);
+  c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !hook_int("L2_TP_FORCE_COMM")) ? 1 : 0);
   c->profile_sync = env_int("L2_PROFILE_SYNC", 0);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
@@ -393,7 +175,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMalloc(&c->hb, c->h_loc * 4)); CK(hipMalloc(&c->hb2, c->h_loc * 4));
   CK(hipMalloc(&c->q, dl * 4)); CK(hipMalloc(&c->k, kvl * 4)); CK(hipMalloc(&c->v, kvl * 4));
   CK(hipMalloc(&c->att, (size_t)c->H_loc * S * 4));
-  c->tp_path = G > 1 || env_int("L2_TP_FORCE_COMM", 0);   // the latter: 1-rank communicator, exercises the RCCL path on one GPU
+  c->tp_path = G > 1 || hook_int("L2_TP_FORCE_COMM");   // the latter: 1-rank communicator, exercises the RCCL path on one GPU
   // the gathered logits of a tensor-parallel rank are written by its peers (tp_p2p_gather_kernel): uncached memory
   if (c->tp_path) CK(hipExtMallocWithFlags((void**)&c->logits, (size_t)V * 4, hipDeviceMallocUncached));
   else CK(hipMalloc(&c->logits, (size_t)V * 4));
@@ -439,11 +221,11 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
 #endif
   CK(hipStreamSynchronize(c->stream));
 #undef CK
-  if (c->tp_path && !env_int("L2_TP_NO_COMM", 0)) { const int rc_ = p2p_alloc(c); if (rc_) { l2_destroy(c); return rc_; } }
-  if (G > 1 && env_int("L2_TP_NO_COMM", 0)) {
+  if (c->tp_path && !hook_int("L2_TP_NO_COMM")) { const int rc_ = p2p_alloc(c); if (rc_) { l2_destroy(c); return rc_; } }
+  if (G > 1 && hook_int("L2_TP_NO_COMM")) {
     // shard-layout tests on a single GPU: the slices are real, the communicator is absent and every
     // forward on this context fails with L2_E_COMM
-  } else if (G > 1 && env_int("L2_TP_LOOPBACK", 0)) {
+  } else if (G > 1 && hook_int("L2_TP_LOOPBACK")) {
     if (G > 16 || !nccl_id) { l2_destroy(c); return fail(L2_E_ARG, "loopback groups need an id and at most 16 ranks"); }
     if (hipMalloc(&c->loop_tmp, (size_t)d * 8) != hipSuccess) { l2_destroy(c); return fail(L2_E_HIP, "hipMalloc failed"); }
     std::lock_guard<std::mutex> lk(g_loop_mu);
@@ -453,8 +235,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     c->loop = grp;
     grp->p2p_base[rank] = c->p2p_base; grp->p2p_logits[rank] = c->logits;
     c->p2p = c->p2p_base != nullptr;          // peers resolved at the first step, once every rank has registered
-  } else if (G > 1 && getenv("L2_TP_IPC_DIR")) {
-    c->ipc_dir = getenv("L2_TP_IPC_DIR");
+  } else if (G > 1 && hook_str("L2_TP_IPC_DIR")) {
+    c->ipc_dir = hook_str("L2_TP_IPC_DIR");
     const int rc = p2p_connect_ipc(c);
     if (rc) { l2_destroy(c); return rc; }
   } else if (c->tp_path) {
@@ -523,7 +305,7 @@ extern "C" int l2_tp_mode(l2_ctx* c) {
   if (!c || !c->tp_path) return 0;
   if (c->loop) return 4;
   if (c->p2p) return 3;
-  return c->opt_graph ? 2 : 1;
+  return 1;
 }
 
 extern "C" int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out) {
@@ -566,662 +348,10 @@ extern "C" int l2_upload(l2_ctx* c, int kind, int layer, const float* host, size
   return L2_OK;
 }
 
-// ---- native checkpoint loader -------------------------------------------------
-extern "C" int l2_get_header(l2_ctx* c, int32_t cfg_out[7]) {
-  if (!c || !cfg_out) return fail(L2_E_ARG, "null argument");
-  memcpy(cfg_out, c->hdr, sizeof(c->hdr));
-  return L2_OK;
-}
+#include "loader.hip.h"
+#include "launch.hip.h"
+#include "tp_exchange.hip.h"
 
-extern "C" int l2_load_checkpoint(const char* path, int device, int tp_rank, int tp_size, const void* nccl_id,
-                                  l2_ctx** out, uint64_t* bytes_read) {
-  if (!path || !out) return fail(L2_E_ARG, "null argument");
-  *out = nullptr;
-  FILE* f = fopen(path, "rb");
-  if (!f) return fail(L2_E_ARG, "cannot open checkpoint %s", path);
-  int32_t hdr[7];
-  if (fread(hdr, 4, 7, f) != 7) { fclose(f); return fail(L2_E_ARG, "checkpoint %s: short header", path); }
-  // llama2.c "version 1" export: magic "ak42", version, the 7 ints, one byte shared_classifier, padded to 256 bytes;
-  // tensors in a different order (norms first) and no freq_cis.  Anything else is the v0 layout the reference reads.
-  static const int order_v0[] = {L2_T_TOKEN_EMBEDDING, L2_T_RMS_ATT, L2_T_WQ, L2_T_WK, L2_T_WV, L2_T_WO, L2_T_RMS_FFN, L2_T_W1, L2_T_W2, L2_T_W3,
-                                 L2_T_RMS_FINAL, L2_T_FREQ_REAL, L2_T_FREQ_IMAG, L2_T_WCLS};
-  static const int order_v1[] = {L2_T_RMS_ATT, L2_T_RMS_FFN, L2_T_RMS_FINAL, L2_T_TOKEN_EMBEDDING, L2_T_WQ, L2_T_WK, L2_T_WV, L2_T_WO, L2_T_W1,
-                                 L2_T_W2, L2_T_W3, L2_T_WCLS};
-  const int* order = order_v0;
-  int n_order = 14;
-  unsigned flags = 0;
-  uint64_t total = 28;
-  if ((uint32_t)hdr[0] == 0x616b3432u) {
-    if (hdr[1] != 1) { fclose(f); return fail(L2_E_CONFIG, "checkpoint %s: version %d export (only the fp32 version 1 is supported)", path, hdr[1]); }
-    int32_t h1[7];
-    unsigned char shared = 0;
-    if (fseek(f, 8, SEEK_SET) || fread(h1, 4, 7, f) != 7 || fread(&shared, 1, 1, f) != 1 || fseek(f, 256, SEEK_SET)) { fclose(f); return fail(L2_E_ARG, "checkpoint %s: short header", path); }
-    memcpy(hdr, h1, sizeof(hdr));
-    hdr[5] = shared ? abs(hdr[5]) : -abs(hdr[5]);        // the v0 convention: sign of vocab_size = shared classifier (llama2.ts:90)
-    order = order_v1; n_order = 12; flags = L2_F_GQA | L2_F_GENERATE_ROPE; total = 256;
-  }
-  l2_ctx* c = nullptr;
-  int rc = (tp_size > 1) ? create_impl(hdr, device, tp_rank, tp_size, nccl_id, &c, flags) : create_impl(hdr, device, 0, 1, nullptr, &c, flags);
-  if (rc) { fclose(f); return rc; }
-  if (flags & L2_F_GENERATE_ROPE) { rc = generate_rope(c); if (rc) { fclose(f); l2_destroy(c); return rc; } }
-  // two pinned staging buffers: fread into one while the other is in flight to the device
-  const size_t CH = (size_t)64 << 20;
-  float* stage[2] = {nullptr, nullptr};
-  hipEvent_t done[2] = {nullptr, nullptr};
-  bool pending[2] = {false, false};
-  auto cleanup = [&](int code) {
-    for (int i = 0; i < 2; ++i) { if (stage[i]) hipHostFree(stage[i]); if (done[i]) hipEventDestroy(done[i]); }
-    fclose(f);
-    if (code) l2_destroy(c);
-    return code;
-  };
-  for (int i = 0; i < 2; ++i) {
-    if (hipHostMalloc(&stage[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreate(&done[i]) != hipSuccess)
-      return cleanup(fail(L2_E_HIP, "cannot allocate pinned staging"));
-  }
-  int cur = 0;
-  for (int oi = 0; oi < n_order; ++oi) {
-    const int kind = order[oi];
-    if (kind == L2_T_WCLS && c->shared) continue;
-    const Slice sl = tensor_slice(c, kind);
-    const size_t full_layer = sl.full_rows * sl.full_cols;
-    for (int layer = 0; layer < c->layers_of[kind]; ++layer) {
-      float* dst = c->w[kind] + c->layer_elems[kind] * (size_t)layer;
-      // stream the layer in whole-row chunks; a rank keeps only its rows / columns
-      const size_t rows_per_chunk = CH / (sl.full_cols * sizeof(float)) ? CH / (sl.full_cols * sizeof(float)) : 1;
-      if (sl.full_cols * sizeof(float) > CH) return cleanup(fail(L2_E_CONFIG, "row of %zu floats exceeds the staging buffer", sl.full_cols));
-      for (size_t r0 = 0; r0 < sl.full_rows; r0 += rows_per_chunk) {
-        const size_t nr = (sl.full_rows - r0 < rows_per_chunk) ? sl.full_rows - r0 : rows_per_chunk;
-        if (pending[cur]) { if (hipEventSynchronize(done[cur]) != hipSuccess) return cleanup(fail(L2_E_HIP, "staging sync failed")); pending[cur] = false; }
-        if (fread(stage[cur], sizeof(float), nr * sl.full_cols, f) != nr * sl.full_cols)
-          return cleanup(fail(L2_E_ARG, "checkpoint %s truncated in tensor kind %d", path, kind));
-        total += nr * sl.full_cols * sizeof(float);
-        // intersect [r0, r0+nr) with the rank's rows [row0, row0+rows)
-        const size_t a = r0 > sl.row0 ? r0 : sl.row0;
-        const size_t b = (r0 + nr < sl.row0 + sl.rows) ? r0 + nr : sl.row0 + sl.rows;
-        if (a < b) {
-          const float* src = stage[cur] + (a - r0) * sl.full_cols + sl.col0;
-          float* d = dst + (a - sl.row0) * sl.cols;
-          hipError_t e = hipMemcpy2DAsync(d, sl.cols * sizeof(float), src, sl.full_cols * sizeof(float), sl.cols * sizeof(float),
-                                          b - a, hipMemcpyHostToDevice, c->stream);
-          if (e != hipSuccess) return cleanup(fail(L2_E_HIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e)));
-          hipEventRecord(done[cur], c->stream);
-          pending[cur] = true;
-        }
-        cur ^= 1;
-      }
-      (void)full_layer;
-      c->uploaded[kind][layer] = 1;
-    }
-  }
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return cleanup(fail(L2_E_HIP, "upload sync failed"));
-  if (bytes_read) *bytes_read = total;
-  *out = c;
-  return cleanup(L2_OK);
-}
-
-// deterministic exp / sincos from IEEE basic operations (same recipe as the oracle's generator)
-static double det_exp(double x) {
-  const double y = x / 1024.0;
-  double t = 1.0, s = 1.0;
-  for (int k = 1; k <= 14; ++k) { t = (t * y) / (double)k; s = s + t; }
-  for (int i = 0; i < 10; ++i) s = s * s;
-  return s;
-}
-static void det_sincos(double x, double* sn, double* cs) {
-  const double x2 = x * x;
-  double ts = x, tc = 1.0, ss = x, cc = 1.0;
-  for (int k = 1; k <= 12; ++k) {
-    tc = ((-tc) * x2) / (double)((2 * k - 1) * (2 * k));
-    cc = cc + tc;
-    ts = ((-ts) * x2) / (double)((2 * k) * (2 * k + 1));
-    ss = ss + ts;
-  }
-  *sn = ss; *cs = cc;
-}
-
-static uint64_t full_count(const l2_ctx* c, int kind) {
-  if (kind == L2_T_WCLS && c->shared) return 0;
-  const size_t d = c->d, h = c->h, V = c->V, S = c->S, hs2 = c->hs / 2, L = c->L;
-  switch (kind) {
-    case L2_T_TOKEN_EMBEDDING: case L2_T_WCLS: return V * d;
-    case L2_T_RMS_ATT: case L2_T_RMS_FFN: return L * d;
-    case L2_T_WQ: case L2_T_WO: return L * d * d;
-    case L2_T_WK: case L2_T_WV: return L * (size_t)c->kvd * d;
-    case L2_T_W1: case L2_T_W2: case L2_T_W3: return L * h * d;
-    case L2_T_RMS_FINAL: return d;
-    case L2_T_FREQ_REAL: case L2_T_FREQ_IMAG: return S * hs2;
-    default: return 0;
-  }
-}
-
-extern "C" int l2_synth_fill(l2_ctx* c, uint32_t seed) {
-  if (!c) return fail(L2_E_ARG, "null context");
-  HIPCHK(hipSetDevice(c->device));
-  uint64_t off = 0;
-  for (int kind = 0; kind < L2_T_COUNT; ++kind) {
-    const uint64_t n = full_count(c, kind);
-    if (!n) continue;
-    if (kind == L2_T_FREQ_REAL || kind == L2_T_FREQ_IMAG) {
-      if (kind == L2_T_FREQ_REAL) {
-        const int hs2 = c->hs / 2;
-        std::vector<float> re((size_t)c->S * hs2), im((size_t)c->S * hs2);
-        for (int j = 0; j < hs2; ++j) {
-          const double theta = det_exp(-(((2.0 * (double)j) / (double)c->hs) * 9.210340371976184));
-          double st, ct;
-          det_sincos(theta, &st, &ct);
-          double cr = 1.0, ci = 0.0;
-          for (int t = 0; t < c->S; ++t) {
-            re[(size_t)t * hs2 + j] = (float)cr;
-            im[(size_t)t * hs2 + j] = (float)ci;
-            const double nr = cr * ct - ci * st, ni = cr * st + ci * ct;
-            cr = nr; ci = ni;
-          }
-        }
-        HIPCHK(hipMemcpy(c->w[L2_T_FREQ_REAL], re.data(), re.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->w[L2_T_FREQ_IMAG], im.data(), im.size() * 4, hipMemcpyHostToDevice));
-      }
-    } else {
-      double sigma = 0.0; float bias = 0.0f;
-      switch (kind) {
-        case L2_T_TOKEN_EMBEDDING: case L2_T_WCLS: sigma = 0.02; break;
-        case L2_T_RMS_ATT: case L2_T_RMS_FFN: case L2_T_RMS_FINAL: sigma = 0.1; bias = 1.0f; break;
-        case L2_T_W2: sigma = 1.0 / sqrt((double)c->h); break;
-        default: sigma = 1.0 / sqrt((double)c->d); break;
-      }
-      const float scale = (float)(sigma / 37837.22723720648);
-      // the rank's slice of every layer (whole tensor when not sharded); a shared classifier aliases the table
-      const Slice sl = tensor_slice(c, kind);
-      SynthSlice ss;
-      ss.g0 = off; ss.full_layer = sl.full_rows * sl.full_cols; ss.rows = sl.rows; ss.cols = sl.cols;
-      ss.full_cols = sl.full_cols; ss.row0 = sl.row0; ss.col0 = sl.col0;
-      ss.n = sl.rows * sl.cols * (uint64_t)c->layers_of[kind];
-      const uint64_t want = (ss.n + 256 * 8 - 1) / (256 * 8);
-      const int blocks = (int)(want > 65535 ? 65535 : (want < 1 ? 1 : want));
-      hipLaunchKernelGGL(synth_fill_kernel, dim3(blocks), dim3(256), 0, c->stream, c->w[kind], ss, seed, scale, bias);
-      HIPCHK(hipGetLastError());
-    }
-    for (auto& u : c->uploaded[kind]) u = 1;
-    off += n;
-  }
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return L2_OK;
-}
-
-extern "C" int l2_read_tensor(l2_ctx* c, int kind, int layer, size_t offset, float* out, size_t n_floats) {
-  if (!c || !out) return fail(L2_E_ARG, "null argument");
-  if (kind < 0 || kind >= L2_T_COUNT) return fail(L2_E_ARG, "tensor kind %d out of range", kind);
-  int li = 0;
-  if (is_layered(kind)) { if (layer < 0 || layer >= c->L) return fail(L2_E_ARG, "layer out of range"); li = layer; }
-  const size_t n = c->layer_elems[kind] ? c->layer_elems[kind] : (size_t)c->V * c->d;
-  if (offset + n_floats > n) return fail(L2_E_ARG, "read of %zu floats at %zu exceeds tensor (%zu)", n_floats, offset, n);
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMemcpy(out, c->w[kind] + n * (size_t)li + offset, n_floats * 4, hipMemcpyDeviceToHost));
-  return L2_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Launch geometry.  A wave owns R rows at a time and loads U x 64 float4 per row per batch; see
-// phase_kernel.  (R, U) is picked so one batch is ~16 loads per lane and a short row is one batch; the
-// grid is capped at what is co-resident so every wave loops over several row groups with its two
-// register sets always full (the per-workgroup prologue is then amortised as well).
-struct Geo { int R, U, pre, nwaves, grid; bool vec; };
-
-static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
-  Geo g;
-  g.vec = (n % 4) == 0;
-  const int n4 = n / 4;
-  const int pair = (mode == MODE_W13) ? 2 : 1;  // W13: R covers R/2 rows of w1 + R/2 of w3
-  // Measured on MI355X (tools/sweep_gemv.py, 7B shapes): small batches at high occupancy win -- R = 2 rows,
-  // U = 2..4 (8..16 KiB in flight per wave, <= 64 VGPRs => 8 waves per SIMD) reach 6.0-6.4 TB/s, R = 4 / U = 8
-  // variants (more bytes per wave, fewer waves) stay below 5.5.
-  g.R = 2;
-  (void)dim;
-  int U = (n4 <= 64) ? 1 : 2;                    // a short row is a single batch
-  if (n4 > 128 && n4 <= 256) U = 4;
-  if (mode == MODE_CLS && n4 > 128 && n4 <= 192) U = 3;   // 768 columns (stories110M): three float4 per lane cover a row exactly; with U = 4 a quarter of the lanes re-read the last one (16.8 -> 16.5 us)
-  if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4 || (c->tune_U == 3 && mode == MODE_CLS)) U = c->tune_U;
-  g.U = U;
-  const int groups = (rows * pair + g.R - 1) / g.R;
-  g.nwaves = groups >= 1024 ? 4 : (groups >= 512 ? 2 : 1);
-  if (c->tune_nwaves == 1 || c->tune_nwaves == 2 || c->tune_nwaves == 4) g.nwaves = c->tune_nwaves;
-  // staging: PRE float4 per thread per round, one round if it can cover the (padded) vector
-  const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 64 * g.nwaves;
-  // one staging round whenever 12 float4 per thread cover the vector (w2 of Llama-2-7B: 11008 floats = 2752 float4 on 256
-  // threads): every extra round is one more dependent L2 round trip in front of the first FMA
-  g.pre = (npad4 <= nth) ? 1 : (npad4 <= 2 * nth ? 2 : (npad4 <= 4 * nth ? 4 : 12));
-  int grid = (groups + g.nwaves - 1) / g.nwaves;
-  // persistent grid: 2 workgroups (8 waves) per CU, each wave looping over row groups with both register sets
-  // full, measured best on the 7B shapes (129.6 us of GEMV per layer vs 134.1 at 6 per CU)
-  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : c->n_cus * 2;
-  if (grid > cap) {
-    // balanced: every wave gets the same number k of row groups (w1/w3 of 7B: 5504 groups on 2048 waves would
-    // leave a third of the chip idle in the last round; 459 workgroups x 4 waves x 3 groups covers it evenly).
-    // Measured against a full grid that deals the odd groups evenly over the CUs (the 53 CUs with one workgroup are done
-    // after 44 us, the others after 53-57: tools/stamps.py STAMPS_WG=2): the full grid's last round ran as slowly as any
-    // other, 216.5 vs 219.3 tok/s.
-    const int waves_cap = cap * g.nwaves;
-    const int k = (groups + waves_cap - 1) / waves_cap;
-    grid = (groups + g.nwaves * k - 1) / (g.nwaves * k);
-  }
-  g.grid = grid < 1 ? 1 : grid;
-  return g;
-}
-
-#ifdef L2_STAMPS
-static int g_stamp_slot = 0;   // each launch of the enqueue gets its own 36-stamp slot
-extern "C" int l2_debug_stamps(l2_ctx* c, unsigned long long* out, size_t n) {
-  hipStreamSynchronize(c->stream);
-  return hipMemcpy(out, c->dbg, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
-}
-#endif
-
-
-// LDS a launch may ask for: 160 KiB per CU on gfx950, opted into per kernel (the default cap is 64 KiB).
-template <class K>
-static hipError_t lds_opt_in(K kernel, size_t lds) {
-  if (lds <= 64 * 1024) return hipSuccess;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
-// Launch with optional start / stop events on THE DISPATCH (hipExtLaunchKernelGGL): their elapsed time is the kernel's
-// own execution time, as a kernel trace reports it -- no launch boundary, no event-record latency (the in-situ probe).
-template <class K, class A>
-static void launch_probed(const l2_ctx* c, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const A& a, bool probe) {
-  l2_ctx* m = const_cast<l2_ctx*>(c);
-  if (probe && m->probe_on && m->probe_used + 2 <= m->probe.size()) {
-    hipEvent_t e0 = m->probe[m->probe_used], e1 = m->probe[m->probe_used + 1];
-    m->probe_used += 2;
-    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0, e1, 0, a);
-  } else {
-    hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
-  }
-}
-
-// Latency form (kernels.hip.h: phase_small_kernel) for matrices of at most `small_max` floats whose input vector fits
-// 8 float4 per lane; everything else (Llama-2-7B's phases, every classifier) streams through phase_kernel.
-static bool use_small(const l2_ctx* c, int mode, int rows, int n) {
-  if (n % 4 || n > 2048 || mode == MODE_CLS) return false;
-  const long long elems = (long long)rows * n * (mode == MODE_W13 ? 2 : 1);
-  return elems <= (long long)c->small_max;
-}
-
-template <int MODE, int XV>
-static hipError_t launch_small_xv(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
-  constexpr bool pair = (MODE == MODE_QKV || MODE == MODE_W13);       // row pairs: RoPE neighbours / (w1, w3)
-  const size_t lds = (size_t)XV * 64 * 16;
-  const int waves = c->n_cus * 7;     // seven compute waves per workgroup (kernels.hip.h)
-  // one row per wave while that still leaves waves idle, else two
-  const bool r1 = !pair && a.rows <= waves;
-  const int rpg = (MODE == MODE_W13) ? 1 : (r1 ? 1 : 2);
-  const int groups = (a.rows + rpg - 1) / rpg;
-  int grid = (groups + 6) / 7;
-  if (grid > c->n_cus) grid = c->n_cus;
-  if (grid < 1) grid = 1;
-  if (!pair && r1) launch_probed(c, phase_small_kernel<MODE, XV, pair ? 2 : 1>, dim3(grid), dim3(512), lds, st, a, MODE == MODE_W13);
-  else launch_probed(c, phase_small_kernel<MODE, XV, 2>, dim3(grid), dim3(512), lds, st, a, MODE == MODE_W13);
-  return hipGetLastError();
-}
-
-template <int MODE>
-static hipError_t launch_small(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
-  const int xv = (a.n / 4 + 63) / 64;
-  switch (xv) {
-    case 1: return launch_small_xv<MODE, 1>(c, a, st);
-    case 2: return launch_small_xv<MODE, 2>(c, a, st);
-    case 3: return launch_small_xv<MODE, 3>(c, a, st);
-    case 4: return launch_small_xv<MODE, 4>(c, a, st);
-    case 5: case 6: return launch_small_xv<MODE, 6>(c, a, st);
-    default: return launch_small_xv<MODE, 8>(c, a, st);
-  }
-}
-
-template <int MODE>
-static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream_t st) {
-  PhaseArgs a = a_in;
-  a.rot = c->tune_rot;
-#ifdef L2_STAMPS
-  a.dbg_wg = c->dbg + 66 * 108 + (size_t)(g_stamp_slot % 64) * 2048;
-  a.dbg = c->dbg + (size_t)(g_stamp_slot++ % 64) * 108;
-#endif
-  if (use_small(c, MODE, a.rows, a.n)) return launch_small<MODE>(c, a, st);
-  const Geo g = pick_geo(c, MODE, a.rows, a.n, a.dim);
-  const dim3 grid(g.grid), block(64 * g.nwaves);
-  if (!g.vec) {
-    const size_t lds = (((size_t)a.n * 4 + 15) & ~(size_t)15) + 64;
-    hipError_t e = lds_opt_in(&phase_kernel_scalar<MODE>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((phase_kernel_scalar<MODE>), grid, block, lds, st, a);
-    return hipGetLastError();
-  }
-  const int n4 = a.n / 4, cpi = 64 * g.U;
-  const int npad4 = ((n4 + cpi - 1) / cpi) * cpi;
-  const bool norm = (MODE == MODE_QKV || MODE == MODE_W13 || MODE == MODE_CLS);
-  const int round4 = g.pre * 64 * g.nwaves;                   // PRE * nthreads (kernels.hip.h)
-  const int nstage4 = ((npad4 + round4 - 1) / round4) * round4;
-  const size_t lds = (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
-#define L2_LAUNCH(UU, PP) do { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \
-                               launch_probed(c, phase_kernel<MODE, 2, UU, PP>, grid, block, lds, st, a, MODE == MODE_W13); } while (0)
-#define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else if (g.pre == 4) L2_LAUNCH(UU, 4); else L2_LAUNCH(UU, 12); } while (0)
-  if (g.U == 3) { if constexpr (MODE == MODE_CLS) { L2_LAUNCH_U(3); } }
-  else if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
-#undef L2_LAUNCH_U
-#undef L2_LAUNCH
-  return hipGetLastError();
-}
-
-static bool attn_vec(const l2_ctx* c) { return (c->hs % 4 == 0) && (c->d_loc % 4 == 0) && (c->kvd_loc % 4 == 0) && c->hs <= 256; }
-
-static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
-  const size_t loff = (size_t)l * c->S * c->kvd_loc;
-  memset(&a, 0, sizeof(a));
-  a.q = c->q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.att = c->opt_keep_state ? c->att : nullptr; a.xb = c->xb;
-  a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter;
-  a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
-  a.kv_dim = c->kvd_loc; a.kv_mul = c->H / c->KVH;
-  a.exact = c->opt_exact;
-  a.inv_sqrt_hs = 1.0 / sqrt((double)c->hs);
-#ifdef L2_STAMPS
-  a.dbg = c->dbg + 64 * 108;   // attention stamps live behind the phase-kernel slots (last launch wins)
-#endif
-}
-
-// Lanes per cache row: head_size / 4 rounded up to a power of two (attention.hip.h); waves per workgroup: 8 from
-// 128-wide heads (a round is then 256 rows), else 4.
-static int attn_lr(int hs) { int l = 4; while (l * 4 < hs) l <<= 1; return l; }
-static int attn_nw(const l2_ctx* c) { return (c->attn_nw == 4 || c->attn_nw == 8) ? c->attn_nw : (c->hs > 64 ? 8 : 4); }
-
-// One launch of the tile kernel; ny = splits (decode) or queries of the chunk (prefill, pos0 >= 0).
-static hipError_t launch_attn_tile(const l2_ctx* c, const AttnArgs& a, int ny, int pos0, hipStream_t st) {
-  const int lr = attn_lr(c->hs), nw = attn_nw(c);
-  const size_t lds = attn_tile_lds(c->S, pos0 >= 0 ? 1 : a.nsplit, nw, nw == 8 ? 8 : 16);
-  const dim3 grid(c->H_loc, ny), block(64 * nw);
-  // 4 waves x 16 tiles (one wave per SIMD, ~290 registers) or 8 waves x 8 tiles (two per SIMD, <= 256 registers)
-#define L2_AT(LR, NW, NT) do { if (pos0 >= 0) { hipError_t e_ = lds_opt_in(&pf_attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
-                                            hipLaunchKernelGGL((pf_attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a, pos0); } \
-                           else { hipError_t e_ = lds_opt_in(&attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
-                                  hipLaunchKernelGGL((attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a); } } while (0)
-#define L2_AT_NW(LR) do { if (nw == 8) L2_AT(LR, 8, 8); else L2_AT(LR, 4, 16); } while (0)
-  switch (lr) {
-    case 4: L2_AT_NW(4); break;
-    case 8: L2_AT_NW(8); break;
-    case 16: L2_AT_NW(16); break;
-    case 32: L2_AT_NW(32); break;
-    default: L2_AT_NW(64); break;
-  }
-#undef L2_AT_NW
-#undef L2_AT
-  return hipGetLastError();
-}
-
-static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // attention (llama2.ts:244-267)
-  AttnArgs a;
-  fill_attn_args(c, l, a);
-  if (!attn_vec(c)) {
-    const size_t lds = (size_t)((c->S + 3) & ~3) * 4 + 64;
-    hipError_t e = lds_opt_in(&attn_scalar_kernel, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_scalar_kernel, dim3(c->H_loc, 1), dim3(256), lds, st, a, 0);
-    return hipGetLastError();
-  }
-  if (c->opt_exact) a.nsplit = 1;
-  return launch_attn_tile(c, a, a.nsplit, -1, st);
-}
-
-// ---- One-shot peer-to-peer exchange over xGMI -------------------------------------------------
-// The two all-reduces of a layer move d fp64 partials (32 KB at 7B) and the logits gather V/G floats per rank:
-// latency-bound messages, for which a ring or tree collective pays several launches and hops.  Here every rank
-// WRITES its contribution straight into a slot of every peer's inbox (peer-mapped, uncached memory), raises one
-// flag per (peer, block), waits for the G flags of its own inbox and sums the G slots IN RANK ORDER -- every rank
-// adds the same numbers in the same order, so x stays bit-identical across ranks and is rounded to fp32 once
-// (llama2.ts:201), exactly as the RCCL path and the oracle's orc_forward_tp do.  One kernel = exchange + residual;
-// nothing but kernels, so the whole tensor-parallel step is captured in one hipGraph.
-//   * epochs: a device counter per rank counts exchanges (all ranks run the same sequence); a flag holds the epoch
-//     of the exchange that last wrote its slot; slots alternate by epoch parity -- a rank cannot start exchange
-//     e + 2 before every peer has finished reading exchange e, because e + 1 needs their contribution first;
-//   * block b of every rank handles the same elements, so it only waits for block b of its peers;
-//   * release: stores, __threadfence_system(), barrier, then the flags (system-scope atomic stores); acquire:
-//     system-scope atomic polls (bounded: a rank that never arrives sets `err` instead of hanging the GPU), barrier,
-//     system fence, plain loads of the uncached inbox.
-
-__device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) { return *a.epoch + 1; }
-
-// flags of this block up on every peer ...
-__device__ __forceinline__ void p2p_raise(const P2PArgs& a, unsigned long long e, int tid) {
-  const int par = (int)(e & 1), b = blockIdx.x;
-  __threadfence_system();
-  __syncthreads();
-  if (tid < a.G) __hip_atomic_store(a.pr.flags[tid] + ((size_t)(par * P2P_MAXG + a.rank) * P2P_FB + b), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// ... then wait for every source's flag in the local inbox
-__device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e, int tid) {
-  const int par = (int)(e & 1), b = blockIdx.x;
-  if (tid < a.G) {
-    const unsigned long long* mine = a.pr.flags[a.rank] + ((size_t)(par * P2P_MAXG + tid) * P2P_FB + b);
-    unsigned spins = 0;
-    unsigned long long t0 = 0;
-    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-      __builtin_amdgcn_s_sleep(2);
-      // bounded by WALL time on the constant 100 MHz clock (a.wait_ticks, default 30 s, L2_TP_WAIT_S): ordinary rank skew
-      // -- a peer still capturing its graph, a slower checkpoint read -- must not trip it; a rank that died must.
-      // The host then marks the context broken (check_p2p): epochs and flags no longer match the peers'.
-      if ((++spins & 255u) == 0) {
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        if (!t0) t0 = now;
-        else if (now - t0 > a.wait_ticks) { *a.err = 1; break; }
-      }
-    }
-  }
-  __syncthreads();
-  __threadfence_system();
-}
-
-__device__ __forceinline__ void p2p_end(const P2PArgs& a, unsigned long long e, int tid) {
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) { __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *a.epoch = e; }
-  }
-}
-
-// PART 0: the whole exchange in one kernel (product path).  PART 1 / 2: its two halves -- contribute, then wait + combine
-// -- as separate launches with a host barrier in between: the loopback test group runs all ranks on ONE GPU, where
-// G kernels that wait for each other are not guaranteed to be resident together (they deadlock until the bounded
-// wait gives up when two ranks' streams share a hardware queue); on a node every rank has its own GPU.
-// all-reduce(sum) of the d fp64 partials + ONE fp32 rounding + residual accumulate (llama2.ts:201, 168-170)
-template <int PART>
-__global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, const double* partial, float* x, const float* res_emb,
-                                                            float* mv_out, const int* tokpos) {
-  const int tid = threadIdx.x, stride = gridDim.x * 256;
-  const unsigned long long e = p2p_begin(a);
-  const size_t slot = (size_t)((int)(e & 1) * P2P_MAXG) * a.n;
-  if (PART != 2) {
-    for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
-      const double v = partial[i];
-      for (int p = 0; p < a.G; ++p) a.pr.inbox[p][slot + (size_t)a.rank * a.n + i] = v;
-    }
-  }
-  if (PART == 1) { p2p_raise(a, e, tid); return; }
-  if (PART == 0) p2p_raise(a, e, tid);
-  p2p_wait(a, e, tid);
-  for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
-    const double* in = a.pr.inbox[a.rank] + slot + i;
-    double s = in[0];
-    for (int r = 1; r < a.G; ++r) s += in[(size_t)r * a.n];      // rank order on every rank
-    const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : x[i];
-    const float mv = (float)s;
-    x[i] = xr + mv;
-    if (mv_out) mv_out[i] = mv;
-  }
-  p2p_end(a, e, tid);
-}
-
-// all-gather of the logits slices: every rank writes its V/G floats into every peer's (uncached) logits vector
-template <int PART>
-__global__ void __launch_bounds__(256) tp_p2p_gather_kernel(const P2PArgs a, const float* mine) {
-  const int tid = threadIdx.x, stride = gridDim.x * 256;
-  const unsigned long long e = p2p_begin(a);
-  if (PART != 2) {
-    for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
-      const float v = mine[i];
-      for (int p = 0; p < a.G; ++p) a.pr.logits[p][(size_t)a.rank * a.n + i] = v;
-    }
-  }
-  if (PART == 1) { p2p_raise(a, e, tid); return; }
-  if (PART == 0) p2p_raise(a, e, tid);
-  p2p_wait(a, e, tid);
-  p2p_end(a, e, tid);
-}
-
-__global__ void tp_residual_kernel(float* x, const float* res_emb, const double* sum, float* mv_out, const int* tokpos, int d) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d) return;
-  const float xr = res_emb ? res_emb[(size_t)tokpos[0] * d + i] : x[i];
-  const float mv = (float)sum[i];   // ONE rounding of the all-reduced fp64 sum (llama2.ts:201)
-  x[i] = xr + mv;                   // accum, llama2.ts:168-170
-  if (mv_out) mv_out[i] = mv;
-}
-
-// ---- peer-to-peer exchange: setup -----------------------------------------------------------------------------
-static size_t p2p_bytes(const l2_ctx* c) { return (size_t)2 * P2P_MAXG * P2P_FB * 8 + (size_t)2 * P2P_MAXG * c->d * 8; }
-static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits) {
-  c->p2p_peers.flags[r] = (unsigned long long*)base;
-  c->p2p_peers.inbox[r] = (double*)((char*)base + (size_t)2 * P2P_MAXG * P2P_FB * 8);
-  c->p2p_peers.logits[r] = logits;
-}
-static P2PArgs p2p_args(const l2_ctx* c, int n) {
-  P2PArgs a;
-  a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = (unsigned*)(c->p2p_epoch + 1); a.err = c->p2p_err_dev;
-  a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks;
-  return a;
-}
-static int p2p_grid(int n) { const int b = (n + 255) / 256; return b > P2P_FB ? P2P_FB : (b < 1 ? 1 : b); }
-
-// Own buffers (every tensor-parallel context): inbox + flags and the gathered-logits vector are UNCACHED device
-// memory, because peers write them while this GPU's L2 knows nothing about it.
-static int p2p_alloc(l2_ctx* c) {
-  if (c->G > P2P_MAXG) return L2_OK;
-  const char* mode = getenv("L2_TP_ALLREDUCE");
-  if (mode && !strcmp(mode, "rccl")) return L2_OK;
-  if (hipExtMallocWithFlags(&c->p2p_base, p2p_bytes(c), hipDeviceMallocUncached) != hipSuccess) { c->p2p_base = nullptr; (void)hipGetLastError(); return L2_OK; }
-  HIPCHK(hipMemset(c->p2p_base, 0, p2p_bytes(c)));
-  HIPCHK(hipMalloc(&c->p2p_epoch, 16));
-  HIPCHK(hipMemset(c->p2p_epoch, 0, 16));
-  HIPCHK(hipHostMalloc(&c->p2p_err, sizeof(int), hipHostMallocMapped));
-  *c->p2p_err = 0;
-  HIPCHK(hipHostGetDevicePointer((void**)&c->p2p_err_dev, c->p2p_err, 0));
-  return L2_OK;
-}
-
-// Multi-process group: IPC handles of every rank's buffers travel through one RCCL all-gather; then ONE exchange on
-// a known vector is checked against the closed form, and the ranks agree (all-reduce of a flag) whether the
-// peer-to-peer path is used -- any rank that cannot map or complete it sends everybody back to the RCCL collectives.
-enum { NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_MIN = 3 };
-__global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n, int k) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { partial[i] = (double)((rank + 1) * (k + 1)) + 0.5 * (double)i; x[i] = 0.0f; }
-}
-// Test hook (L2_TP_IPC_DIR=<directory>): the ranks are separate PROCESSES that meet through files instead of an RCCL
-// communicator, so the IPC mapping, the self-test and the peer-to-peer exchange run between processes on a box with one GPU
-// (RCCL refuses two ranks on one device).  No fallback in this mode: the exchange works or creation fails.
-static bool file_exchange(const char* dir, const char* tag, int rank, int G, const void* mine, void* all, size_t bytes) {
-  char path[512];
-  snprintf(path, sizeof(path), "%s/%s.%d.tmp", dir, tag, rank);
-  FILE* f = fopen(path, "wb");
-  if (!f) return false;
-  const bool wrote = fwrite(mine, 1, bytes, f) == bytes;
-  fclose(f);
-  char final_path[512];
-  snprintf(final_path, sizeof(final_path), "%s/%s.%d", dir, tag, rank);
-  if (!wrote || rename(path, final_path) != 0) return false;
-  for (int r = 0; r < G; ++r) {
-    snprintf(path, sizeof(path), "%s/%s.%d", dir, tag, r);
-    bool got = false;
-    for (int tries = 0; tries < 6000 && !got; ++tries) {            // 60 s
-      f = fopen(path, "rb");
-      if (f) { got = fread((char*)all + (size_t)r * bytes, 1, bytes, f) == bytes; fclose(f); }
-      if (!got) usleep(10000);
-    }
-    if (!got) return false;
-  }
-  return true;
-}
-
-static int p2p_connect_ipc(l2_ctx* c) {
-  if (!c->p2p_base) return c->ipc_dir.empty() ? L2_OK : fail(L2_E_COMM, "L2_TP_IPC_DIR: no peer-to-peer inbox was allocated");
-  const int G = c->G;
-  const char* dir = c->ipc_dir.empty() ? nullptr : c->ipc_dir.c_str();
-  int round = 0;
-  auto all_min = [&](int v, int* out) -> int {                      // every rank learns the minimum of v
-    if (dir) {
-      std::vector<int> vs(G, 0);
-      char tag[32]; snprintf(tag, sizeof(tag), "min%d", round++);
-      if (!file_exchange(dir, tag, c->rank, G, &v, vs.data(), sizeof(int))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive");
-      *out = *std::min_element(vs.begin(), vs.end());
-      return L2_OK;
-    }
-    int* d_v = nullptr;
-    HIPCHK(hipMalloc(&d_v, sizeof(int)));
-    HIPCHK(hipMemcpy(d_v, &v, 4, hipMemcpyHostToDevice));
-    NCCLCHK(g_rccl.AllReduce(d_v, d_v, 1, NCCL_INT32, NCCL_MIN, c->comm, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, d_v, 4, hipMemcpyDeviceToHost));
-    hipFree(d_v);
-    return L2_OK;
-  };
-  struct Rec { hipIpcMemHandle_t base, logits; };
-  static_assert(sizeof(Rec) == 128, "two 64-byte IPC handles");
-  Rec mine;
-  bool ok = hipIpcGetMemHandle(&mine.base, c->p2p_base) == hipSuccess && hipIpcGetMemHandle(&mine.logits, c->logits) == hipSuccess;
-  (void)hipGetLastError();
-  std::vector<Rec> all(G);
-  if (dir) {
-    if (!file_exchange(dir, "handles", c->rank, G, &mine, all.data(), sizeof(Rec))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive");
-  } else {
-    Rec* d_all = nullptr;
-    HIPCHK(hipMalloc(&d_all, sizeof(Rec) * (G + 1)));
-    HIPCHK(hipMemcpy(d_all + G, &mine, sizeof(Rec), hipMemcpyHostToDevice));
-    NCCLCHK(g_rccl.AllGather(d_all + G, d_all, sizeof(Rec), NCCL_UINT8, c->comm, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(all.data(), d_all, sizeof(Rec) * G, hipMemcpyDeviceToHost));
-    hipFree(d_all);
-  }
-  for (int r = 0; r < G && ok; ++r) {
-    if (r == c->rank) { p2p_set_peer(c, r, c->p2p_base, c->logits); continue; }
-    void *pb = nullptr, *pl = nullptr;
-    if (hipIpcOpenMemHandle(&pb, all[r].base, hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
-        hipIpcOpenMemHandle(&pl, all[r].logits, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ok = false; (void)hipGetLastError(); break; }
-    c->p2p_opened.push_back(pb); c->p2p_opened.push_back(pl);
-    p2p_set_peer(c, r, pb, (float*)pl);
-  }
-  // every rank learns whether every rank mapped everything BEFORE anybody waits on a peer
-  int h_ok = ok ? 1 : 0;
-  { const int rc_ = all_min(h_ok, &h_ok); if (rc_) return rc_; }
-  if (h_ok) {   // four exchanges (each inbox slot is reused once) on known vectors: sum over ranks of ((rank + 1)(k + 1) + i / 2)
-    const int n = c->d;
-    std::vector<float> got(n);
-    for (int k = 0; k < 4 && h_ok; ++k) {
-      hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
-      hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
-      HIPCHK(hipStreamSynchronize(c->stream));
-      HIPCHK(hipMemcpy(got.data(), c->xb2, (size_t)n * 4, hipMemcpyDeviceToHost));
-      if (*c->p2p_err) h_ok = 0;
-      for (int i = 0; i < n && h_ok; ++i) if (got[i] != (float)(0.5 * G * (G + 1) * (k + 1) + 0.5 * (double)i * G)) h_ok = 0;
-    }
-    *c->p2p_err = 0;
-    HIPCHK(hipMemset(c->xb2, 0, (size_t)n * 4));
-    { const int rc_ = all_min(h_ok, &h_ok); if (rc_) return rc_; }
-  }
-  c->p2p = h_ok != 0;
-  c->p2p_peers_ready = true;
-  if (!c->p2p && dir) return fail(L2_E_COMM, "L2_TP_IPC_DIR: the peer-to-peer exchange between the processes failed its self-test");
-  if (!c->p2p && getenv("L2_TP_ALLREDUCE") && !strcmp(getenv("L2_TP_ALLREDUCE"), "p2p"))
-    return fail(L2_E_COMM, "L2_TP_ALLREDUCE=p2p but the peer-to-peer exchange could not be set up on every rank");
-  return L2_OK;
-}
-
-#define LCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(L2_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 // Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
 // PhaseArgs of each phase of layer l
@@ -1279,52 +409,6 @@ static PhaseArgs cls_args(const l2_ctx* c, bool to_host) {   // final rmsnorm + 
   return a;
 }
 
-// Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
-// The two collectives of the tensor-parallel step: RCCL, or the loopback test hook.
-static int tp_all_reduce(l2_ctx* c, hipStream_t st) {
-  if (!c->loop) { NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st)); return L2_OK; }
-  LoopGroup& g = *c->loop;
-  HIPCHK(hipStreamSynchronize(st));
-  { std::lock_guard<std::mutex> lk(g.mu); g.ptrs[c->rank] = c->partial; }
-  if (!g.wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");
-  LoopPtrs in;
-  for (int r = 0; r < g.G; ++r) in.p[r] = (const double*)g.ptrs[r];
-  hipLaunchKernelGGL(loop_sum_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->loop_tmp, in, g.G, c->d);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
-  if (!g.wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");   // every rank has read every partial
-  HIPCHK(hipMemcpyAsync(c->partial, c->loop_tmp, (size_t)c->d * 8, hipMemcpyDeviceToDevice, st));
-  return L2_OK;
-}
-static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
-  if (!c->loop) { NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st)); return L2_OK; }
-  LoopGroup& g = *c->loop;
-  HIPCHK(hipStreamSynchronize(st));
-  { std::lock_guard<std::mutex> lk(g.mu); g.ptrs[c->rank] = c->logits_loc; }
-  if (!g.wait()) return fail(L2_E_COMM, "loopback all-gather: a rank never arrived");
-  for (int r = 0; r < g.G; ++r)
-    HIPCHK(hipMemcpyAsync(c->logits + (size_t)r * c->V_loc, g.ptrs[r], (size_t)c->V_loc * 4, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (!g.wait()) return fail(L2_E_COMM, "loopback all-gather: a rank never arrived");
-  return L2_OK;
-}
-
-// one all-reduce + residual of the tensor-parallel step: ONE kernel; the loopback test group (all ranks on one GPU)
-// runs its two halves around a host barrier instead (see tp_p2p_reduce_kernel)
-static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out) {
-  const dim3 grid(p2p_grid(c->d));
-  if (!c->loop) {
-    hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
-  } else {
-    hipLaunchKernelGGL(tp_p2p_reduce_kernel<1>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
-    HIPCHK(hipStreamSynchronize(st));
-    if (!c->loop->wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");
-    hipLaunchKernelGGL(tp_p2p_reduce_kernel<2>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
-  }
-  LCHK(hipGetLastError());
-  return L2_OK;
-}
-
 static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fold_argmax = false) {
   for (int l = 0; l < c->L; ++l) {
     PhaseArgs a = qkv_args(c, l);
@@ -1372,8 +456,6 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
 
 static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
 
-static int p2p_first_sync(l2_ctx* c);
-
 static int ensure_ready(l2_ctx* c) {
   if (c->broken) return fail(L2_E_COMM, "tensor-parallel context is unusable: an earlier peer-to-peer exchange timed out");
   if (c->tp_path && !c->comm && !c->loop && !(c->p2p && !c->ipc_dir.empty())) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
@@ -1391,34 +473,6 @@ static int ensure_ready(l2_ctx* c) {
       if (!c->uploaded[k][l]) return fail(L2_E_STATE, "tensor kind %d layer %zu was never uploaded", k, l);
   }
   if (c->p2p && !c->p2p_synced) { const int rc_ = p2p_first_sync(c); if (rc_) return rc_; }
-  return L2_OK;
-}
-
-// The ranks meet once on the HOST right before their first peer-to-peer step: whatever happened between creation and now
-// (per-rank checkpoint I/O, synthetic fill) is skew the in-kernel flag wait should not have to absorb.
-static int p2p_first_sync(l2_ctx* c) {
-  if (c->loop) { if (!c->loop->wait()) return fail(L2_E_COMM, "loopback group: a rank never arrived"); }
-  else if (!c->ipc_dir.empty()) {
-    int mine = 1; std::vector<int> all(c->G, 0);
-    if (!file_exchange(c->ipc_dir.c_str(), "first", c->rank, c->G, &mine, all.data(), sizeof(int))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive for the first step");
-  } else if (c->comm) {
-    int* d_v = nullptr;
-    HIPCHK(hipMalloc(&d_v, sizeof(int)));
-    HIPCHK(hipMemsetAsync(d_v, 0, sizeof(int), c->stream));
-    NCCLCHK(g_rccl.AllReduce(d_v, d_v, 1, NCCL_INT32, NCCL_SUM, c->comm, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(d_v);
-  }
-  c->p2p_synced = true;
-  return L2_OK;
-}
-
-static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer wait give up?
-  if (c->p2p_err && *c->p2p_err) {
-    *c->p2p_err = 0;
-    c->broken = true;   // the device-side epoch / flag state is out of step with the peers for good: fail fast from now on
-    return fail(L2_E_COMM, "peer-to-peer exchange: a rank never raised its flag (wait of %.0f s gave up); the context is unusable", (double)c->p2p_wait_ticks / 1e8);
-  }
   return L2_OK;
 }
 
@@ -1486,155 +540,7 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
 
 extern "C" float* l2_logits_host(l2_ctx* c) { return c ? c->h_logits : nullptr; }
 
-// ---- prefill -----------------------------------------------------------------
-static bool can_prefill(const l2_ctx* c) {
-  return !c->tp_path && c->kvd == c->d && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
-}
-
-// One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1, 2 or 4).  QKV / WO / W2 take their weights through an LDS
-// tile by default (L2_PF_LDS: 0 never, 1 default, 2 W13 too -- its two tiles per wave measured slower).
-// register-blocked form (prefill.hip.h: pf_gemm3_kernel): RT row tiles per wave, 4 waves split K, `chunks` 64-token chunks per launch
-template <int MODE, int RT>
-static void launch_pf3(const PfArgs& a, int chunks, hipStream_t st) {
-  constexpr int NW = 4;
-  const size_t lds = (size_t)4 * NW * 4 * 64 * 8;
-  hipLaunchKernelGGL((pf_gemm3_kernel<MODE, NW, RT, 4>), dim3(a.rows / (16 * RT), chunks), dim3(64 * NW), lds, st, a);
-}
-
-// Shapes the register-blocked GEMMs cover: whole 64-column batches (n % 64) of both input widths and qkv's 3 d / 16 row tiles in threes.
-static bool pf3_ok(const l2_ctx* c) { return c->pf3 && c->d % 64 == 0 && c->h % 64 == 0 && (3 * c->d / 16) % 3 == 0; }
-
-template <int MODE>
-static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int chunks, hipStream_t st) {
-  if (pf3_ok(c) && tt == 4) {
-    // row tiles per wave: conversions per MFMA are 16 (R + 64) / (64 R) for R rows per workgroup, so as many as still leave >= 256
-    // workgroups: qkv 3 (3 d / 16 tiles), w1 / w3 one pair (688 pairs at 7B), wo / w2 (d / 16 tiles) 1, 2 or 4 with the chunk count
-    if constexpr (MODE == MODE_QKV) { launch_pf3<MODE, 3>(a, chunks, st); return; }
-    else if constexpr (MODE == MODE_W13) { launch_pf3<MODE, 1>(a, chunks, st); return; }
-    else {
-      const int tiles = a.rows / 16;
-      if (chunks == 4 && tiles % 4 == 0) launch_pf3<MODE, 4>(a, chunks, st);
-      else if (chunks == 2 && tiles % 2 == 0) launch_pf3<MODE, 2>(a, chunks, st);
-      else launch_pf3<MODE, 1>(a, chunks, st);
-      return;
-    }
-  }
-  const dim3 grid(a.rows / 16);
-  // four token tiles: the LDS form's 8-block register sets (32 activation fragments) leave one spilled wave per SIMD: 3200 vs 3490 tok/s
-  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && (tt < 4 || c->pf_lds >= 3)) {
-    const size_t tiles = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
-    const size_t parts = (size_t)4 * 2 * 3 * 4 * 64 * 8;
-    const size_t lds = tiles > parts ? tiles : parts;
-    static bool attr = false;
-    if (!attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
-    if (tt == 4) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 4>), grid, dim3(256), lds, st, a);
-    else if (tt == 2) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 2>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 1>), grid, dim3(256), lds, st, a);
-    return;
-  }
-#define L2_PFG(NW) do { if (tt == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 4>), grid, dim3(64 * NW), 0, st, a); \
-                        else if (tt == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 2>), grid, dim3(64 * NW), 0, st, a); \
-                        else hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 1>), grid, dim3(64 * NW), 0, st, a); } while (0)
-  if (nw <= 4) L2_PFG(4); else L2_PFG(8);
-#undef L2_PFG
-}
-
-// One launch sequence for up to PF_S chunks of PF_T prompt positions (n tokens at pos0 ...): every GEMM sees all of them.
-static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
-  hipStream_t st = c->stream;
-  const size_t d = c->d, h = c->h;
-  constexpr size_t ROWS = (size_t)PF_S * PF_T;
-  if (!c->pf_x) {
-    HIPCHK(hipMalloc(&c->pf_x, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_xn, ROWS * (d > h ? d : h) * 4));
-    HIPCHK(hipMalloc(&c->pf_q, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_xb, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_hb, ROWS * h * 4));
-    HIPCHK(hipMalloc(&c->pf_tok, ROWS * sizeof(int)));
-    HIPCHK(hipMemset(c->pf_xb, 0, ROWS * d * 4)); HIPCHK(hipMemset(c->pf_q, 0, ROWS * d * 4));
-  }
-  const int chunks = (n + PF_T - 1) / PF_T;                              // > 1 only on the register-blocked path (l2_prefill)
-  const int tt = (n > 32) ? 4 : (n > 16) ? 2 : 1, nt = (chunks > 1) ? chunks * PF_T : 16 * tt;   // token rows the kernels see (whole 16-token MFMA tiles)
-  int32_t tk[ROWS] = {0};
-  for (int i = 0; i < n; ++i) tk[i] = tokens[i];
-  HIPCHK(hipMemcpyAsync(c->pf_tok, tk, sizeof(tk), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));   // tk is on the stack
-  hipLaunchKernelGGL(pf_embed_kernel, dim3(nt), dim3(256), 0, st, c->pf_x, c->w[L2_T_TOKEN_EMBEDDING], c->pf_tok, c->d, n);
-  LCHK(hipGetLastError());
-  for (int l = 0; l < c->L; ++l) {
-    const size_t loff = (size_t)l * c->S * c->d;
-    PfArgs a;
-    memset(&a, 0, sizeof(a));
-    a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG]; a.head_size = c->hs; a.dim = c->d; a.pos0 = pos0; a.nvalid = n;
-    a.x = c->pf_x;
-    // rmsnorm + q,k,v + RoPE + cache rows (llama2.ts:216-240)
-    hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_ATT] + d * l, c->d);
-    a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
-    a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
-    a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
-    launch_pf_gemm<MODE_QKV>(c, a, c->pf_nw[0], tt, chunks, st);
-    LCHK(hipGetLastError());
-    // attention, one workgroup per (head, query) (llama2.ts:244-267)
-    {
-      AttnArgs aa;
-      c->cur_splits = 1;
-      fill_attn_args(c, l, aa);
-      aa.q = c->pf_q; aa.xb = c->pf_xb; aa.att = nullptr; aa.pos_plus1 = 1;
-      LCHK(launch_attn_tile(c, aa, n, pos0, st));
-    }
-    // wo + residual (llama2.ts:270-273)
-    a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
-    launch_pf_gemm<MODE_WO>(c, a, c->pf_nw[1], tt, chunks, st);
-    // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
-    hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
-    a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
-    a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
-    launch_pf_gemm<MODE_W13>(c, a, c->pf_nw[2], tt, chunks, st);
-    // w2 + residual (llama2.ts:292-295)
-    a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
-    launch_pf_gemm<MODE_W2>(c, a, c->pf_nw[3], tt, chunks, st);
-    LCHK(hipGetLastError());
-  }
-  return L2_OK;
-}
-
-extern "C" int l2_prefill(l2_ctx* c, const int32_t* tokens, int n_tokens, int pos0, float* logits_out) {
-  if (!c || !tokens) return fail(L2_E_ARG, "null argument");
-  if (n_tokens <= 0 || pos0 < 0 || pos0 + n_tokens > c->S) return fail(L2_E_ARG, "positions %d..%d outside [0, seq_len=%d)", pos0, pos0 + n_tokens - 1, c->S);
-  for (int i = 0; i < n_tokens; ++i) if (tokens[i] < 0 || tokens[i] >= c->V) return fail(L2_E_ARG, "token %d outside [0, vocab_size=%d)", tokens[i], c->V);
-  int rc = ensure_ready(c);
-  if (rc) return rc;
-  if (!can_prefill(c)) {   // shapes the 16x16 tiles do not cover: the reference's own one-token-per-call loop
-    for (int i = 0; i < n_tokens; ++i) { rc = l2_forward(c, tokens[i], pos0 + i, (i == n_tokens - 1) ? logits_out : nullptr); if (rc) return rc; }
-    return L2_OK;
-  }
-  HIPCHK(hipSetDevice(c->device));
-  const int step = pf3_ok(c) ? PF_S * PF_T : PF_T;      // positions per launch sequence: several 64-token chunks where the register-blocked GEMMs apply
-  int done = 0;
-  while (done < n_tokens) {
-    const int n = (n_tokens - done < step) ? n_tokens - done : step;
-    rc = prefill_chunk(c, tokens + done, n, pos0 + done);
-    if (rc) return rc;
-    done += n;
-  }
-  // logits of the last position only (llama2.ts:299-302): the decode classifier on the last row of the chunk
-  const int last = (n_tokens - 1) % step;
-  c->h_tokpos[0] = tokens[n_tokens - 1]; c->h_tokpos[1] = pos0 + n_tokens - 1; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
-  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  PhaseArgs a = cls_args(c, true);
-  a.in = c->pf_x + (size_t)last * c->d;
-  LCHK(launch_phase<MODE_CLS>(c, a, c->stream));
-  if (!(c->opt_zero_copy && !c->tp_path))
-    HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  c->ran_forward = true;
-  if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
-  return L2_OK;
-}
-
-
+#include "prefill_host.hip.h"
 
 static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool timed, float* ms) {
   if (!c) return fail(L2_E_ARG, "null context");
@@ -1739,38 +645,6 @@ extern "C" int l2_decode_greedy(l2_ctx* c, int first_token, int pos0, int steps,
   return L2_OK;
 }
 
-extern "C" int l2_bench_decode(l2_ctx* c, int first_token, int pos0, int steps, float* total_ms) {
-  if (!total_ms) return fail(L2_E_ARG, "null total_ms");
-  return run_greedy(c, first_token, pos0, steps, true, total_ms);
-}
-
-// The dominant kernel (rmsnorm + w1/w3 GEMV + SwiGLU) timed IN SITU: `steps` greedy decode steps launched eagerly
-// with a HIP event pair around every one of its launches on the library's stream; mean duration in microseconds.
-extern "C" int l2_bench_dominant_in_situ(l2_ctx* c, int first_token, int pos0, int steps, float* avg_us, int* launches) {
-  if (!c || !avg_us) return fail(L2_E_ARG, "null argument");
-  if (steps <= 0 || pos0 < 0 || pos0 + steps > c->S) return fail(L2_E_ARG, "bad step range");
-  HIPCHK(hipSetDevice(c->device));
-  const size_t need = (size_t)2 * c->L * steps;
-  while (c->probe.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->probe.push_back(e); }
-  const int saved_graph = c->opt_graph;
-  c->opt_graph = 0;
-  c->probe_used = 0; c->probe_on = true;
-  int rc = run_greedy(c, first_token, pos0, steps, false, nullptr);
-  c->probe_on = false; c->opt_graph = saved_graph;
-  if (rc) return rc;
-  double total = 0.0;
-  size_t n = 0;
-  for (size_t i = 0; i + 1 < c->probe_used; i += 2) {
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c->probe[i], c->probe[i + 1]));
-    total += ms; ++n;
-  }
-  if (!n) return fail(L2_E_STATE, "no launches were probed");
-  *avg_us = (float)(1e3 * total / (double)n);
-  if (launches) *launches = (int)n;
-  return L2_OK;
-}
-
 extern "C" int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t n_floats) {
   if (!c || !out) return fail(L2_E_ARG, "null argument");
   HIPCHK(hipSetDevice(c->device));
@@ -1833,74 +707,4 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
   }
 }
 
-extern "C" int l2_timer_start(l2_ctx* c) {
-  if (!c) return fail(L2_E_ARG, "null context");
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipEventRecord(c->ev0, c->stream));
-  return L2_OK;
-}
-
-extern "C" int l2_timer_stop(l2_ctx* c, float* ms) {
-  if (!c || !ms) return fail(L2_E_ARG, "null argument");
-  HIPCHK(hipEventRecord(c->ev1, c->stream));
-  HIPCHK(hipEventSynchronize(c->ev1));
-  HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
-  return L2_OK;
-}
-
-// The dominant kernel alone: one weight-streaming GEMV phase, launched `iters` times back to back.
-extern "C" int l2_bench_gemv(l2_ctx* c, int kind, int layer, int iters, float* avg_ms) {
-  if (!c || !avg_ms || iters <= 0) return fail(L2_E_ARG, "bad argument");
-  if (layer < 0 || layer >= c->L) layer = 0;
-  int rc = ensure_ready(c);
-  if (rc) return rc;
-  HIPCHK(hipSetDevice(c->device));
-  // the phases read {token, pos} from device memory: whatever a previous decode left there may be pos == seq_len
-  memset(c->h_tokpos, 0, 4 * sizeof(int));
-  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  PhaseArgs a;
-  memset(&a, 0, sizeof(a));
-  a.tokpos = c->tokpos; a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG]; a.head_size = c->hs; a.dim = c->d;
-  a.inv_n = 1.0 / (double)c->d;
-  const size_t loff = (size_t)layer * c->S * c->kvd_loc;
-  int mode;
-  switch (kind) {
-    case L2_T_WQ: case L2_T_WK: case L2_T_WV:
-      mode = MODE_QKV;
-      a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * layer; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * layer;
-      a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * layer;
-      a.in = c->xn; a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * layer; a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff;
-      a.n = c->d; a.rows = c->d_loc + 2 * c->kvd_loc; a.dim = c->d_loc; a.kv_dim = c->kvd_loc; break;
-    case L2_T_WO:
-      mode = MODE_WO; a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * layer; a.in = c->xb; a.res = c->xn; a.out = c->xb2;
-      a.n = c->d_loc; a.rows = c->d; break;
-    case L2_T_W1: case L2_T_W3:
-      mode = MODE_W13; a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * layer; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * layer;
-      a.in = c->xn; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * layer; a.out = c->hb; a.n = c->d; a.rows = c->h_loc; break;
-    case L2_T_W2:
-      mode = MODE_W2; a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * layer; a.in = c->hb; a.res = c->xn; a.out = c->xb2;
-      a.n = c->h_loc; a.rows = c->d; break;
-    case L2_T_WCLS: case L2_T_TOKEN_EMBEDDING:
-      mode = MODE_CLS; a.w0 = c->w[L2_T_WCLS]; a.in = c->xn; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xb2;
-      a.n = c->d; a.rows = c->V_loc; break;
-    default: return fail(L2_E_ARG, "tensor kind %d is not a GEMV matrix", kind);
-  }
-  for (int it = -2; it < iters; ++it) {
-    if (it == 0) HIPCHK(hipEventRecord(c->ev0, c->stream));
-    hipError_t e;
-    switch (mode) {
-      case MODE_QKV: e = launch_phase<MODE_QKV>(c, a, c->stream); break;
-      case MODE_WO: e = launch_phase<MODE_WO>(c, a, c->stream); break;
-      case MODE_W13: e = launch_phase<MODE_W13>(c, a, c->stream); break;
-      case MODE_W2: e = launch_phase<MODE_W2>(c, a, c->stream); break;
-      default: e = launch_phase<MODE_CLS>(c, a, c->stream); break;
-    }
-    if (e != hipSuccess) return fail(L2_E_HIP, "gemv launch: %s", hipGetErrorString(e));
-  }
-  HIPCHK(hipEventRecord(c->ev1, c->stream));
-  HIPCHK(hipEventSynchronize(c->ev1));
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  *avg_ms = ms / (float)iters;
-  return L2_OK;
-}
+#include "bench_hooks.hip.h"

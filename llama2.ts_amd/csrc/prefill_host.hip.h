@@ -1,0 +1,151 @@
+// prefill_host.hip.h -- host side of batched prompt ingestion: l2_prefill and its launch sequence
+// Part of the one translation unit llama2_hip.hip (included there, in order); not a stand-alone header.
+#pragma once
+
+// ---- prefill -----------------------------------------------------------------
+static bool can_prefill(const l2_ctx* c) {
+  return !c->tp_path && c->kvd == c->d && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
+}
+
+// One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1, 2 or 4).  QKV / WO / W2 take their weights through an LDS
+// tile by default (L2_PF_LDS: 0 never, 1 default, 2 W13 too -- its two tiles per wave measured slower).
+// register-blocked form (prefill.hip.h: pf_gemm3_kernel): RT row tiles per wave, 4 waves split K, `chunks` 64-token chunks per launch
+template <int MODE, int RT>
+static void launch_pf3(const PfArgs& a, int chunks, hipStream_t st) {
+  constexpr int NW = 4;
+  const size_t lds = (size_t)4 * NW * 4 * 64 * 8;
+  hipLaunchKernelGGL((pf_gemm3_kernel<MODE, NW, RT, 4>), dim3(a.rows / (16 * RT), chunks), dim3(64 * NW), lds, st, a);
+}
+
+// Shapes the register-blocked GEMMs cover: whole 64-column batches (n % 64) of both input widths and qkv's 3 d / 16 row tiles in threes.
+static bool pf3_ok(const l2_ctx* c) { return c->pf3 && c->d % 64 == 0 && c->h % 64 == 0 && (3 * c->d / 16) % 3 == 0; }
+
+template <int MODE>
+static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int chunks, hipStream_t st) {
+  if (pf3_ok(c) && tt == 4) {
+    // row tiles per wave: conversions per MFMA are 16 (R + 64) / (64 R) for R rows per workgroup, so as many as still leave >= 256
+    // workgroups: qkv 3 (3 d / 16 tiles), w1 / w3 one pair (688 pairs at 7B), wo / w2 (d / 16 tiles) 1, 2 or 4 with the chunk count
+    if constexpr (MODE == MODE_QKV) { launch_pf3<MODE, 3>(a, chunks, st); return; }
+    else if constexpr (MODE == MODE_W13) { launch_pf3<MODE, 1>(a, chunks, st); return; }
+    else {
+      const int tiles = a.rows / 16;
+      if (chunks == 4 && tiles % 4 == 0) launch_pf3<MODE, 4>(a, chunks, st);
+      else if (chunks == 2 && tiles % 2 == 0) launch_pf3<MODE, 2>(a, chunks, st);
+      else launch_pf3<MODE, 1>(a, chunks, st);
+      return;
+    }
+  }
+  const dim3 grid(a.rows / 16);
+  // four token tiles: the LDS form's 8-block register sets (32 activation fragments) leave one spilled wave per SIMD: 3200 vs 3490 tok/s
+  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && (tt < 4 || c->pf_lds >= 3)) {
+    const size_t tiles = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
+    const size_t parts = (size_t)4 * 2 * 3 * 4 * 64 * 8;
+    const size_t lds = tiles > parts ? tiles : parts;
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    if (tt == 4) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 4>), grid, dim3(256), lds, st, a);
+    else if (tt == 2) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 2>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 1>), grid, dim3(256), lds, st, a);
+    return;
+  }
+#define L2_PFG(NW) do { if (tt == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 4>), grid, dim3(64 * NW), 0, st, a); \
+                        else if (tt == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 2>), grid, dim3(64 * NW), 0, st, a); \
+                        else hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 1>), grid, dim3(64 * NW), 0, st, a); } while (0)
+  if (nw <= 4) L2_PFG(4); else L2_PFG(8);
+#undef L2_PFG
+}
+
+// One launch sequence for up to PF_S chunks of PF_T prompt positions (n tokens at pos0 ...): every GEMM sees all of them.
+static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
+  hipStream_t st = c->stream;
+  const size_t d = c->d, h = c->h;
+  constexpr size_t ROWS = (size_t)PF_S * PF_T;
+  if (!c->pf_x) {
+    HIPCHK(hipMalloc(&c->pf_x, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_xn, ROWS * (d > h ? d : h) * 4));
+    HIPCHK(hipMalloc(&c->pf_q, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_xb, ROWS * d * 4)); HIPCHK(hipMalloc(&c->pf_hb, ROWS * h * 4));
+    HIPCHK(hipMalloc(&c->pf_tok, ROWS * sizeof(int)));
+    HIPCHK(hipMemset(c->pf_xb, 0, ROWS * d * 4)); HIPCHK(hipMemset(c->pf_q, 0, ROWS * d * 4));
+  }
+  const int chunks = (n + PF_T - 1) / PF_T;                              // > 1 only on the register-blocked path (l2_prefill)
+  const int tt = (n > 32) ? 4 : (n > 16) ? 2 : 1, nt = (chunks > 1) ? chunks * PF_T : 16 * tt;   // token rows the kernels see (whole 16-token MFMA tiles)
+  int32_t tk[ROWS] = {0};
+  for (int i = 0; i < n; ++i) tk[i] = tokens[i];
+  HIPCHK(hipMemcpyAsync(c->pf_tok, tk, sizeof(tk), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));   // tk is on the stack
+  hipLaunchKernelGGL(pf_embed_kernel, dim3(nt), dim3(256), 0, st, c->pf_x, c->w[L2_T_TOKEN_EMBEDDING], c->pf_tok, c->d, n);
+  LCHK(hipGetLastError());
+  for (int l = 0; l < c->L; ++l) {
+    const size_t loff = (size_t)l * c->S * c->d;
+    PfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.fr = c->w[L2_T_FREQ_REAL]; a.fi = c->w[L2_T_FREQ_IMAG]; a.head_size = c->hs; a.dim = c->d; a.pos0 = pos0; a.nvalid = n;
+    a.x = c->pf_x;
+    // rmsnorm + q,k,v + RoPE + cache rows (llama2.ts:216-240)
+    hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_ATT] + d * l, c->d);
+    a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
+    a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
+    a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
+    launch_pf_gemm<MODE_QKV>(c, a, c->pf_nw[0], tt, chunks, st);
+    LCHK(hipGetLastError());
+    // attention, one workgroup per (head, query) (llama2.ts:244-267)
+    {
+      AttnArgs aa;
+      c->cur_splits = 1;
+      fill_attn_args(c, l, aa);
+      aa.q = c->pf_q; aa.xb = c->pf_xb; aa.att = nullptr; aa.pos_plus1 = 1;
+      LCHK(launch_attn_tile(c, aa, n, pos0, st));
+    }
+    // wo + residual (llama2.ts:270-273)
+    a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
+    launch_pf_gemm<MODE_WO>(c, a, c->pf_nw[1], tt, chunks, st);
+    // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
+    hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
+    a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
+    a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
+    launch_pf_gemm<MODE_W13>(c, a, c->pf_nw[2], tt, chunks, st);
+    // w2 + residual (llama2.ts:292-295)
+    a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
+    launch_pf_gemm<MODE_W2>(c, a, c->pf_nw[3], tt, chunks, st);
+    LCHK(hipGetLastError());
+  }
+  return L2_OK;
+}
+
+extern "C" int l2_prefill(l2_ctx* c, const int32_t* tokens, int n_tokens, int pos0, float* logits_out) {
+  if (!c || !tokens) return fail(L2_E_ARG, "null argument");
+  if (n_tokens <= 0 || pos0 < 0 || pos0 + n_tokens > c->S) return fail(L2_E_ARG, "positions %d..%d outside [0, seq_len=%d)", pos0, pos0 + n_tokens - 1, c->S);
+  for (int i = 0; i < n_tokens; ++i) if (tokens[i] < 0 || tokens[i] >= c->V) return fail(L2_E_ARG, "token %d outside [0, vocab_size=%d)", tokens[i], c->V);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  if (!can_prefill(c)) {   // shapes the 16x16 tiles do not cover: the reference's own one-token-per-call loop
+    for (int i = 0; i < n_tokens; ++i) { rc = l2_forward(c, tokens[i], pos0 + i, (i == n_tokens - 1) ? logits_out : nullptr); if (rc) return rc; }
+    return L2_OK;
+  }
+  HIPCHK(hipSetDevice(c->device));
+  const int step = pf3_ok(c) ? PF_S * PF_T : PF_T;      // positions per launch sequence: several 64-token chunks where the register-blocked GEMMs apply
+  int done = 0;
+  while (done < n_tokens) {
+    const int n = (n_tokens - done < step) ? n_tokens - done : step;
+    rc = prefill_chunk(c, tokens + done, n, pos0 + done);
+    if (rc) return rc;
+    done += n;
+  }
+  // logits of the last position only (llama2.ts:299-302): the decode classifier on the last row of the chunk
+  const int last = (n_tokens - 1) % step;
+  c->h_tokpos[0] = tokens[n_tokens - 1]; c->h_tokpos[1] = pos0 + n_tokens - 1; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
+  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  PhaseArgs a = cls_args(c, true);
+  a.in = c->pf_x + (size_t)last * c->d;
+  LCHK(launch_phase<MODE_CLS>(c, a, c->stream));
+  if (!(c->opt_zero_copy && !c->tp_path))
+    HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->ran_forward = true;
+  if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
+  return L2_OK;
+}

@@ -1,0 +1,329 @@
+// tp_exchange.hip.h -- the two exchanges of the tensor-parallel step: one-shot peer-to-peer over xGMI, RCCL baseline, one-GPU test groups
+// Part of the one translation unit llama2_hip.hip (included there, in order); not a stand-alone header.
+#pragma once
+
+// ---- One-shot peer-to-peer exchange over xGMI -------------------------------------------------
+// The two all-reduces of a layer move d fp64 partials (32 KB at 7B) and the logits gather V/G floats per rank:
+// latency-bound messages, for which a ring or tree collective pays several launches and hops.  Here every rank
+// WRITES its contribution straight into a slot of every peer's inbox (peer-mapped, uncached memory), raises one
+// flag per (peer, block), waits for the G flags of its own inbox and sums the G slots IN RANK ORDER -- every rank
+// adds the same numbers in the same order, so x stays bit-identical across ranks and is rounded to fp32 once
+// (llama2.ts:201), exactly as the RCCL path and the oracle's orc_forward_tp do.  One kernel = exchange + residual;
+// nothing but kernels, so the whole tensor-parallel step is captured in one hipGraph.
+//   * epochs: a device counter per rank counts exchanges (all ranks run the same sequence); a flag holds the epoch
+//     of the exchange that last wrote its slot; slots alternate by epoch parity -- a rank cannot start exchange
+//     e + 2 before every peer has finished reading exchange e, because e + 1 needs their contribution first;
+//   * block b of every rank handles the same elements, so it only waits for block b of its peers;
+//   * release: stores, __threadfence_system(), barrier, then the flags (system-scope atomic stores); acquire:
+//     system-scope atomic polls (bounded: a rank that never arrives sets `err` instead of hanging the GPU), barrier,
+//     system fence, plain loads of the uncached inbox.
+
+__device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) { return *a.epoch + 1; }
+
+// flags of this block up on every peer ...
+__device__ __forceinline__ void p2p_raise(const P2PArgs& a, unsigned long long e, int tid) {
+  const int par = (int)(e & 1), b = blockIdx.x;
+  __threadfence_system();
+  __syncthreads();
+  if (tid < a.G) __hip_atomic_store(a.pr.flags[tid] + ((size_t)(par * P2P_MAXG + a.rank) * P2P_FB + b), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... then wait for every source's flag in the local inbox
+__device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e, int tid) {
+  const int par = (int)(e & 1), b = blockIdx.x;
+  if (tid < a.G) {
+    const unsigned long long* mine = a.pr.flags[a.rank] + ((size_t)(par * P2P_MAXG + tid) * P2P_FB + b);
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+      __builtin_amdgcn_s_sleep(2);
+      // bounded by WALL time on the constant 100 MHz clock (a.wait_ticks, default 30 s, L2_TP_WAIT_S): ordinary rank skew
+      // -- a peer still capturing its graph, a slower checkpoint read -- must not trip it; a rank that died must.
+      // The host then marks the context broken (check_p2p): epochs and flags no longer match the peers'.
+      if ((++spins & 255u) == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (!t0) t0 = now;
+        else if (now - t0 > a.wait_ticks) { *a.err = 1; break; }
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+}
+
+__device__ __forceinline__ void p2p_end(const P2PArgs& a, unsigned long long e, int tid) {
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) { __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *a.epoch = e; }
+  }
+}
+
+// PART 0: the whole exchange in one kernel (product path).  PART 1 / 2: its two halves -- contribute, then wait + combine
+// -- as separate launches with a host barrier in between: the loopback test group runs all ranks on ONE GPU, where
+// G kernels that wait for each other are not guaranteed to be resident together (they deadlock until the bounded
+// wait gives up when two ranks' streams share a hardware queue); on a node every rank has its own GPU.
+// all-reduce(sum) of the d fp64 partials + ONE fp32 rounding + residual accumulate (llama2.ts:201, 168-170)
+template <int PART>
+__global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, const double* partial, float* x, const float* res_emb,
+                                                            float* mv_out, const int* tokpos) {
+  const int tid = threadIdx.x, stride = gridDim.x * 256;
+  const unsigned long long e = p2p_begin(a);
+  const size_t slot = (size_t)((int)(e & 1) * P2P_MAXG) * a.n;
+  if (PART != 2) {
+    for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+      const double v = partial[i];
+      for (int p = 0; p < a.G; ++p) a.pr.inbox[p][slot + (size_t)a.rank * a.n + i] = v;
+    }
+  }
+  if (PART == 1) { p2p_raise(a, e, tid); return; }
+  if (PART == 0) p2p_raise(a, e, tid);
+  p2p_wait(a, e, tid);
+  for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+    const double* in = a.pr.inbox[a.rank] + slot + i;
+    double s = in[0];
+    for (int r = 1; r < a.G; ++r) s += in[(size_t)r * a.n];      // rank order on every rank
+    const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : x[i];
+    const float mv = (float)s;
+    x[i] = xr + mv;
+    if (mv_out) mv_out[i] = mv;
+  }
+  p2p_end(a, e, tid);
+}
+
+// all-gather of the logits slices: every rank writes its V/G floats into every peer's (uncached) logits vector
+template <int PART>
+__global__ void __launch_bounds__(256) tp_p2p_gather_kernel(const P2PArgs a, const float* mine) {
+  const int tid = threadIdx.x, stride = gridDim.x * 256;
+  const unsigned long long e = p2p_begin(a);
+  if (PART != 2) {
+    for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+      const float v = mine[i];
+      for (int p = 0; p < a.G; ++p) a.pr.logits[p][(size_t)a.rank * a.n + i] = v;
+    }
+  }
+  if (PART == 1) { p2p_raise(a, e, tid); return; }
+  if (PART == 0) p2p_raise(a, e, tid);
+  p2p_wait(a, e, tid);
+  p2p_end(a, e, tid);
+}
+
+__global__ void tp_residual_kernel(float* x, const float* res_emb, const double* sum, float* mv_out, const int* tokpos, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  const float xr = res_emb ? res_emb[(size_t)tokpos[0] * d + i] : x[i];
+  const float mv = (float)sum[i];   // ONE rounding of the all-reduced fp64 sum (llama2.ts:201)
+  x[i] = xr + mv;                   // accum, llama2.ts:168-170
+  if (mv_out) mv_out[i] = mv;
+}
+
+// ---- peer-to-peer exchange: setup -----------------------------------------------------------------------------
+static size_t p2p_bytes(const l2_ctx* c) { return (size_t)2 * P2P_MAXG * P2P_FB * 8 + (size_t)2 * P2P_MAXG * c->d * 8; }
+static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits) {
+  c->p2p_peers.flags[r] = (unsigned long long*)base;
+  c->p2p_peers.inbox[r] = (double*)((char*)base + (size_t)2 * P2P_MAXG * P2P_FB * 8);
+  c->p2p_peers.logits[r] = logits;
+}
+static P2PArgs p2p_args(const l2_ctx* c, int n) {
+  P2PArgs a;
+  a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = (unsigned*)(c->p2p_epoch + 1); a.err = c->p2p_err_dev;
+  a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks;
+  return a;
+}
+static int p2p_grid(int n) { const int b = (n + 255) / 256; return b > P2P_FB ? P2P_FB : (b < 1 ? 1 : b); }
+
+// Own buffers (every tensor-parallel context): inbox + flags and the gathered-logits vector are UNCACHED device
+// memory, because peers write them while this GPU's L2 knows nothing about it.
+static int p2p_alloc(l2_ctx* c) {
+  if (c->G > P2P_MAXG) return L2_OK;
+  const char* mode = getenv("L2_TP_ALLREDUCE");
+  if (mode && !strcmp(mode, "rccl")) return L2_OK;
+  if (hipExtMallocWithFlags(&c->p2p_base, p2p_bytes(c), hipDeviceMallocUncached) != hipSuccess) { c->p2p_base = nullptr; (void)hipGetLastError(); return L2_OK; }
+  HIPCHK(hipMemset(c->p2p_base, 0, p2p_bytes(c)));
+  HIPCHK(hipMalloc(&c->p2p_epoch, 16));
+  HIPCHK(hipMemset(c->p2p_epoch, 0, 16));
+  HIPCHK(hipHostMalloc(&c->p2p_err, sizeof(int), hipHostMallocMapped));
+  *c->p2p_err = 0;
+  HIPCHK(hipHostGetDevicePointer((void**)&c->p2p_err_dev, c->p2p_err, 0));
+  return L2_OK;
+}
+
+// Multi-process group: IPC handles of every rank's buffers travel through one RCCL all-gather; then ONE exchange on
+// a known vector is checked against the closed form, and the ranks agree (all-reduce of a flag) whether the
+// peer-to-peer path is used -- any rank that cannot map or complete it sends everybody back to the RCCL collectives.
+enum { NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_MIN = 3 };
+__global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { partial[i] = (double)((rank + 1) * (k + 1)) + 0.5 * (double)i; x[i] = 0.0f; }
+}
+// Test hook (L2_TP_IPC_DIR=<directory>): the ranks are separate PROCESSES that meet through files instead of an RCCL
+// communicator, so the IPC mapping, the self-test and the peer-to-peer exchange run between processes on a box with one GPU
+// (RCCL refuses two ranks on one device).  No fallback in this mode: the exchange works or creation fails.
+static bool file_exchange(const char* dir, const char* tag, int rank, int G, const void* mine, void* all, size_t bytes) {
+  char path[512];
+  snprintf(path, sizeof(path), "%s/%s.%d.tmp", dir, tag, rank);
+  FILE* f = fopen(path, "wb");
+  if (!f) return false;
+  const bool wrote = fwrite(mine, 1, bytes, f) == bytes;
+  fclose(f);
+  char final_path[512];
+  snprintf(final_path, sizeof(final_path), "%s/%s.%d", dir, tag, rank);
+  if (!wrote || rename(path, final_path) != 0) return false;
+  for (int r = 0; r < G; ++r) {
+    snprintf(path, sizeof(path), "%s/%s.%d", dir, tag, r);
+    bool got = false;
+    for (int tries = 0; tries < 6000 && !got; ++tries) {            // 60 s
+      f = fopen(path, "rb");
+      if (f) { got = fread((char*)all + (size_t)r * bytes, 1, bytes, f) == bytes; fclose(f); }
+      if (!got) usleep(10000);
+    }
+    if (!got) return false;
+  }
+  return true;
+}
+
+static int p2p_connect_ipc(l2_ctx* c) {
+  if (!c->p2p_base) return c->ipc_dir.empty() ? L2_OK : fail(L2_E_COMM, "L2_TP_IPC_DIR: no peer-to-peer inbox was allocated");
+  const int G = c->G;
+  const char* dir = c->ipc_dir.empty() ? nullptr : c->ipc_dir.c_str();
+  int round = 0;
+  auto all_min = [&](int v, int* out) -> int {                      // every rank learns the minimum of v
+    if (dir) {
+      std::vector<int> vs(G, 0);
+      char tag[32]; snprintf(tag, sizeof(tag), "min%d", round++);
+      if (!file_exchange(dir, tag, c->rank, G, &v, vs.data(), sizeof(int))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive");
+      *out = *std::min_element(vs.begin(), vs.end());
+      return L2_OK;
+    }
+    int* d_v = nullptr;
+    HIPCHK(hipMalloc(&d_v, sizeof(int)));
+    HIPCHK(hipMemcpy(d_v, &v, 4, hipMemcpyHostToDevice));
+    NCCLCHK(g_rccl.AllReduce(d_v, d_v, 1, NCCL_INT32, NCCL_MIN, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d_v, 4, hipMemcpyDeviceToHost));
+    hipFree(d_v);
+    return L2_OK;
+  };
+  struct Rec { hipIpcMemHandle_t base, logits; };
+  static_assert(sizeof(Rec) == 128, "two 64-byte IPC handles");
+  Rec mine;
+  bool ok = hipIpcGetMemHandle(&mine.base, c->p2p_base) == hipSuccess && hipIpcGetMemHandle(&mine.logits, c->logits) == hipSuccess;
+  (void)hipGetLastError();
+  std::vector<Rec> all(G);
+  if (dir) {
+    if (!file_exchange(dir, "handles", c->rank, G, &mine, all.data(), sizeof(Rec))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive");
+  } else {
+    Rec* d_all = nullptr;
+    HIPCHK(hipMalloc(&d_all, sizeof(Rec) * (G + 1)));
+    HIPCHK(hipMemcpy(d_all + G, &mine, sizeof(Rec), hipMemcpyHostToDevice));
+    NCCLCHK(g_rccl.AllGather(d_all + G, d_all, sizeof(Rec), NCCL_UINT8, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(all.data(), d_all, sizeof(Rec) * G, hipMemcpyDeviceToHost));
+    hipFree(d_all);
+  }
+  for (int r = 0; r < G && ok; ++r) {
+    if (r == c->rank) { p2p_set_peer(c, r, c->p2p_base, c->logits); continue; }
+    void *pb = nullptr, *pl = nullptr;
+    if (hipIpcOpenMemHandle(&pb, all[r].base, hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
+        hipIpcOpenMemHandle(&pl, all[r].logits, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ok = false; (void)hipGetLastError(); break; }
+    c->p2p_opened.push_back(pb); c->p2p_opened.push_back(pl);
+    p2p_set_peer(c, r, pb, (float*)pl);
+  }
+  // every rank learns whether every rank mapped everything BEFORE anybody waits on a peer
+  int h_ok = ok ? 1 : 0;
+  { const int rc_ = all_min(h_ok, &h_ok); if (rc_) return rc_; }
+  if (h_ok) {   // four exchanges (each inbox slot is reused once) on known vectors: sum over ranks of ((rank + 1)(k + 1) + i / 2)
+    const int n = c->d;
+    std::vector<float> got(n);
+    for (int k = 0; k < 4 && h_ok; ++k) {
+      hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
+      hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipMemcpy(got.data(), c->xb2, (size_t)n * 4, hipMemcpyDeviceToHost));
+      if (*c->p2p_err) h_ok = 0;
+      for (int i = 0; i < n && h_ok; ++i) if (got[i] != (float)(0.5 * G * (G + 1) * (k + 1) + 0.5 * (double)i * G)) h_ok = 0;
+    }
+    *c->p2p_err = 0;
+    HIPCHK(hipMemset(c->xb2, 0, (size_t)n * 4));
+    { const int rc_ = all_min(h_ok, &h_ok); if (rc_) return rc_; }
+  }
+  c->p2p = h_ok != 0;
+  c->p2p_peers_ready = true;
+  if (!c->p2p && dir) return fail(L2_E_COMM, "L2_TP_IPC_DIR: the peer-to-peer exchange between the processes failed its self-test");
+  if (!c->p2p && getenv("L2_TP_ALLREDUCE") && !strcmp(getenv("L2_TP_ALLREDUCE"), "p2p"))
+    return fail(L2_E_COMM, "L2_TP_ALLREDUCE=p2p but the peer-to-peer exchange could not be set up on every rank");
+  return L2_OK;
+}
+
+// Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
+// The two collectives of the tensor-parallel step: RCCL, or the loopback test hook.
+static int tp_all_reduce(l2_ctx* c, hipStream_t st) {
+  if (!c->loop) { NCCLCHK(g_rccl.AllReduce(c->partial, c->partial, (size_t)c->d, NCCL_FLOAT64, NCCL_SUM, c->comm, st)); return L2_OK; }
+  LoopGroup& g = *c->loop;
+  HIPCHK(hipStreamSynchronize(st));
+  { std::lock_guard<std::mutex> lk(g.mu); g.ptrs[c->rank] = c->partial; }
+  if (!g.wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");
+  LoopPtrs in;
+  for (int r = 0; r < g.G; ++r) in.p[r] = (const double*)g.ptrs[r];
+  hipLaunchKernelGGL(loop_sum_kernel, dim3((c->d + 255) / 256), dim3(256), 0, st, c->loop_tmp, in, g.G, c->d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  if (!g.wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");   // every rank has read every partial
+  HIPCHK(hipMemcpyAsync(c->partial, c->loop_tmp, (size_t)c->d * 8, hipMemcpyDeviceToDevice, st));
+  return L2_OK;
+}
+static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
+  if (!c->loop) { NCCLCHK(g_rccl.AllGather(c->logits_loc, c->logits, (size_t)c->V_loc, NCCL_FLOAT32, c->comm, st)); return L2_OK; }
+  LoopGroup& g = *c->loop;
+  HIPCHK(hipStreamSynchronize(st));
+  { std::lock_guard<std::mutex> lk(g.mu); g.ptrs[c->rank] = c->logits_loc; }
+  if (!g.wait()) return fail(L2_E_COMM, "loopback all-gather: a rank never arrived");
+  for (int r = 0; r < g.G; ++r)
+    HIPCHK(hipMemcpyAsync(c->logits + (size_t)r * c->V_loc, g.ptrs[r], (size_t)c->V_loc * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (!g.wait()) return fail(L2_E_COMM, "loopback all-gather: a rank never arrived");
+  return L2_OK;
+}
+
+// one all-reduce + residual of the tensor-parallel step: ONE kernel; the loopback test group (all ranks on one GPU)
+// runs its two halves around a host barrier instead (see tp_p2p_reduce_kernel)
+static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out) {
+  const dim3 grid(p2p_grid(c->d));
+  if (!c->loop) {
+    hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
+  } else {
+    hipLaunchKernelGGL(tp_p2p_reduce_kernel<1>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
+    HIPCHK(hipStreamSynchronize(st));
+    if (!c->loop->wait()) return fail(L2_E_COMM, "loopback all-reduce: a rank never arrived");
+    hipLaunchKernelGGL(tp_p2p_reduce_kernel<2>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
+  }
+  LCHK(hipGetLastError());
+  return L2_OK;
+}
+
+// The ranks meet once on the HOST right before their first peer-to-peer step: whatever happened between creation and now
+// (per-rank checkpoint I/O, synthetic fill) is skew the in-kernel flag wait should not have to absorb.
+static int p2p_first_sync(l2_ctx* c) {
+  if (c->loop) { if (!c->loop->wait()) return fail(L2_E_COMM, "loopback group: a rank never arrived"); }
+  else if (!c->ipc_dir.empty()) {
+    int mine = 1; std::vector<int> all(c->G, 0);
+    if (!file_exchange(c->ipc_dir.c_str(), "first", c->rank, c->G, &mine, all.data(), sizeof(int))) return fail(L2_E_COMM, "L2_TP_IPC_DIR: a rank did not arrive for the first step");
+  } else if (c->comm) {
+    int* d_v = nullptr;
+    HIPCHK(hipMalloc(&d_v, sizeof(int)));
+    HIPCHK(hipMemsetAsync(d_v, 0, sizeof(int), c->stream));
+    NCCLCHK(g_rccl.AllReduce(d_v, d_v, 1, NCCL_INT32, NCCL_SUM, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(d_v);
+  }
+  c->p2p_synced = true;
+  return L2_OK;
+}
+
+static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer wait give up?
+  if (c->p2p_err && *c->p2p_err) {
+    *c->p2p_err = 0;
+    c->broken = true;   // the device-side epoch / flag state is out of step with the peers for good: fail fast from now on
+    return fail(L2_E_COMM, "peer-to-peer exchange: a rank never raised its flag (wait of %.0f s gave up); the context is unusable", (double)c->p2p_wait_ticks / 1e8);
+  }
+  return L2_OK;
+}

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the library's tensor-parallel test hooks (one-GPU groups: L2_TP_LOOPBACK / _FORCE_COMM / _NO_COMM / _IPC_DIR) only exist behind this
+# gate, which the library reads once per process; child processes the tests start inherit it
+os.environ.setdefault("L2_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
