@@ -339,57 +339,92 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo")   # rendezvous + barriers only; the data path is inside the library
         if shards:
-            idbuf = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                import ctypes as C
-                b = C.create_string_buffer(128)
-                runtime._check(runtime.lib().l2_tp_unique_id(b))
-                idbuf = torch.frombuffer(bytearray(b.raw), dtype=torch.uint8).clone()
-            dist.broadcast(idbuf, 0)
-            tp = {"rank": rank, "size": world, "id": bytes(idbuf.numpy().tobytes())}
+            tp = {"rank": rank, "size": world}
 
     device = int(os.environ.get("L2_BENCH_FORCE_DEVICE", local_rank))   # test hook: several ranks on one GPU (replicas only)
     cfg = runtime.Config(hdr)
     tp_note = None
     ctx = None
+    tp_proof = None
     if tp:
-        # the tensor-parallel group has never run on more than one GPU (no multi-GPU box in development): if any rank cannot
-        # join it, every rank says so over gloo and the job measures independent replicas instead of dying without a line
+        # The tensor-parallel group has never run on more than one GPU (no multi-GPU box in development), so every way of forming
+        # it is PROVED before it is timed: the group is created, filled, and decodes a few tokens; every rank reports over gloo
+        # whether that worked and what it decoded (all ranks must agree, and agree with the real reference's golden tokens where
+        # a fixture exists).  Order: (1) RCCL communicator + the one-shot peer-to-peer exchange if its self-test passes,
+        # (2) RCCL collectives only, (3) no RCCL: the ranks meet through files and exchange over IPC-mapped inboxes,
+        # (4) independent replicas.  The line says which one ran and why.
         import tempfile
         import torch
 
-        def join():
-            err = ""
-            c = None
+        def golden_tokens(n):
             try:
-                c = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=tp["id"])
-            except Exception as e:      # noqa: BLE001 -- whatever it is, the other ranks have to hear about it
-                err = "%s: %s" % (type(e).__name__, e)
-            flag = torch.tensor([0 if err else 1], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]) == 0 and c is not None:
-                c.close()
-                c = None
-            return c, (err or "another rank failed") if int(flag[0]) == 0 else ""
+                g = json.load(open(os.path.join(ROOT, "tests", "golden", args.config + ".json")))
+                return g["argmax"][:n] if g.get("seed") == args.seed and len(g["argmax"]) >= n else None
+            except (OSError, ValueError, KeyError):
+                return None
 
-        ctx, err = join()                       # 1: RCCL communicator (+ the peer-to-peer exchange if its self-test passes)
+        def attempt(env, fresh_id=True):
+            err, c, toks = "", None, []
+            for k, v in env.items():
+                os.environ[k] = v
+            try:
+                nid = b"\x01" * 128     # the file rendezvous ignores it
+                if fresh_id:             # a communicator id is good for one ncclCommInitRank round
+                    idb = torch.zeros(128, dtype=torch.uint8)
+                    if rank == 0:
+                        import ctypes as C
+                        b = C.create_string_buffer(128)
+                        if runtime.lib().l2_tp_unique_id(b) == 0:
+                            idb = torch.frombuffer(bytearray(b.raw), dtype=torch.uint8).clone()
+                    dist.broadcast(idb, 0)
+                    nid = bytes(idb.numpy().tobytes())
+                try:
+                    if fresh_id and not any(nid):
+                        raise RuntimeError("rank 0 could not create an RCCL id (%s)" % runtime.lib().l2_last_error().decode("utf8", "replace"))
+                    c = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=nid)
+                    c.synth_fill(args.seed)
+                    toks = c.decode_greedy(1, 0, min(3, K)).tolist()
+                except Exception as e:      # noqa: BLE001 -- whatever it is, the other ranks have to hear about it
+                    err = "%s: %s" % (type(e).__name__, e)
+                mine = {"rank": rank, "err": err, "tokens": toks, "mode": c.tp_mode_id() if (c is not None and not err) else -1}
+                every = [None] * world
+                dist.all_gather_object(every, mine)
+                errs = [r["err"] for r in every if r["err"]]
+                same = all(r["tokens"] == every[0]["tokens"] for r in every)
+                gold = golden_tokens(len(every[0]["tokens"]))
+                ok = not errs and same and (gold is None or every[0]["tokens"] == gold)
+                why = "" if ok else (errs[0] if errs else ("ranks decoded different tokens: %s" % [r["tokens"] for r in every] if not same
+                                                         else "tokens %s differ from the reference golden %s" % (every[0]["tokens"], gold)))
+                if not ok and c is not None:
+                    c.close()
+                    c = None
+                proof = {"tokens": every[0]["tokens"], "same_on_every_rank": same, "equals_reference_golden": (None if gold is None else every[0]["tokens"] == gold)}
+                return c, why, proof
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+
+        notes = []
+        ctx, why, tp_proof = attempt({})
+        if ctx is None:
+            notes.append("RCCL + peer-to-peer exchange: %s" % why)
+            ctx, why, tp_proof = attempt({"L2_TP_ALLREDUCE": "rccl"})
         if ctx is None and "L2_TP_IPC_DIR" not in os.environ:
-            # 2: no RCCL at all -- the ranks meet through files and exchange over IPC-mapped inboxes only
+            notes.append("RCCL collectives only: %s" % why)
             meet = [tempfile.mkdtemp(prefix="l2_meet_") if rank == 0 else None]
             dist.broadcast_object_list(meet, 0)
-            os.environ["L2_TP_IPC_DIR"] = meet[0]
-            ctx, err2 = join()
-            if ctx is None:
-                del os.environ["L2_TP_IPC_DIR"]
-                err = "%s; without RCCL: %s" % (err, err2)
-            else:
-                tp_note = "the RCCL communicator could not be created (%s); the ranks met through files and exchange peer to peer" % err
+            ctx, why, tp_proof = attempt({"L2_TP_IPC_DIR": meet[0]}, fresh_id=False)
+            if ctx is not None:
+                notes.append("the ranks met through files and exchange peer to peer (no RCCL)")
         if ctx is None:
-            tp, shards = None, False
-            tp_note = "tensor-parallel group could not be created (%s); measured %d independent replicas instead" % (err, world)
+            notes.append("file rendezvous + peer-to-peer exchange: %s" % why)
+            tp, shards, tp_proof = None, False, None
+            notes.append("measured %d independent replicas instead" % world)
+        if notes:
+            tp_note = "; ".join(notes)
     if ctx is None:
         ctx = runtime.Context(hdr, device=device)
-    ctx.synth_fill(args.seed)
+        ctx.synth_fill(args.seed)
 
     def sync_all():
         if dist is not None:
@@ -447,7 +482,7 @@ def main():
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
         out["tp"] = {"ranks": world, "sharded": bool(shards), "l2_tp_mode": sorted({r["tp_mode"] for r in ranks}),
-                     "devices": [r["device"] for r in ranks], "step": ctx.tp_mode()}
+                     "devices": [r["device"] for r in ranks], "step": ctx.tp_mode(), "proved_before_timing": tp_proof}
     if tp_note:
         out["note"] = tp_note
     if extras:

@@ -68,15 +68,20 @@ def test_bench_tensor_parallel_flow_with_two_processes_on_one_gpu(tmp_path):
 
 def test_bench_second_chance_without_rccl(tmp_path):
     """Two ranks on one device over RCCL: ncclCommInitRank refuses the duplicate GPU, every rank hears about it over gloo,
-    and the job tries again with the ranks meeting through files (no RCCL): tensor parallel after all, with a note."""
+    the job tries RCCL collectives only (refused again), then lets the ranks meet through files (no RCCL): tensor parallel after
+    all, with a note that names every step."""
     j = _two_ranks({}, tmp_path, 29615)
-    assert j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong" and "RCCL communicator could not be created" in j["note"]
+    assert j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong"
+    assert "RCCL + peer-to-peer exchange:" in j["note"] and "RCCL collectives only:" in j["note"] and "no RCCL" in j["note"]
+    # every formation is proved before it is timed: all ranks decoded the same tokens, and they are the real reference's
+    pr = j["tp"]["proved_before_timing"]
+    assert pr["same_on_every_rank"] and pr["equals_reference_golden"] is True and len(pr["tokens"]) == 3
 
 
 def test_bench_falls_back_to_replicas_when_the_group_cannot_form(tmp_path):
     """No way to form the group (the meeting directory does not exist): the job measures replicas and says why."""
     j = _two_ranks({"L2_TP_IPC_DIR": str(tmp_path / "missing" / "dir")}, tmp_path, 29617)
-    assert j["config"]["parallelism"] == "replicas2" and j["scaling"] == "weak" and "could not be created" in j["note"]
+    assert j["config"]["parallelism"] == "replicas2" and j["scaling"] == "weak" and "independent replicas instead" in j["note"]
 
 
 def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
@@ -93,7 +98,7 @@ def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong" and j["value"] > 0
-    assert "note" in j and "RCCL communicator could not be created" in j["note"]
+    assert "note" in j and "no RCCL" in j["note"]
     assert j["tp"]["ranks"] == 2 and j["tp"]["sharded"] and j["tp"]["l2_tp_mode"] == [3] and j["tp"]["devices"] == [0, 0]
 
 
