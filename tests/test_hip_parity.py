@@ -389,6 +389,32 @@ def test_prefill_at_the_widths_the_bench_times(built, name, n, pf_lds, monkeypat
     b.close()
 
 
+@pytest.mark.parametrize("n,first", [(65, 0), (70, 0), (129, 0), (200, 0), (160, 100), (300, 37)])
+def test_prefill_ragged_chunk_counts_at_110m_width(built, n, first):
+    """The register-blocked GEMMs take up to four 64-token chunks per launch: prompts that end inside a chunk (65, 70, 129,
+    200 tokens), that are fed in two calls (the second starting at pos0 = `first`: llama2.ts:471-473 has no notion of calls, only
+    of positions) or that exceed one launch sequence (300) must leave the same KV cache and last logits as one transformer()
+    call per token, and the reference's own argmax where its fixture has one."""
+    meta, g = load_gold("stories110M")
+    toks = meta["tokens_fed"][:n]
+    a = runtime.Context(meta["header"]); a.synth_fill(meta["seed"])
+    b = runtime.Context(meta["header"]); b.synth_fill(meta["seed"])
+    for pos, t in enumerate(toks):
+        la = np.array(a.forward(t, pos), copy=True)
+    if first:
+        b.prefill(toks[:first], 0)
+    lb = np.array(b.prefill(toks[first:], first), copy=True)
+    assert np.abs(la - lb).max() <= 1e-5
+    assert runtime.argmax(lb) == meta["argmax"][n - 1]
+    d, S, L = b.cfg.dim, b.cfg.seq_len, b.cfg.n_layers
+    for nm in ("key_cache", "value_cache"):
+        ca = a.read_state(nm).reshape(L, S, d)[:, :n]
+        cb = b.read_state(nm).reshape(L, S, d)[:, :n]
+        assert np.abs(ca - cb).max() <= 1e-6, nm
+    assert b.decode_greedy(runtime.argmax(lb), n, 8).tolist() == meta["argmax"][n:n + 8]
+    a.close(); b.close()
+
+
 def test_prefill_prompt_golden_and_errors(built):
     meta, g = load_gold("stories15M_prompt")          # -i "Once upon a time": BOS + 4 prompt ids are teacher-forced
     ctx = runtime.Context(meta["header"]); ctx.synth_fill(meta["seed"])

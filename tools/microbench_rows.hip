@@ -34,8 +34,10 @@ __global__ void __launch_bounds__(256) stream(const f4* w, size_t n4, const floa
 }
 
 // PAIR: the group's two rows are row g of the first and of the second half of the matrix (w1 / w3); else rows 2g, 2g + 1
-template <bool PAIR, int ROT, bool STAGGER, int WORK = 0>
-__global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const float* carry_in, float* carry_out) {
+// TAILPF: every wave, once its own rows are done, pulls TAILPF KiB of the NEXT link's matrix (plain loads: they allocate in L2 / the
+// Infinity Cache) -- in the pattern the next launch's first batches will ask for them -- so that the next launch finds its first bytes on chip
+template <bool PAIR, int ROT, bool STAGGER, int WORK = 0, int TAILPF = 0>
+__global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const float* carry_in, float* carry_out, const f4* next_w = nullptr) {
   constexpr int U = 2;
   const float c = carry_in[0];
   f4 acc = {c, 0.f, 0.f, 0.f};
@@ -101,6 +103,21 @@ __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const
     }
     g = g3; ci = c3;
   }
+  if (TAILPF > 0 && next_w) {
+    // the next launch's batch 0 (and 1, ...) of this wave's first row group: same rows, same rotated columns
+    const int g0 = blockIdx.x * 4 + wave;
+    if (g0 < groups) {
+#pragma unroll
+      for (int b = 0; b < TAILPF / 4; ++b) {
+        const f4* r0 = next_w + (size_t)(PAIR ? g0 : 2 * g0) * n4;
+        const f4* r1 = next_w + (size_t)(PAIR ? groups + g0 : 2 * g0 + 1) * n4;
+        const int rot = ROT ? (g0 * ROT) % batches : 0;
+        int c0 = b + rot; c0 -= c0 >= batches ? batches : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc += r0[min(c0 * 64 * U + u * 64 + lane, n4 - 1)]; acc += r1[min(c0 * 64 * U + u * 64 + lane, n4 - 1)]; }
+      }
+    }
+  }
   if (acc.x + acc.y + acc.z + acc.w + (float)(d0 + d1) == 12345.678f) carry_out[1] = 1.0f;
   if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
 }
@@ -146,15 +163,15 @@ int main() {
   hipStream_t sa; (void)hipStreamCreate(&sa);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   printf("us per link of a chain of dependent streaming kernels (launch boundary included), 512 workgroups of 256 threads\n");
-  printf("%-34s %8s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma", "cols");
+  printf("%-34s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma", "cols", "fma+pf4K", "fma+pf8K");
   struct { const char* name; int rows, n; bool pair; } shapes[] = {{"w1+w3  2 x 11008 x 4096 (361 MB)", 22016, 4096, true}, {"wqkv   12288 x 4096 (201 MB)", 12288, 4096, false},
                                                                    {"w2     4096 x 11008 (180 MB)", 4096, 11008, false}, {"wo     4096 x 4096 (67 MB)", 4096, 4096, false},
                                                                    {"wcls   32000 x 4096 (524 MB)", 32000, 4096, false}};
   for (auto sh : shapes) {
     const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
     printf("%-34s", sh.name);
-    for (int var = 0; var < 8; ++var) {
-      if (var == 7 && sh.n != 4096) continue;            // eight column batches of 2 KB: 4096 columns
+    for (int var = 0; var < 10; ++var) {
+      if (var == 7 && sh.n != 4096) { printf(" %8s", "-"); continue; }            // eight column batches of 2 KB: 4096 columns
       float best = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0, sa);
@@ -165,6 +182,11 @@ int main() {
 #define ROWS(R_, S_) do { if (sh.pair) hipLaunchKernelGGL((rows2<true, R_, S_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, R_, S_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); } while (0)
           if (var == 0) hipLaunchKernelGGL(stream, g, b, 0, sa, wk, link4, ci, co);
           else if (var == 1) ROWS(0, false); else if (var == 2) ROWS(5, false); else if (var == 3) ROWS(5, true); else if (var == 4) ROWS(3, false); else if (var == 5) ROWS(7, false); else if (var == 6) ROWSW(5, false);
+          else if (var >= 8) {
+            const f4* nx = (k + 1 < nk) ? wk + link4 : nullptr;
+            if (var == 8) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 5, false, 1, 4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co, nx); else hipLaunchKernelGGL((rows2<false, 5, false, 1, 4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co, nx); }
+            else { if (sh.pair) hipLaunchKernelGGL((rows2<true, 5, false, 1, 8>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co, nx); else hipLaunchKernelGGL((rows2<false, 5, false, 1, 8>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co, nx); }
+          }
           else { if (sh.pair) hipLaunchKernelGGL((cols8<true>), dim3(256), dim3(512), 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((cols8<false>), dim3(256), dim3(512), 0, sa, wk, sh.rows, sh.n, ci, co); }
         }
         (void)hipEventRecord(e1, sa); (void)hipEventSynchronize(e1);
