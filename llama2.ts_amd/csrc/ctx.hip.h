@@ -161,7 +161,6 @@ struct l2_ctx {
   unsigned long long* amax = nullptr;   // greedy loop: 8 argmax keys, one per 128-byte line, zero between tokens
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int pf3 = 1;                      // L2_PF3: 1 (default) register-blocked prefill GEMMs where the shape allows, 0: the 16-row-tile kernels everywhere (A/B, tests)
-  int pf_nw[4] = {4, 4, 4, 4};      // L2_PF_NW_QKV / _WO / _W13 / _W2: waves per 16-row tile in the older prefill GEMMs (4 or 8)
   int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int cur_splits = 1;               // split count of the step being enqueued / captured
   int split_rows = 144;             // L2_ATTN_SPLIT_ROWS: cached rows of a head beyond which attention runs 8 workgroups per head
@@ -228,4 +227,6 @@ static int env_int(const char* name, int dflt) {
 // L2_TEST_HOOKS=1, read once per process: a production host cannot trip them through a stray variable.
 static bool hooks_on() { static const bool on = env_int("L2_TEST_HOOKS", 0) != 0; return on; }
 static int hook_int(const char* name) { return hooks_on() ? env_int(name, 0) : 0; }
+// development switches (launch geometry, attention split policy, A/B forms): the same gate, with the shipped default otherwise
+static int dev_int(const char* name, int dflt) { return hooks_on() ? env_int(name, dflt) : dflt; }
 static const char* hook_str(const char* name) { const char* s = hooks_on() ? getenv(name) : nullptr; return (s && *s) ? s : nullptr; }

@@ -131,7 +131,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("L2_ALLOW_ANY_ARCH"))
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !hook_int("L2_ALLOW_ANY_ARCH"))
     return fail(L2_E_NOGPU, "device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
 
   l2_ctx* c = new l2_ctx();
@@ -142,13 +142,13 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->G = G; c->rank = rank;
   c->d_loc = d / G; c->h_loc = h / G; c->H_loc = H / G; c->V_loc = V / G;
   c->KVH = KVH; c->kvd = KVH * (d / H); c->kvd_loc = c->kvd / G; c->flags = flags;
-  c->tune_R = env_int("L2_TUNE_R", 0);
-  c->tune_U = env_int("L2_TUNE_U", 0);
-  c->tune_nwaves = env_int("L2_TUNE_NWAVES", 0);
-  c->tune_gridcap = env_int("L2_TUNE_GRIDCAP", 0);
-  c->tune_rot = env_int("L2_TUNE_ROT", 5);
+  c->tune_R = dev_int("L2_TUNE_R", 0);
+  c->tune_U = dev_int("L2_TUNE_U", 0);
+  c->tune_nwaves = dev_int("L2_TUNE_NWAVES", 0);
+  c->tune_gridcap = dev_int("L2_TUNE_GRIDCAP", 0);
+  c->tune_rot = dev_int("L2_TUNE_ROT", 5);
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !hook_int("L2_TP_FORCE_COMM")) ? 1 : 0);
-  c->profile_sync = env_int("L2_PROFILE_SYNC", 0);
+  c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
@@ -189,14 +189,13 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMemsetAsync(c->att, 0, (size_t)c->H_loc * S * 4, c->stream));
   CK(hipMemsetAsync(c->logits, 0, (size_t)V * 4, c->stream));
   // split attention scratch (sized for the largest split count)
-  c->attn_splits_forced = env_int("L2_ATTN_SPLITS", 0);
-  c->attn_nw = env_int("L2_ATTN_NW", 0);
-  c->split_rows = env_int("L2_ATTN_SPLIT_ROWS", 144);
-  c->small_max = env_int("L2_SMALL_MAX", 8 << 20);
+  c->attn_splits_forced = dev_int("L2_ATTN_SPLITS", 0);
+  c->attn_nw = dev_int("L2_ATTN_NW", 0);
+  c->split_rows = dev_int("L2_ATTN_SPLIT_ROWS", 144);
+  c->small_max = dev_int("L2_SMALL_MAX", 8 << 20);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->pf_lds = env_int("L2_PF_LDS", 1);
-  c->pf3 = env_int("L2_PF3", 1);
-  c->pf_nw[0] = env_int("L2_PF_NW_QKV", 4); c->pf_nw[1] = env_int("L2_PF_NW_WO", 4); c->pf_nw[2] = env_int("L2_PF_NW_W13", 4); c->pf_nw[3] = env_int("L2_PF_NW_W2", 4);
+  c->pf_lds = dev_int("L2_PF_LDS", 1);
+  c->pf3 = dev_int("L2_PF3", 1);
   if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;
   {
     const size_t rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;

@@ -90,7 +90,7 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
     a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
     a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
-    launch_pf_gemm<MODE_QKV>(c, a, c->pf_nw[0], tt, chunks, st);
+    launch_pf_gemm<MODE_QKV>(c, a, 4, tt, chunks, st);
     LCHK(hipGetLastError());
     // attention, one workgroup per (head, query) (llama2.ts:244-267)
     {
@@ -102,15 +102,15 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     }
     // wo + residual (llama2.ts:270-273)
     a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
-    launch_pf_gemm<MODE_WO>(c, a, c->pf_nw[1], tt, chunks, st);
+    launch_pf_gemm<MODE_WO>(c, a, 4, tt, chunks, st);
     // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
     hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
     a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
     a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
-    launch_pf_gemm<MODE_W13>(c, a, c->pf_nw[2], tt, chunks, st);
+    launch_pf_gemm<MODE_W13>(c, a, 4, tt, chunks, st);
     // w2 + residual (llama2.ts:292-295)
     a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
-    launch_pf_gemm<MODE_W2>(c, a, c->pf_nw[3], tt, chunks, st);
+    launch_pf_gemm<MODE_W2>(c, a, 4, tt, chunks, st);
     LCHK(hipGetLastError());
   }
   return L2_OK;

@@ -959,7 +959,7 @@ hipError_t create(Sampler* s, int V) {
   L2S(hipMalloc(&s->cm, padded * sizeof(int)));
   L2S(hipMalloc(&s->mxkey, sizeof(unsigned)));
   L2S(hipMemset(s->mxkey, 0, sizeof(unsigned)));
-  { const char* e_ = getenv("L2_SAMPLER_SERIAL"); s->serial = e_ && atoi(e_) != 0; }
+  { const char* g_ = getenv("L2_TEST_HOOKS"); const char* e_ = getenv("L2_SAMPLER_SERIAL"); s->serial = g_ && atoi(g_) != 0 && e_ && atoi(e_) != 0; }   // A/B form, development gate
   // the rank merge holds every tile in LDS: 4 bytes per (padded) element of the 160 KB
   const size_t rank_lds = padded * 4 + (size_t)s->G * 8;
   s->own_sort = !s->serial && rank_lds <= 160 * 1024;

@@ -347,15 +347,17 @@ def test_prefill_equals_token_by_token(built, name, n):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("pf_lds", ["0", "1"])
+@pytest.mark.parametrize("form", ["register-blocked", "16-row tiles", "16-row tiles, no LDS"])
 @pytest.mark.parametrize("name,n", [("stories110M", 128), ("stories110M", 256), ("llama2_7b_L2", 64), ("llama2_7b_L2", 128), ("llama2_7b_L2", 256)])
-def test_prefill_at_the_widths_the_bench_times(built, name, n, pf_lds, monkeypatch):
+def test_prefill_at_the_widths_the_bench_times(built, name, n, form, monkeypatch):
     """Prompt ingestion where bench.py reports `prefill_tok_s` (d = 4096 / h = 11008, and the 110M width): the first n
     tokens the TRUE reference fed itself (llama2.ts:471-473 teacher-forces a prompt one transformer() call per token) go
     through l2_prefill in one call; the logits of position n - 1 must be the reference's own (kept positions 63 / 127 /
     255, <= 1e-4), the KV cache must equal the token-by-token path's, and the greedy continuation must follow the
-    reference's tokens through the next kept position.  Both weight-load forms of the GEMMs (L2_PF_LDS 0 / 1)."""
-    monkeypatch.setenv("L2_PF_LDS", pf_lds)
+    reference's tokens through the next kept position.  Every form of the GEMMs: the register-blocked kernels (default: up to
+    four 64-token chunks per launch) and the older 16-row-tile kernels with and without the LDS weight tile."""
+    monkeypatch.setenv("L2_PF3", "1" if form == "register-blocked" else "0")
+    monkeypatch.setenv("L2_PF_LDS", "0" if form.endswith("no LDS") else "1")
     meta, g = load_gold(name)
     keep = {p: i for i, p in enumerate(meta["logit_positions"])}
     assert n - 1 in keep, "fixture keeps no logits at %d" % (n - 1)
@@ -385,7 +387,7 @@ def test_prefill_at_the_widths_the_bench_times(built, name, n, pf_lds, monkeypat
     # and on from there with the device loop: token-exact for 32 more positions
     cont = b.decode_greedy(tok, nxt + 1, 32)
     assert cont.tolist() == meta["argmax"][nxt + 1:nxt + 33]
-    print("\n[prefill %s n=%d L2_PF_LDS=%s] max|dlogit| vs reference %.3g" % (name, n, pf_lds, err))
+    print("\n[prefill %s n=%d %s] max|dlogit| vs reference %.3g" % (name, n, form, err))
     b.close()
 
 

@@ -1,4 +1,5 @@
 """ms/token of the device-resident decode loop in windows along the context (attention split levels)."""
+import os as _os; _os.environ.setdefault("L2_TEST_HOOKS", "1")   # development switches are gated
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llama2_ts_amd import configs, runtime

@@ -1,5 +1,6 @@
 # per-kernel average durations of the decode step under the given environment (eager launches, rocprofv3 kernel trace):
 #   bash tools/kernel_times.sh llama2_7b L2_TUNE_ROT=0
+export L2_TEST_HOOKS=1   # the development switches below only exist behind this gate
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 cfg=$1; shift
 rm -rf gpurun_out/kt

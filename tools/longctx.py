@@ -1,4 +1,5 @@
 """Decode speed at a long context: `steps` tokens starting at pos0 (KV history is whatever the cache holds)."""
+import os as _os; _os.environ.setdefault("L2_TEST_HOOKS", "1")   # development switches are gated
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llama2_ts_amd import configs, runtime

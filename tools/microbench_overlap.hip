@@ -34,10 +34,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // consumer side: one lane polls the predecessor's `done` until it is one ahead of this phase's own count, then acquires
-__device__ __forceinline__ void wait_prev(const Flag* prev, const Flag* mine, int* err, int lead) {
+__device__ __forceinline__ void wait_prev(const Flag* prev, const Flag* mine, int* err, int lead, int want_arg = -1) {
   if (prev) {
     if (threadIdx.x == 0) {
-      const unsigned want = __hip_atomic_load(&mine->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned)lead;   // lead 0: the first phase of the cycle (its predecessor is the LAST phase of the previous round)
+      const unsigned want = want_arg >= 0 ? (unsigned)want_arg : __hip_atomic_load(&mine->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned)lead;   // lead 0: the first phase of the cycle (its predecessor is the LAST phase of the previous round)
       unsigned spins = 0; unsigned long long t0 = 0;
       const unsigned* word = g_private ? &prev->per_wg[(blockIdx.x % MAXWG) * 32] : &prev->done;
       const int slp = g_sleep;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void signal_done(Flag* mine) {
 // NB batches of 2 x 64 float4 per row with a rotated start, two register sets in flight; PRE batches of the FIRST group are
 // requested before the wait for x.  PAIR: rows g and groups + g (w1 / w3), else 2g and 2g + 1.
 template <int NB, int PRE, bool PAIR>
-__global__ void __launch_bounds__(256) phase(const f4* w, int rows, int n, const float* xin, float* xout, const Flag* prev, Flag* mine, int* err, int lead) {
+__global__ void __launch_bounds__(256) phase(const f4* w, int rows, int n, const float* xin, float* xout, const Flag* prev, Flag* mine, int* err, int lead, int want = -1) {
   constexpr int U = 2;
   extern __shared__ f4 xs[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) phase(const f4* w, int rows, int n, const
   f4 P[PRE][2][U];
 #pragma unroll
   for (int b = 0; b < PRE; ++b) load(P[b], have ? g0 : groups - 1, b);
-  wait_prev(prev, mine, err, lead);
+  wait_prev(prev, mine, err, lead, want);
   if (g_fences) { for (int i = threadIdx.x; i < NB * 64 * U; i += 256) xs[i] = i < n4 ? reinterpret_cast<const f4*>(xin)[i] : f4{0.f, 0.f, 0.f, 0.f}; }
   else { for (int i = threadIdx.x; i < NB * 64 * U * 4; i += 256) reinterpret_cast<float*>(xs)[i] = i < n ? ld1(xin + i) : 0.f; }
   __syncthreads();
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) phase(const f4* w, int rows, int n, const
 
 // attention stand-in: 32 workgroups; per head a dependent chain q -> 64 cache rows -> reduce -> out (the cache rows do not depend
 // on the previous phase and are requested before the wait)
-__global__ void __launch_bounds__(256) attn_like(const float* cache, const float* q, float* out, const Flag* prev, Flag* mine, int* err, int lead) {
+__global__ void __launch_bounds__(256) attn_like(const float* cache, const float* q, float* out, const Flag* prev, Flag* mine, int* err, int lead, int want = -1) {
   __shared__ float qs[128];
   __shared__ float red[256];
   const int h = blockIdx.x, t = threadIdx.x;
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) attn_like(const float* cache, const float
   f4 kv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) kv[j] = rows[j * 256 + t];           // 64 rows x 128 floats = 2048 float4
-  wait_prev(prev, mine, err, lead);
+  wait_prev(prev, mine, err, lead, want);
   if (t < 128) qs[t] = g_fences ? q[h * 128 + t] : ld1(q + h * 128 + t);
   __syncthreads();
   float s = 0.f;
@@ -192,7 +192,9 @@ int main(int argc, char** argv) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&phase<22, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&phase<22, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   printf("us per Llama-2-7B-shaped layer (qkv, attention stand-in, wo, w1/w3, w2), %d layers, best of 5\n", LAYERS);
-  const int variants[][4] = {{0, 8, 0, 1}, {1, 8, 0, 1}, {1, 8, 0, 0}, {2, 8, 0, 0}, {1, 8, 1, 0}, {3, 8, 0, 1}, {3, 8, 0, 0}};   // {mode, sleep, private flags, fences}; mode 3: ONE stream, but with the completion signal / wait protocol
+  // {mode, sleep, private flags, fences}; mode 3: ONE stream, but with the completion signal / wait protocol on every edge; modes 10..14: ONE stream, the
+  // protocol on ONE edge only (10: qkv -> attention, 11: attention -> wo, 12: wo -> w1/w3, 13: w1/w3 -> w2, 14: w2 -> next qkv), everything else plain
+  const int variants[][4] = {{0, 8, 0, 1}, {1, 8, 0, 1}, {1, 8, 0, 0}, {2, 8, 0, 0}, {3, 8, 0, 1}, {3, 8, 0, 0}, {10, 8, 0, 1}, {11, 8, 0, 1}, {12, 8, 0, 1}, {13, 8, 0, 1}, {14, 8, 0, 1}, {0, 8, 0, 1}};
   for (auto& var : variants) {
     const int mode = var[0];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sleep), &var[1], 4); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_private), &var[2], 4); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fences), &var[3], 4);
@@ -211,15 +213,20 @@ int main(int argc, char** argv) {
         const f4* w2 = (const f4*)(wl + (size_t)4 * d * d + (size_t)2 * hd * d);
         auto st = [&]() { hipStream_t s = (two && (k & 1)) ? sb : sa; ++k; return s; };
         Flag* F = mode ? flags : nullptr;
+        const int edge = mode >= 10 ? mode - 10 : -1;          // the one edge that carries the protocol (producer phase index)
         auto fl = [&](int i) -> Flag* { return F ? F + i : nullptr; };
-#define PH(NB, PAIR, grid, lds, W, rows, n, xin, xout, prev, mine, lead) do { hipStream_t s_ = st(); \
-          if (mode == 2) hipLaunchKernelGGL((phase<NB, 6, PAIR>), dim3(grid), dim3(256), lds, s_, W, rows, n, xin, xout, prev, mine, err, lead); \
-          else hipLaunchKernelGGL((phase<NB, 2, PAIR>), dim3(grid), dim3(256), lds, s_, W, rows, n, xin, xout, prev, mine, err, lead); } while (0)
-        PH(8, false, 512, lds4096, wqkv, 3 * d, d, x, q, fl(4), fl(0), 0);
-        { hipStream_t s_ = st(); hipLaunchKernelGGL(attn_like, dim3(32), dim3(256), 0, s_, cache, q, xb, fl(0), fl(1), err, 1); }
-        PH(8, false, 512, lds4096, wo, d, d, xb, x, fl(1), fl(2), 1);
-        PH(8, true, 459, lds4096, w13, 2 * hd, d, x, hb, fl(2), fl(3), 1);
-        PH(22, false, 512, lds11008, w2, d, hd, hb, x, fl(3), fl(4), 1);
+        // per phase p (0 qkv, 1 attention, 2 wo, 3 w1/w3, 4 w2): the flag it waits on, the flag it signals, the count it expects
+        auto prev_of = [&](int p) -> Flag* { if (edge < 0) return fl((p + 4) % 5); return ((p + 4) % 5 == edge) ? flags + edge : nullptr; };
+        auto mine_of = [&](int p) -> Flag* { if (edge < 0) return fl(p); return (p == edge) ? flags + edge : nullptr; };
+        auto want_of = [&](int p) { return edge < 0 ? -1 : (p == 0 ? l : l + 1); };   // one signal per layer on that edge (edge 4 is consumed by the NEXT layer's qkv)
+#define PH(NB, PAIR, grid, lds, W, rows, n, xin, xout, prev, mine, lead, want) do { hipStream_t s_ = st(); \
+          if (mode == 2) hipLaunchKernelGGL((phase<NB, 6, PAIR>), dim3(grid), dim3(256), lds, s_, W, rows, n, xin, xout, prev, mine, err, lead, want); \
+          else hipLaunchKernelGGL((phase<NB, 2, PAIR>), dim3(grid), dim3(256), lds, s_, W, rows, n, xin, xout, prev, mine, err, lead, want); } while (0)
+        PH(8, false, 512, lds4096, wqkv, 3 * d, d, x, q, prev_of(0), mine_of(0), 0, want_of(0));
+        { hipStream_t s_ = st(); hipLaunchKernelGGL(attn_like, dim3(32), dim3(256), 0, s_, cache, q, xb, prev_of(1), mine_of(1), err, 1, want_of(1)); }
+        PH(8, false, 512, lds4096, wo, d, d, xb, x, prev_of(2), mine_of(2), 1, want_of(2));
+        PH(8, true, 459, lds4096, w13, 2 * hd, d, x, hb, prev_of(3), mine_of(3), 1, want_of(3));
+        PH(22, false, 512, lds11008, w2, d, hd, hb, x, prev_of(4), mine_of(4), 1, want_of(4));
       }
       if (two) { (void)hipEventRecord(ej, sb); (void)hipStreamWaitEvent(sa, ej, 0); }
       (void)hipEventRecord(e1, sa); (void)hipEventSynchronize(e1);
@@ -228,7 +235,8 @@ int main(int argc, char** argv) {
     int herr = 0; (void)hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost);
     float hx[4]; (void)hipMemcpy(hx, x + 100, 16, hipMemcpyDeviceToHost);
     printf("mode %d sleep %2d private %d fences %d  %s  %8.2f us per layer   (%.3f ms per 32 layers; bounded waits that gave up: %d; x[0..1] = %g %g)\n", mode, var[1], var[2], var[3],
-           mode == 0 ? "one stream, plain launches          " : mode == 1 ? "two streams, hand-off, 2 batches pre" : mode == 2 ? "two streams, hand-off, 6 batches pre" : "ONE stream + the hand-off protocol   ", best * 1e3 / LAYERS, best, herr, hx[0], hx[1]);
+           mode == 0 ? "one stream, plain launches          " : mode == 1 ? "two streams, hand-off, 2 batches pre" : mode == 2 ? "two streams, hand-off, 6 batches pre" : mode == 3 ? "ONE stream + the hand-off protocol   " :
+           mode == 10 ? "protocol on qkv -> attention only   " : mode == 11 ? "protocol on attention -> wo only    " : mode == 12 ? "protocol on wo -> w1/w3 only        " : mode == 13 ? "protocol on w1/w3 -> w2 only        " : "protocol on w2 -> next qkv only     ", best * 1e3 / LAYERS, best, herr, hx[0], hx[1]);
   }
   return 0;
 }

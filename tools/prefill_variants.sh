@@ -1,5 +1,6 @@
 # per-kernel times of the prompt-ingestion GEMMs, 7B width: the 16-row-tile kernels (L2_PF3=0) against the register-blocked ones with 1, 2 and 4
 # 64-token chunks per launch (PF_TOKENS = 64 / 128 / 256).  bash tools/prefill_variants.sh   (GPU box)
+export L2_TEST_HOOKS=1   # the development switches below only exist behind this gate
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {
   tag=$1; shift

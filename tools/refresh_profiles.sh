@@ -22,7 +22,7 @@ done
 bash tools/prefill_variants.sh > $out/prefill_kernels_old_vs_register_blocked.txt 2>&1
 python tools/prefill_bench.py llama2_7b > $out/prefill_bench_llama2_7b.txt 2>&1
 python tools/prefill_bench.py stories110M > $out/prefill_bench_stories110M.txt 2>&1
-bash tools/prefill_pmc3.sh > /dev/null 2>&1; cp gpurun_out/pfpmc3/summary.txt $out/prefill_pmc_sq_counters_7b_width_64tok.txt
+bash tools/prefill_pmc.sh > /dev/null 2>&1; cp gpurun_out/pfpmc/summary.txt $out/prefill_pmc_sq_counters_7b_width_64tok.txt
 # device sampler
 for c in stories110M stories110M stories15M llama2_7b_L2; do python tools/sampler_bench.py $c; done > $out/sampler_bench_run.txt 2>&1
 bash tools/sampler_profile.sh > $out/sampler_kernels.txt 2>&1

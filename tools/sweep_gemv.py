@@ -1,4 +1,5 @@
 """Sweep launch geometry of the GEMV phase kernels (env L2_TUNE_*) and print GB/s per matrix kind."""
+import os as _os; _os.environ.setdefault("L2_TEST_HOOKS", "1")   # development switches are gated
 import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llama2_ts_amd import configs, runtime
