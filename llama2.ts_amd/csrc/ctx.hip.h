@@ -161,6 +161,7 @@ struct l2_ctx {
   unsigned long long* amax = nullptr;   // greedy loop: 8 argmax keys, one per 128-byte line, zero between tokens
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int pf3 = 1;                      // L2_PF3: 1 (default) register-blocked prefill GEMMs where the shape allows, 0: the 16-row-tile kernels everywhere (A/B, tests)
+  int pf_attn = 1;                  // L2_PF_ATTN: 1 (default) prompt attention on the fp64 MFMA (16 queries per workgroup), 0: the decode kernel per (head, query)
   int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int cur_splits = 1;               // split count of the step being enqueued / captured
   int split_rows = 144;             // L2_ATTN_SPLIT_ROWS: cached rows of a head beyond which attention runs 8 workgroups per head

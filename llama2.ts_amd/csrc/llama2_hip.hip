@@ -196,6 +196,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->pf_lds = dev_int("L2_PF_LDS", 1);
   c->pf3 = dev_int("L2_PF3", 1);
+  c->pf_attn = dev_int("L2_PF_ATTN", 1);
   if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;
   {
     const size_t rec = ((size_t)c->hs + 2 + 15) & ~(size_t)15;

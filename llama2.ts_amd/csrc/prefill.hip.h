@@ -498,4 +498,134 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention of a prompt chunk on the matrix cores (llama2.ts:244-267 for 16 query positions at a time).
+// pf_attn_tile_kernel (attention.hip.h) is the decode kernel run once per (head, query): every query re-reads its head's cache
+// rows, 23 / 57 / 155 us per layer at 64 / 128 / 256 prompt tokens (7B width).  Here one workgroup takes one head and 16
+// consecutive queries: scores = Q (16 x hs) K^T on v_mfma_f64_16x16x4_f64 (Q widened once into registers, the key blocks of 16
+// dealt round-robin to the 4 waves), one fp32 rounding of dot x 1/sqrt(hs) per score as the reference has it (:253), causal
+// mask, softmax per query row with the reference's roundings (exp stored fp32 :187, fp64 sum of the rounded values :190, quotient
+// stored fp32 :192), then xb = P V on the same instruction (each wave owns hs / 64 of the 16-wide output column tiles, fp64
+// accumulate over all keys, ONE rounding: the accumulate of L2_OPT_EXACT_ATTENTION = 0).  Scores / probabilities live in LDS
+// as 16 rows of fp32 (row stride + 4 floats: conflict-free 16-byte reads of the A fragments).
+struct PfAttnArgs {
+  const float* q;       // [rows][dim] rotated queries of the chunk
+  const float* kc;      // key_cache + l*S*dim (rows pos0 .. pos0+n-1 were written by the chunk's qkv GEMM)
+  const float* vc;
+  float* xb;            // [rows][dim] out
+  int dim, head_size, seq_len, pos0, nvalid;
+  double inv_sqrt_hs;
+};
+
+// LDS of a launch whose last query sits at position `last_pos`: 16 rows x (keys rounded up to 16, + 4 floats of padding)
+__host__ __device__ inline size_t pf_attn_lds(int last_pos) { return (size_t)16 * (size_t)((((last_pos + 16) + 15) & ~15) + 4) * 4 + 64 * 8; }
+
+template <int HS>      // head_size: 64 or 128
+__global__ void __launch_bounds__(256) pf_attn_mfma_kernel(const PfAttnArgs a) {
+  static_assert(HS % 64 == 0, "four waves x whole 16-wide column tiles");
+  constexpr int KB = HS / 16;                          // 16-column blocks of a head row
+  constexpr int CT = HS / 64;                          // output column tiles per wave
+  extern __shared__ __attribute__((aligned(16))) char pfa_smem[];
+  const int h = blockIdx.x, qt = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int q0 = qt * 16;                              // first query row of the tile (relative to the chunk)
+  const int T = a.pos0 + q0 + 16;                      // keys 0 .. T-1 cover every query of the tile (T % 16 == pos0 % 16)
+  const int Tb = (T + 15) >> 4;                        // key blocks of 16
+  const int ST = Tb * 16 + 4;                          // LDS row stride, floats
+  float* sc = reinterpret_cast<float*>(pfa_smem);      // [16][ST]
+  double* red = reinterpret_cast<double*>(pfa_smem + (size_t)16 * ST * 4);
+  const int dim = a.dim;
+  const unsigned slab = (unsigned)a.seq_len * (unsigned)dim * 4u;
+  const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.kc), 0, slab, 0x00020000);
+  const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vc), 0, slab, 0x00020000);
+
+  // ---- Q fragments of the tile, widened once: lane (j, kq) holds q[q0 + j][h*HS + 16 b + 4 kq + e], b < KB, e < 4
+  double qd[KB][4];
+  {
+    const float* qrow = a.q + (size_t)(q0 + j) * dim + (size_t)h * HS + 4 * kq;
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+      const f4 v = *reinterpret_cast<const f4*>(qrow + 16 * b);
+      qd[b][0] = v.x; qd[b][1] = v.y; qd[b][2] = v.z; qd[b][3] = v.w;
+    }
+  }
+  // ---- scores: key block kb (keys 16 kb .. 16 kb + 15) -> D[query kq + 4 r][key j]
+  const unsigned kvoff = (unsigned)(((size_t)j * dim + (size_t)h * HS + 4 * kq) * 4);     // this lane's element of a 16-row block
+  const unsigned blk = 16u * (unsigned)dim * 4u;                                          // bytes per key block
+  const double rsq = a.inv_sqrt_hs;
+  for (int kb = wave; kb < Tb; kb += 4) {
+    f4 kf[KB];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) kf[b] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff, (unsigned)kb * blk + (unsigned)b * 64u, 0));
+    d4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two chains: a dependent MFMA does not issue back to back
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qd[b][0], (double)kf[b].x, acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qd[b][1], (double)kf[b].y, acc1, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qd[b][2], (double)kf[b].z, acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qd[b][3], (double)kf[b].w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
+    const int t = kb * 16 + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = kq + 4 * r;                        // query row of the tile; its position is pos0 + q0 + qi
+      const float s = (float)(acc[r] * rsq);            // one rounding (llama2.ts:253 divides by sqrt(head_size))
+      sc[qi * ST + t] = (t <= a.pos0 + q0 + qi) ? s : -INFINITY;
+    }
+  }
+  __syncthreads();
+  // ---- softmax per query row (llama2.ts:181-194): wave w owns rows 4w .. 4w + 3
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    float* row = sc + (wave * 4 + rr) * ST;
+    const int nk = a.pos0 + q0 + wave * 4 + rr + 1;     // keys this query sees
+    float mx = -INFINITY;
+    for (int t = lane; t < nk; t += 64) mx = fmaxf(mx, row[t]);
+    mx = wave_max(mx);
+    double lsum = 0.0;
+    for (int t = lane; t < Tb * 16; t += 64) {
+      const float e = (t < nk) ? (float)exp_fast((double)row[t] - (double)mx) : 0.0f;    // stored to fp32 (:187); masked keys contribute nothing
+      row[t] = e;
+      lsum += (double)e;                                                                  // sum of the ROUNDED values (:190)
+    }
+    lsum = wave_sum(lsum);
+    const double rs = rcp_fast(lsum);
+    for (int t = lane; t < nk; t += 64) row[t] = (float)((double)row[t] * rs);            // quotient stored fp32 (:192)
+  }
+  __syncthreads();
+  // ---- xb = P V: wave w owns output columns [w * 16 CT, (w + 1) * 16 CT) of the head; D[query kq + 4 r][column j]
+  d4 o[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) o[c] = d4{0.0, 0.0, 0.0, 0.0};
+  const unsigned vcol = (unsigned)(((size_t)h * HS + (size_t)wave * 16 * CT + j) * 4);    // this lane's column, bytes
+  for (int kb = 0; kb < Tb; ++kb) {
+    const f4 pf = *reinterpret_cast<const f4*>(sc + j * ST + kb * 16 + 4 * kq);          // P[query j][keys 16 kb + 4 kq .. + 3]
+    float vv[CT][4];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)      // V[key 16 kb + 4 kq + e][column]: the key differs per lane, so the row offset rides in the vector offset
+        vv[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrs, vcol + (unsigned)c * 64u + (unsigned)(kb * 16 + 4 * kq + e) * (unsigned)dim * 4u, 0, 0));
+    const double p0 = pf.x, p1 = pf.y, p2 = pf.z, p3 = pf.w;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      o[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, (double)vv[c][0], o[c], 0, 0, 0);
+      o[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, (double)vv[c][1], o[c], 0, 0, 0);
+      o[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(p2, (double)vv[c][2], o[c], 0, 0, 0);
+      o[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(p3, (double)vv[c][3], o[c], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = kq + 4 * r;
+      if (q0 + qi < a.nvalid) a.xb[(size_t)(q0 + qi) * dim + (size_t)h * HS + (size_t)wave * 16 * CT + c * 16 + j] = (float)o[c][r];   // ONE rounding of the fp64 sum
+    }
+  (void)red;
+}
+
 }  // namespace l2k

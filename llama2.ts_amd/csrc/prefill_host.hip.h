@@ -93,7 +93,23 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     launch_pf_gemm<MODE_QKV>(c, a, 4, tt, chunks, st);
     LCHK(hipGetLastError());
     // attention, one workgroup per (head, query) (llama2.ts:244-267)
-    {
+    const size_t alds = pf_attn_lds(pos0 + ((n + 15) & ~15) - 1);
+    if (c->pf_attn && !c->opt_exact && (c->hs == 64 || c->hs == 128) && alds <= 150 * 1024) {
+      // 16 queries per workgroup on the fp64 MFMA (prefill.hip.h: pf_attn_mfma_kernel)
+      PfAttnArgs pa;
+      pa.q = c->pf_q; pa.kc = c->kc + loff; pa.vc = c->vc + loff; pa.xb = c->pf_xb;
+      pa.dim = c->d; pa.head_size = c->hs; pa.seq_len = c->S; pa.pos0 = pos0; pa.nvalid = n;
+      pa.inv_sqrt_hs = 1.0 / sqrt((double)c->hs);
+      const dim3 grid(c->H, (n + 15) / 16);
+      if (c->hs == 128) {
+        LCHK(lds_opt_in(&pf_attn_mfma_kernel<128>, alds));
+        hipLaunchKernelGGL((pf_attn_mfma_kernel<128>), grid, dim3(256), alds, st, pa);
+      } else {
+        LCHK(lds_opt_in(&pf_attn_mfma_kernel<64>, alds));
+        hipLaunchKernelGGL((pf_attn_mfma_kernel<64>), grid, dim3(256), alds, st, pa);
+      }
+      LCHK(hipGetLastError());
+    } else {   // one workgroup per (head, query): the decode kernel (other head sizes, the exact accumulate, very long contexts)
       AttnArgs aa;
       c->cur_splits = 1;
       fill_attn_args(c, l, aa);
