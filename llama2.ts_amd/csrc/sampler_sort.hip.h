@@ -1,0 +1,121 @@
+// sampler_sort.hip.h -- top-p order without a library sort: bitonic tile sort in registers + rank merge out of LDS
+// Part of sampler.hip (included there inside namespace l2s, in order); not a stand-alone header.
+#pragma once
+
+// ---- top-p: descending stable order = ascending order of the key (~probability bits, id)
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void order_pair(u64& a, u64& b, bool up) {
+  const bool sw = (a > b) == up;
+  const u64 lo = sw ? b : a, hi = sw ? a : b;
+  a = lo; b = hi;
+}
+
+// Bitonic sort of one sort tile: SIT consecutive positions per thread, so the small strides stay inside a thread, the
+// middle ones are lane exchanges inside a wave, and only the strides >= 64 * SIT go through LDS.  Measured: 8 keys per
+// thread (2048-key tiles, half as many for the rank merge to search) take 12 us longer here and save 4 us there.
+constexpr int SIT = 4, STILE = TN * SIT;
+template <bool FUSED>
+__global__ void __launch_bounds__(TN) sort_tile_kernel(ChainArgs a, const float* probs, int V, float* run_p, int* run_id) {
+  __shared__ union { ChainShared sh; u64 xch[STILE]; } lds;      // the chain is over before the first exchange (a barrier in between)
+  ChainShared& sh = lds.sh;
+  u64* xch = lds.xch;
+  const int tid = threadIdx.x, base = blockIdx.x * STILE, p0 = tid * SIT;
+  double s = 1.0;
+  if (FUSED) {                                                 // probs holds the exps: every workgroup derives their exact total itself
+    bool in_lds;
+    chain_total(a, sh, &in_lds);
+    s = sh.val;
+  }
+  u64 v[SIT];
+#pragma unroll
+  for (int k = 0; k < SIT; ++k) {
+    const int i = base + p0 + k;
+    const float e = (i < V) ? probs[i] : 0.0f;
+    const float p = FUSED ? (float)((double)e / s) : e;                      // :192
+    v[k] = (i < V) ? (((u64)(0xffffffffu - __float_as_uint(p)) << 32) | (unsigned)i) : ~0ull;
+  }
+#pragma unroll
+  for (int k2 = 2; k2 <= STILE; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      if (j < SIT) {
+#pragma unroll
+        for (int k = 0; k < SIT; ++k) if ((k & j) == 0) order_pair(v[k], v[k | j], ((p0 + k) & k2) == 0);
+      } else {
+        const bool keep_min = ((p0 & j) == 0) == ((p0 & k2) == 0);
+        u64 o[SIT];
+        if (j < 64 * SIT) {
+#pragma unroll
+          for (int k = 0; k < SIT; ++k) o[k] = __shfl_xor(v[k], j / SIT, 64);
+        } else {
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < SIT; ++k) xch[p0 + k] = v[k];
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < SIT; ++k) o[k] = xch[(p0 ^ j) + k];
+        }
+#pragma unroll
+        for (int k = 0; k < SIT; ++k) v[k] = keep_min ? (v[k] < o[k] ? v[k] : o[k]) : (v[k] > o[k] ? v[k] : o[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SIT; ++k) {
+    const bool pad = v[k] == ~0ull;
+    run_p[base + p0 + k] = pad ? -1.0f : __uint_as_float(0xffffffffu - (unsigned)(v[k] >> 32));
+    run_id[base + p0 + k] = pad ? -1 : (int)(unsigned)v[k];
+  }
+}
+
+// Every element's place in the merged order: its place in its own tile + the number of elements of every other tile
+// in front of it (ties: the tile with the smaller ids first), by binary search in the G sorted tiles held in LDS.
+constexpr int RT = 512;                                           // threads = elements per workgroup of the rank merge (256 and 1024: the same time)
+// Also adds every element to the sum of the tile of the merged order it lands in (part[], zero on entry): the approximate
+// prefix of the next stage.  fp64 atomics in no fixed order -- the prefix only has to be approximate (exact_sum.h).
+__global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const int* run_id, int GS, int G, float* sorted, int* ids, double* part) {
+  extern __shared__ int lds_p[];                                // GS * STILE probability bit patterns (pads: negative), then G tile sums
+  const int tid = threadIdx.x, n = GS * STILE;
+  double* lpart = reinterpret_cast<double*>(lds_p + n);
+  if (tid < G) lpart[tid] = 0.0;
+  // every workgroup pulls all G tiles; measured: one 16-byte load in flight per thread (8 KB per workgroup) beats 4, 8 and 16
+  // (+5 / +5 / +8 us) -- the same lines are wanted by every CU at once and deeper queues only lengthen the wait behind them;
+  // an LDS-DMA fill (global_load_lds_dwordx4, every 1 KB chunk in flight at once) takes the same time as this loop
+  for (int j = tid * 4; j < n; j += RT * 4) *reinterpret_cast<int4*>(lds_p + j) = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(run_p) + j);
+  const int e = blockIdx.x * RT + tid;
+  const int my_id = e < n ? run_id[e] : -1;
+  __syncthreads();
+  const int mine = e < n ? lds_p[e] : -1;
+  if (mine >= 0) {                                              // not a pad
+  const int own = e / STILE;
+  int rank = e - own * STILE;
+  constexpr int U = 8;                                          // searches in flight per thread
+  for (int b0 = 0; b0 < GS; b0 += U) {
+    int lo[U], thr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = min(b0 + u, GS - 1);
+      lo[u] = b * STILE;
+      thr[u] = mine - (b < own ? 1 : 0);                        // earlier tile: elements >= mine come first; later tile: only > mine
+    }
+#pragma unroll
+    for (int s = STILE / 2; s > 0; s >>= 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (lds_p[lo[u] + s - 1] > thr[u]) lo[u] += s;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = min(b0 + u, GS - 1);
+      int cnt = lo[u] - b * STILE;
+      if (cnt == STILE - 1 && lds_p[lo[u]] > thr[u]) cnt = STILE;
+      if (b0 + u < GS && b != own) rank += cnt;
+    }
+  }
+  sorted[rank] = __int_as_float(mine);
+  ids[rank] = my_id;
+  atomicAdd(lpart + rank / TILE, (double)__int_as_float(mine));
+  }
+  __syncthreads();
+  if (tid < G && lpart[tid] != 0.0) atomicAdd(part + tid, lpart[tid]);
+}
