@@ -97,9 +97,9 @@ int l2_create_ex(const int32_t cfg[7], int device, unsigned flags, l2_ctx** out)
  * [rank*H/G, ...).  `nccl_id` is the 128-byte ncclUniqueId produced by l2_tp_unique_id on rank 0 and
  * handed to the others by the caller (e.g. over torch.distributed).  tp_size 1 == l2_create. */
 int l2_tp_unique_id(void* id_out_128);
-/* How this context's tensor-parallel step runs: 0 not tensor parallel, 1 eager launches with RCCL collectives,
- * 3 one hipGraph per token with the one-shot peer-to-peer all-reduce, 4 loopback test group (L2_TEST_HOOKS).
- * (2 is not used: RCCL collectives are not captured into the graph.) */
+/* How this context's tensor-parallel step runs: 0 not tensor parallel, 1 eager launches with RCCL collectives (this RCCL
+ * refused stream capture, or L2_USE_GRAPH=0), 2 one hipGraph per token with the RCCL collectives captured in it, 3 one hipGraph
+ * per token with the one-shot peer-to-peer all-reduce, 4 loopback test group (L2_TEST_HOOKS). */
 int l2_tp_mode(l2_ctx* ctx);
 int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out);
 

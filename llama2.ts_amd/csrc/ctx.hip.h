@@ -144,6 +144,7 @@ struct l2_ctx {
   P2PPeers p2p_peers = {};
   std::vector<void*> p2p_opened;     // IPC mappings to close
   bool p2p_peers_ready = false;
+  bool rccl_graph = false;           // the RCCL collectives of the step are captured into the per-token hipGraph (cleared if capture is refused)
   unsigned long long p2p_wait_ticks = 3000000000ull;   // L2_TP_WAIT_S (default 30 s) on the 100 MHz clock
   bool p2p_synced = false;           // the ranks have met once (host side) right before the first exchange of a step
   bool broken = false;               // a peer-to-peer wait gave up: this rank's epochs no longer match its peers'

@@ -258,6 +258,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     if (rc) { l2_destroy(c); return rc; }
   }
   if (c->p2p && !c->loop && !getenv("L2_USE_GRAPH")) c->opt_graph = 1;   // nothing but kernels in the step: one hipGraph per token
+  if (c->tp_path && !c->p2p && !c->loop && c->comm && !getenv("L2_USE_GRAPH")) { c->opt_graph = 1; c->rccl_graph = true; }   // RCCL collectives captured with the step (eager if capture is refused)
   if (c->loop) c->opt_graph = 0;                                          // host barriers between the halves of an exchange
   *out = c;
   return L2_OK;
@@ -305,7 +306,7 @@ extern "C" int l2_tp_mode(l2_ctx* c) {
   if (!c || !c->tp_path) return 0;
   if (c->loop) return 4;
   if (c->p2p) return 3;
-  return 1;
+  return (c->rccl_graph && c->opt_graph) ? 2 : 1;
 }
 
 extern "C" int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out) {
@@ -495,7 +496,9 @@ static int enqueue_sample(l2_ctx* c, hipStream_t st) {  // device-resident sampl
   return L2_OK;
 }
 
-static int capture(l2_ctx* c, int (*enq)(l2_ctx*, hipStream_t), hipGraphExec_t* out) {
+enum { L2_RUN_EAGER = 1 };   // capture(): the step cannot be captured on this context (RCCL collectives that refuse capture): launch it eagerly from now on
+
+static int capture_impl(l2_ctx* c, int (*enq)(l2_ctx*, hipStream_t), hipGraphExec_t* out) {
   hipGraph_t graph = nullptr;
   LCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = enq(c, c->stream);
@@ -506,6 +509,21 @@ static int capture(l2_ctx* c, int (*enq)(l2_ctx*, hipStream_t), hipGraphExec_t* 
   hipGraphDestroy(graph);
   if (e != hipSuccess) return fail(L2_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
   return L2_OK;
+}
+
+// A tensor-parallel step whose exchanges are RCCL collectives is captured like any other (one graph launch per token instead
+// of ~290 host-issued launches); if this RCCL refuses stream capture the context falls back to eager launches for good.
+static int capture(l2_ctx* c, int (*enq)(l2_ctx*, hipStream_t), hipGraphExec_t* out) {
+  const int rc = capture_impl(c, enq, out);
+  if (rc && c->rccl_graph) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    c->rccl_graph = false; c->opt_graph = 0;
+    destroy_graphs(c);
+    hipStreamSynchronize(c->stream);
+    return L2_RUN_EAGER;
+  }
+  return rc;
 }
 
 extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
@@ -522,7 +540,9 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
   const int lvl = split_level(c, pos);
   c->cur_splits = splits_of(c, lvl);
   if (c->opt_graph) {
-    if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc) return rc; }
+    if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc && rc != L2_RUN_EAGER) return rc; }
+  }
+  if (c->opt_graph) {
     HIPCHK(hipGraphLaunch(c->g_step[lvl], c->stream));
   } else {
     rc = enqueue_forward_host(c, c->stream);
@@ -555,7 +575,7 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   if (c->opt_graph) {   // capture what this run needs before the timed region
     for (int s = 0; s < steps; ++s) {
       const int lvl = split_level(c, pos0 + s);
-      if (!c->g_greedy[lvl]) { c->cur_splits = splits_of(c, lvl); rc = capture(c, enqueue_greedy, &c->g_greedy[lvl]); if (rc) return rc; }
+      if (!c->g_greedy[lvl]) { c->cur_splits = splits_of(c, lvl); rc = capture(c, enqueue_greedy, &c->g_greedy[lvl]); if (rc == L2_RUN_EAGER) break; if (rc) return rc; }
     }
   }
   if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
@@ -609,8 +629,10 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
     c->cur_splits = splits_of(c, lvl);
     if (graph) {
       hipGraphExec_t& g = c->g_sample[lvl][c->samp_mode + (c->samp_amax ? 2 : 0)];
-      if (!g) { rc = capture(c, enqueue_sample, &g); if (rc) return rc; }
-      HIPCHK(hipGraphLaunch(g, c->stream));
+      if (!g) { rc = capture(c, enqueue_sample, &g); if (rc && rc != L2_RUN_EAGER) return rc; }
+    }
+    if (graph && c->opt_graph) {
+      HIPCHK(hipGraphLaunch(c->g_sample[lvl][c->samp_mode + (c->samp_amax ? 2 : 0)], c->stream));
     } else {
       rc = enqueue_sample(c, c->stream);
       if (rc) return rc;

@@ -269,6 +269,7 @@ class Context:
     def tp_mode(self):
         """How the tensor-parallel step runs (l2_tp_mode): none / RCCL eager / peer-to-peer in a graph / loopback test group."""
         return {0: "single GPU", 1: "eager launches, 2L RCCL fp64 all-reduces + 1 all-gather per token",
+                2: "one hipGraph per token with the RCCL collectives captured in it",
                 3: "one hipGraph per token, one-shot peer-to-peer fp64 all-reduce inside the residual kernels",
                 4: "loopback test group"}.get(lib().l2_tp_mode(self._h), "?")
 

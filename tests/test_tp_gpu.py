@@ -54,7 +54,8 @@ def test_rank_slices_match_plan(G):
 @pytest.mark.parametrize("collective", ["rccl", "p2p"])
 def test_one_rank_communicator(collective):
     """L2_TP_FORCE_COMM=1: a 1-rank RCCL communicator drives the tensor-parallel code path on a single GPU --
-    `rccl`: fp64 partials, ncclAllReduce(double, sum), residual kernel, ncclAllGather of the logits, eager launches;
+    `rccl`: fp64 partials, ncclAllReduce(double, sum), residual kernel, ncclAllGather of the logits, captured into the
+    per-token graph (or eager launches where RCCL refuses capture);
     `p2p`: IPC handles through ncclAllGather, the self-test, then the one-shot exchange kernels inside one captured
     graph per token.  Results must match the goldens of the TRUE reference like the ordinary path does."""
     import json
@@ -64,7 +65,9 @@ def test_one_rank_communicator(collective):
     os.environ["L2_TP_ALLREDUCE"] = collective
     try:
         ctx = runtime.Context(meta["header"])
-        assert ctx.tp_mode().startswith("one hipGraph per token, one-shot peer-to-peer" if collective == "p2p" else "eager launches")
+        # rccl: the collectives are captured into the per-token graph when this RCCL allows stream capture (mode 2), else launched eagerly (mode 1)
+        assert ctx.tp_mode_id() == 3 if collective == "p2p" else ctx.tp_mode_id() in (1, 2)
+        print("\n[one-rank communicator, %s] %s" % (collective, ctx.tp_mode()))
         ctx.synth_fill(meta["seed"])
         for pos, tok in enumerate(meta["tokens_fed"][:24]):
             got = np.array(ctx.forward(tok, pos), copy=True)
