@@ -256,6 +256,12 @@ def secondary_config(name, seed, device, with_cpu, traffic):
     S = hdr[6]
     ms = ctx.bench_decode(1, 0, S)
     out["whole_context_tok_s"] = round(S / (ms * 1e-3), 2)
+    for key, n_p in (("prefill_tok_s", min(128, S)), ("prefill_256_tok_s", min(256, S))):     # prompt ingestion, as in the main block
+        ptoks = (np.arange(n_p, dtype=np.int32) * 7919 + 2) % cfg.vocab_size
+        ctx.prefill(ptoks, 0)
+        t0 = time.perf_counter()
+        ctx.prefill(ptoks, 0)
+        out[key] = round(n_p / (time.perf_counter() - t0), 1)
     ctx.close()
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(name, hdr, seed)
