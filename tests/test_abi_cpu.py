@@ -73,3 +73,35 @@ def test_config_reader_and_shapes():
     assert 28 + 4 * total == configs.checkpoint_bytes(cfg.header) == 26954711068
     cfg = runtime.readConfig(struct.pack("<7i", *configs.header("stories15M")))
     assert cfg.shared_weights and 28 + 4 * sum(max(l, 1) * n for _, l, n in runtime.tensor_shapes(cfg)) == 60816028
+
+
+def test_bun_ffi_snippet_matches_the_header():
+    """INTEGRATION.md section 2 (bun:ffi) cannot be executed here (no Bun in the image); what can be checked is that every symbol it
+    binds exists in the header with the same number of parameters and compatible kinds (ptr <-> pointer / array, i32 <-> int,
+    u64 <-> size_t / uint64_t) and the same return kind."""
+    hdr = open(os.path.join(ROOT, "include", "llama2_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    snippet = doc[doc.index("## 2. bun:ffi"):doc.index("## 3.")]
+    bound = re.findall(r"(l2_[a-z_]+):\s*\{\s*args:\s*\[([^\]]*)\],\s*returns:\s*FFIType\.(\w+)", snippet)
+    assert {b[0] for b in bound} >= {"l2_create", "l2_upload", "l2_forward", "l2_last_error", "l2_destroy"}
+
+    def kind(ctype):
+        t = ctype.strip()
+        if "*" in t or "[" in t:
+            return "ptr"
+        if re.search(r"\b(size_t|uint64_t)\b", t):
+            return "u64"
+        if re.search(r"\b(int|int32_t|unsigned|uint32_t)\b", t):
+            return "i32"
+        raise AssertionError("unmapped C type: %r" % t)
+
+    for name, args, ret in bound:
+        m = re.search(r"([\w \*]+?)\b%s\s*\(([^)]*)\)\s*;" % name, hdr)
+        assert m, name
+        params = [p for p in m.group(2).split(",") if p.strip() and p.strip() != "void"]
+        ffi = [a.strip().replace("FFIType.", "") for a in args.split(",") if a.strip()]
+        assert [kind(p) for p in params] == ffi, (name, params, ffi)
+        rt = m.group(1).strip()
+        want = "cstring" if "char" in rt else ("void" if rt.endswith("void") else "i32")
+        assert ret == want, (name, rt, ret)
