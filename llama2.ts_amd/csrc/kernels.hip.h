@@ -503,19 +503,10 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
       }
     }
   };
-#ifdef L2_PRE2
-  // EXPERIMENT: the second batch is requested before the prologue as well (both register sets in flight while x is normalised)
-  int g1 = g0, c1 = c0, r1 = r0;
-  bool h1 = h0;
-  if (h0) next(g1, c1, h1, r1);
-#endif
   {
     f4 xr[PRE], wr[PRE];
     stage_load(xr, wr, 0);
     issue(bufA, h0 ? g0 : groups - 1, h0 ? col(c0, r0) : 0);
-#ifdef L2_PRE2
-    issue(bufB, h1 ? g1 : (h0 ? g0 : groups - 1), h1 ? col(c1, r1) : (h0 ? col(c0, r0) : 0));
-#endif
     STAMP(1);
     stage_store(xr, wr, 0);
     STAMP(2);
@@ -571,31 +562,6 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   // (Pre-issuing two batches costs ~20 VGPRs and one wave per SIMD of occupancy: measured slower.)
   int g = g0, ch = c0, rg = r0;
   bool have = h0;
-#ifdef L2_PRE2
-  // A holds batch k, B batch k + 1 on entry of every iteration; each is refilled (two batches ahead) right after it is consumed
-  while (have) {
-    int g2 = g, ch2 = ch, rg2 = rg;
-    bool have2 = true;
-    next(g2, ch2, have2, rg2);
-    int g3 = g2, ch3 = ch2, rg3 = rg2;
-    bool have3 = have2;
-    if (have2) next(g3, ch3, have3, rg3);
-    finish();
-    consume(bufA, col(ch, rg));
-    STAMP(5);
-    if (ch == nchunks - 1) stash(g);
-    issue(bufA, have3 ? g3 : g, have3 ? col(ch3, rg3) : col(ch, rg));   // unconditional: keeps the wait counts uniform
-    if (!have2) break;
-    int g4 = g3, ch4 = ch3, rg4 = rg3;
-    bool have4 = have3;
-    if (have3) next(g4, ch4, have4, rg4);
-    finish();
-    consume(bufB, col(ch2, rg2));
-    if (ch2 == nchunks - 1) stash(g2);
-    issue(bufB, have4 ? g4 : g2, have4 ? col(ch4, rg4) : col(ch2, rg2));
-    g = g3; ch = ch3; rg = rg3; have = have3;
-  }
-#else
   while (have) {
     int g2 = g, ch2 = ch, rg2 = rg;
     bool have2 = true;
@@ -615,7 +581,6 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
     if (ch2 == nchunks - 1) stash(g2);
     g = g3; ch = ch3; rg = rg3; have = have3;
   }
-#endif
   finish();
   if (MODE == MODE_CLS && a.amax) {
     // greedy loop: ONE memory-side maximum per workgroup (no value returned, nothing waits for it); the launch
