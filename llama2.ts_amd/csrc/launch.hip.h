@@ -97,7 +97,9 @@ static hipError_t launch_small_xv(const l2_ctx* c, const PhaseArgs& a, hipStream
   const bool r1 = !pair && a.rows <= waves;
   const int rpg = (MODE == MODE_W13) ? 1 : (r1 ? 1 : 2);
   const int groups = (a.rows + rpg - 1) / rpg;
-  int grid = (groups + 6) / 7;
+  // one workgroup per CU as soon as there are that many row groups: fewer busy waves per CU beat fewer CUs (the CU's 64 B / clock
+  // address path is what a 7-wave workgroup queues on): stories15M 8 660 -> 8 945 tok/s, stories110M +0.7 % (profiles/r03/ab_small_kernel_grid.txt)
+  int grid = groups;
   if (grid > c->n_cus) grid = c->n_cus;
   if (grid < 1) grid = 1;
   if (!pair && r1) launch_probed(c, phase_small_kernel<MODE, XV, pair ? 2 : 1>, dim3(grid), dim3(512), lds, st, a, MODE == MODE_W13);
