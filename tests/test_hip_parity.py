@@ -113,6 +113,49 @@ def test_whole_context_matches_reference_goldens(built, name):
     ctx.close()
 
 
+def _random_headers(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        H = int(rng.choice([1, 2, 3, 4, 6, 8]))
+        hs = int(rng.choice([2, 4, 6, 8, 10, 16, 22, 32, 48, 64, 128]))
+        d = H * hs
+        if d > 512:
+            continue
+        h = int(rng.integers(d // 2 + 1, 3 * d + 2))
+        L = int(rng.integers(1, 4))
+        V = int(rng.integers(17, 700)) * int(rng.choice([-1, 1]))
+        S = int(rng.integers(3, 200))
+        out.append((d, h, L, H, H, V, S))
+    return out
+
+
+@pytest.mark.parametrize("hdr", _random_headers(14, 20261003))
+def test_random_shapes_match_the_oracle(built, hdr):
+    """Shapes nobody tuned for -- odd hidden sizes, head sizes that are not powers of two or not multiples of 4 (scalar kernels),
+    one head, vocabularies that are not multiples of anything, shared and unshared classifiers, contexts shorter than a tile --
+    against the oracle (itself pinned to the reference): logits <= 1e-4 and the same argmax at every step of the whole context
+    (up to 40 steps), l2_forward and the device greedy loop, then the same prompt through l2_prefill."""
+    orc = O.Oracle(hdr, 7)
+    ctx = runtime.Context(hdr)
+    upload_from_oracle(ctx, orc)
+    steps = min(hdr[6], 40)
+    tok, fed = 1, []
+    for pos in range(steps):
+        fed.append(tok)
+        got = ctx.forward(tok, pos)
+        want = orc.forward(tok, pos)
+        assert np.abs(got - want).max() <= TOL, (hdr, pos)
+        assert runtime.argmax(got) == O.argmax(want), (hdr, pos)
+        tok = O.argmax(want)
+    assert ctx.decode_greedy(1, 0, steps).tolist() == fed[1:] + [tok]
+    b = runtime.Context(hdr)
+    upload_from_oracle(b, orc)
+    lp = b.prefill(fed, 0)
+    assert np.abs(lp - want).max() <= TOL and runtime.argmax(lp) == tok
+    ctx.close(); b.close(); orc.close()
+
+
 def test_full_llama2_7b_matches_reference_golden(built):
     """BASELINE.json config 4 itself -- all 32 layers, 27 GB of weights: the reference's first three steps (it runs
     6 s per token and needs the whole file in host memory), logits at pos 0 and 2 and every argmax."""
