@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
 // w1 / w3) x TT accumulators in AGPRs), takes all operands through buffer loads whose per-block / per-tile offsets are SCALAR
 // (no vector address arithmetic, no exec masks: every wave runs whole batches), and the NW waves of a workgroup split K; their
 // partial tiles are added in wave order through LDS, one weight stream at a time (64 KB at NW = 8), by NW waves in parallel.
-// Requires n % 64 == 0 and (rows / 16) % RT == 0; other shapes take pf_gemm_kernel.
+// Requires n % 32 == 0 (whole batches of two blocks) and (rows / 16) % RT == 0; other shapes take pf_gemm_kernel.
 // One k-step of a wave's NS x 4 output tiles as ONE asm statement: acc[s][t] += x[t] (A operand, 16 tokens) * w[s] (B operand, 16 rows).
 // The accumulators are pinned in AGPRs ("+a"): left to hipcc, the loop-carried tiles live in VGPRs and are copied to AGPRs and
 // back around every iteration (64 - 96 v_accvgpr_write per 128 - 192 MFMAs -- on the very pipe the MFMAs need).  What hipcc does
@@ -380,10 +380,7 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   }
   constexpr bool DUAL = (MODE == MODE_W13);
   constexpr int NS = DUAL ? 2 * RT : RT;             // weight streams of the wave: row tiles (w1 tile r, w3 tile r, ... when DUAL)
-#ifndef L2_PF3_UN12
-#define L2_PF3_UN12 2
-#endif
-  constexpr int UN = (NS <= 2) ? L2_PF3_UN12 : 2;    // 16-column blocks per batch (two batches in flight)
+  constexpr int UN = 2;                              // 16-column blocks per batch, two batches in flight (4 blocks: occupancy 2 -> 1 for w1 / w3, 215 -> 232 us)
   extern __shared__ __attribute__((aligned(16))) double part3[];     // [TT][NW][4][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.n, npair = (n >> 4) / UN;

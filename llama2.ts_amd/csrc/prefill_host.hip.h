@@ -17,8 +17,9 @@ static void launch_pf3(const PfArgs& a, int chunks, hipStream_t st) {
   hipLaunchKernelGGL((pf_gemm3_kernel<MODE, NW, RT, 4>), dim3(a.rows / (16 * RT), chunks), dim3(64 * NW), lds, st, a);
 }
 
-// Shapes the register-blocked GEMMs cover: whole 64-column batches (n % 64) of both input widths and qkv's 3 d / 16 row tiles in threes.
-static bool pf3_ok(const l2_ctx* c) { return c->pf3 && c->d % 64 == 0 && c->h % 64 == 0 && (3 * c->d / 16) % 3 == 0; }
+// Shapes the register-blocked GEMMs cover: whole batches of two 16-column blocks (n % 32) of both input widths (qkv's 3 d / 16 row
+// tiles always come in threes).  stories15M (288 / 768) qualifies; the test shapes with hidden sizes like 176 keep the 16-row-tile kernels.
+static bool pf3_ok(const l2_ctx* c) { return c->pf3 && c->d % 32 == 0 && c->h % 32 == 0; }
 
 template <int MODE>
 static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int chunks, hipStream_t st) {
