@@ -369,8 +369,17 @@ def main():
             except (OSError, ValueError, KeyError):
                 return None
 
+        attempts = [0]
+        ipc_base = os.environ.get("L2_TP_IPC_DIR")      # set from outside (tests): every attempt then meets in a directory of its own
+
         def attempt(env, fresh_id=True):
             err, c, toks = "", None, []
+            attempts[0] += 1
+            env = dict(env)
+            if ipc_base and os.path.isdir(ipc_base) and "L2_TP_IPC_DIR" not in env:
+                sub = os.path.join(ipc_base, "attempt%d" % attempts[0])     # files of an earlier, failed formation must not be read again
+                os.makedirs(sub, exist_ok=True)
+                env["L2_TP_IPC_DIR"] = sub
             for k, v in env.items():
                 os.environ[k] = v
             try:
@@ -409,6 +418,8 @@ def main():
             finally:
                 for k in env:
                     os.environ.pop(k, None)
+                if ipc_base:
+                    os.environ["L2_TP_IPC_DIR"] = ipc_base
 
         notes = []
         ctx, why, tp_proof = attempt({})
