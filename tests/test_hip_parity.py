@@ -460,6 +460,33 @@ def test_prefill_ragged_chunk_counts_at_110m_width(built, n, first):
     a.close(); b.close()
 
 
+def test_prefill_of_the_whole_7b_width_context(built):
+    """All 2048 positions of the 7B-width golden through l2_prefill in ONE call (eight launch sequences of 256; the last query
+    tile sees 2048 keys: 131 KB of score rows in LDS): logits of the last position and of position 1919 (a second context fed
+    1920 tokens) against the TRUE reference, the KV cache of the last 128 positions against token-by-token decoding from 1920 on."""
+    meta, g = load_gold("llama2_7b_L2")
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    fed = meta["tokens_fed"]
+    a = runtime.Context(meta["header"]); a.synth_fill(meta["seed"])
+    la = np.array(a.prefill(fed[:2048], 0), copy=True)
+    assert np.abs(la - g["logits"][keep[2047]]).max() <= TOL and runtime.argmax(la) == meta["argmax"][2047]
+    b = runtime.Context(meta["header"]); b.synth_fill(meta["seed"])
+    lb = np.array(b.prefill(fed[:1920], 0), copy=True)
+    assert np.abs(lb - g["logits"][keep[1919]]).max() <= TOL
+    tok = runtime.argmax(lb)
+    for pos in range(1920, 2048):                     # the rest one transformer() call per token, as the reference does
+        assert tok == fed[pos]
+        lb = b.forward(tok, pos)
+        tok = runtime.argmax(lb)
+    assert np.abs(lb - la).max() <= 1e-5
+    d, S, L = a.cfg.dim, a.cfg.seq_len, a.cfg.n_layers
+    for nm in ("key_cache", "value_cache"):
+        ca = a.read_state(nm).reshape(L, S, d)[:, 1920:]
+        cb = b.read_state(nm).reshape(L, S, d)[:, 1920:]
+        assert np.abs(ca - cb).max() <= 1e-6, nm
+    a.close(); b.close()
+
+
 def test_prefill_prompt_golden_and_errors(built):
     meta, g = load_gold("stories15M_prompt")          # -i "Once upon a time": BOS + 4 prompt ids are teacher-forced
     ctx = runtime.Context(meta["header"]); ctx.synth_fill(meta["seed"])
