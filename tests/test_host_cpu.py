@@ -63,3 +63,14 @@ def test_synthetic_tokenizer_is_deterministic(tmp_path):
     h = hashlib.sha256(open(tmp_path / "t.bin", "rb").read()).hexdigest()
     v2, _ = synth_tokenizer.write(str(tmp_path / "t2.bin"))
     assert v2 == v and hashlib.sha256(open(tmp_path / "t2.bin", "rb").read()).hexdigest() == h
+
+
+def test_typescript_declarations_cover_the_addon(built):
+    """l2_napi.d.ts (for hosts that stay TypeScript) declares exactly the functions the addon exports."""
+    import re
+    dts = open(os.path.join(ROOT, "llama2.ts_amd", "host", "l2_napi.d.ts")).read()
+    declared = sorted(set(re.findall(r"export function (\w+)\(", dts)))
+    js = "console.log(Object.keys(require(%r)).sort().join(','))" % os.path.join(ROOT, "llama2.ts_amd", "host", "l2_napi.node")
+    r = subprocess.run(["node", "-e", js], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert declared == r.stdout.decode().strip().split(",")
