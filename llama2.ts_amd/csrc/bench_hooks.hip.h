@@ -86,6 +86,7 @@ extern "C" int l2_bench_gemv(l2_ctx* c, int kind, int layer, int iters, float* a
       a.n = c->d; a.rows = c->V_loc; break;
     default: return fail(L2_E_ARG, "tensor kind %d is not a GEMV matrix", kind);
   }
+  a.wp = packed_of(c, mode, mode == MODE_CLS ? 0 : layer);
   for (int it = -2; it < iters; ++it) {
     if (it == 0) HIPCHK(hipEventRecord(c->ev0, c->stream));
     hipError_t e;

@@ -192,6 +192,11 @@ struct l2_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // tuning overrides (env)
   int tune_R = 0, tune_U = 0, tune_nwaves = 0, tune_gridcap = 0, tune_rot = 5;
+  // Streaming-form matrices repacked in consumption order (kernels.hip.h, phase_body PK): a second copy, per phase (MODE_*),
+  // built on the device from the row-major tensors (which prefill, the embedding gather and l2_read_tensor keep using).
+  struct Packed { float* buf = nullptr; size_t layer_elems = 0; int U = 0, nwaves = 0, grid = 0; } packed[5];
+  bool packed_valid = false;        // false after any upload: rebuilt before the next step
+  int opt_packed = 1;               // L2_PACKED=0: stream the row-major tensors (A/B)
 };
 
 static bool is_layered(int kind) { return kind >= L2_T_RMS_ATT && kind <= L2_T_W3; }

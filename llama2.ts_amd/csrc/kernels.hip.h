@@ -98,6 +98,7 @@ struct PhaseArgs {
   double* partial;    // non-null (WO/W2 of a tensor-parallel rank): out[i] is not written, partial[i] = fp64 sum
   double inv_n;       // 1.0 / n, correctly rounded by the host (rmsnorm's mean, llama2.ts:174)
   int rot;            // streaming form: row group g starts its rows at column batch (g * rot) % batches and wraps (0: every row from column 0)
+  const float* wp;    // streaming form: this launch's matrix (matrices) repacked in the order the chip consumes it (pack_kernel), or null
   unsigned long long* amax;  // CLS of the greedy loop: 8 argmax keys (one per 128-byte line) the workgroups fold their best logit into, or null
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
   unsigned long long* dbg_wg;  // the same: {start, end} of every workgroup
@@ -406,14 +407,22 @@ __device__ __forceinline__ constexpr bool mode_has_norm() { return MODE == MODE_
 // in-order load queue into counted `s_waitcnt vmcnt(R*U)` waits, so ~2*R*U KiB per wave stay in flight.
 // Vector path: n % 4 == 0 (every real checkpoint).  LDS: xs[npad4] float4 (zero padded to whole batches),
 // ws[n4] float4 (norm weight, norm modes only), 8 doubles of reduction scratch.
-template <int MODE, int R, int U, int PRE>
+//
+// PK: the matrix comes from `a.wp`, REPACKED in consumption order (pack_kernel below): [round][column batch][wave][row of the
+// group][u][lane] float4, round = the wave's row groups in turn.  All waves of the (co-resident) grid march through their
+// batches in step, so what the chip asks for at one moment is ONE contiguous stretch (2048 waves x 4 KB = 8 MB) moving through
+// memory, as in a plain copy -- instead of 4096 pieces of 2 KB a whole row apart.  tools/microbench_rows.hip: 55.3 -> 51.6 us
+// for the w1/w3 shape of Llama-2-7B (rows + rotation vs packed, FMAs included), 31.9 -> 30.2 wqkv, 29.2 -> 27.7 w2,
+// 12.4 -> 11.7 wo; a grid-stride copy takes 53.3 / 30.7 / 27.7 / 11.4.  Same rows to the same waves, same columns to the
+// same lanes in the same order: the arithmetic is untouched.  Needs n % 256 == 0 (whole 64-lane sub-batches).
+template <int MODE, int R, int U, int PRE, bool PK = false>
 __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const int vblock, const int vgrid) {
   constexpr int CPI = 64 * U;                       // float4 per row per batch
   const int n = a.n, n4 = n >> 2;
   const int nchunks = (n4 + CPI - 1) / CPI;
   const int npad4 = nchunks * CPI;
   // PRE = float4 per thread per staging round, picked by the host so one round covers the vector
-  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
   const int nstage4 = ((npad4 + PRE * nthreads - 1) / (PRE * nthreads)) * (PRE * nthreads);  // whole staging rounds
   f4* xs4 = reinterpret_cast<f4*>(smem);
   f4* ws4 = xs4 + nstage4;
@@ -426,7 +435,21 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   STAMP_INIT_WG(a.dbg, a.dbg_wg);
   STAMP(0);
   f4 bufA[R][U], bufB[R][U];
-  auto issue = [&](f4 (&buf)[R][U], int gi, int ci) {
+  const int ulast = (n4 - (nchunks - 1) * CPI) >> 6;   // PK: 64-lane sub-batches of a row's last batch
+  // rnd (PK only) = which of its row groups the wave is at: gi = (place in the round) + rnd * wstride
+  auto issue = [&](f4 (&buf)[R][U], int gi, int ci, int rnd) {
+    if (PK) {
+      const int nwr = min(wstride, groups - rnd * wstride);        // row groups of this round (the last one may be short)
+      const int uc = (ci == nchunks - 1) ? ulast : U;
+      const f4* base = reinterpret_cast<const f4*>(a.wp) + ((size_t)rnd * wstride * R * n4 + (size_t)nwr * (R * CPI) * ci + (size_t)(gi - rnd * wstride) * (R * 64) * uc);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int uu = (u < uc) ? u : 0;                           // past the row's end: re-read the first sub-batch (x there is 0)
+#pragma unroll
+        for (int r = 0; r < R; ++r) buf[r][u] = __builtin_nontemporal_load(base + (r * uc + uu) * 64 + lane);
+      }
+      return;
+    }
     const float* rp[R];
     row_ptrs<MODE, R>(a, gi, n, rp);
 #pragma unroll
@@ -458,10 +481,11 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   // Every wave starts its rows at another column batch and wraps around: with all waves marching through their rows in step,
   // the chip's requests of one moment sit a whole row (a power of two of bytes) apart and crowd the same HBM channels
   // (tools/microbench_rows.hip: 56.5 -> 54.2 us for the w1/w3 shape).  ci counts batches, col(gi, ci) is where batch ci lies.
-  auto rot_of = [&](int gi) { return a.rot ? (int)((unsigned)(gi * a.rot) % (unsigned)nchunks) : 0; };
-  auto col = [&](int ci, int rg) { const int c = ci + rg; return c >= nchunks ? c - nchunks : c; };
+  // (PK: no rotation -- the layout is what spreads the requests; `rg` then counts the wave's rounds instead)
+  auto rot_of = [&](int gi) { return (!PK && a.rot) ? (int)((unsigned)(gi * a.rot) % (unsigned)nchunks) : 0; };
+  auto col = [&](int ci, int rg) { if (PK) return ci; const int c = ci + rg; return c >= nchunks ? c - nchunks : c; };
   auto next = [&](int& gi, int& ci, bool& hv, int& rg) {
-    if (++ci == nchunks) { ci = 0; gi += wstride; rg = rot_of(gi); }
+    if (++ci == nchunks) { ci = 0; gi += wstride; rg = PK ? rg + 1 : rot_of(gi); }
     hv = gi < groups;
   };
   const int g0 = vblock * nwaves + wave, c0 = 0;
@@ -506,7 +530,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   {
     f4 xr[PRE], wr[PRE];
     stage_load(xr, wr, 0);
-    issue(bufA, h0 ? g0 : groups - 1, h0 ? col(c0, r0) : 0);
+    issue(bufA, h0 ? g0 : groups - 1, h0 ? col(c0, r0) : 0, h0 ? 0 : (groups - 1) / wstride);
     STAMP(1);
     stage_store(xr, wr, 0);
     STAMP(2);
@@ -566,7 +590,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
     int g2 = g, ch2 = ch, rg2 = rg;
     bool have2 = true;
     next(g2, ch2, have2, rg2);
-    issue(bufB, have2 ? g2 : g, have2 ? col(ch2, rg2) : col(ch, rg));   // unconditional: keeps the wait counts uniform
+    issue(bufB, have2 ? g2 : g, have2 ? col(ch2, rg2) : col(ch, rg), have2 ? rg2 : rg);   // unconditional: keeps the wait counts uniform
     finish();
     consume(bufA, col(ch, rg));
     STAMP(5);
@@ -575,7 +599,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
     int g3 = g2, ch3 = ch2, rg3 = rg2;
     bool have3 = true;
     next(g3, ch3, have3, rg3);
-    issue(bufA, have3 ? g3 : g2, have3 ? col(ch3, rg3) : col(ch2, rg2));
+    issue(bufA, have3 ? g3 : g2, have3 ? col(ch3, rg3) : col(ch2, rg2), have3 ? rg3 : rg2);
     finish();
     consume(bufB, col(ch2, rg2));
     if (ch2 == nchunks - 1) stash(g2);
@@ -597,10 +621,31 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   }
 }
 
-template <int MODE, int R, int U, int PRE>
+template <int MODE, int R, int U, int PRE, bool PK = false>
 __global__ void __launch_bounds__(256) phase_kernel(const PhaseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  phase_body<MODE, R, U, PRE>(a, smem, blockIdx.x, gridDim.x);
+  phase_body<MODE, R, U, PRE, PK>(a, smem, blockIdx.x, gridDim.x);
+}
+
+// Repack the matrix (matrices) of one launch for phase_body<.., PK = true>: one thread per float4, the same row_ptrs as the
+// GEMV, so a row group is whatever the phase says it is (rows 2g, 2g + 1; row g of w1 and of w3; q rows, then k, then v).
+//   dst[round][batch ci][place in the round][r][u][lane],  group g = place + round * wstride,  column = ci * cpi + u * 64 + lane
+template <int MODE, int R>
+__global__ void __launch_bounds__(256) pack_kernel(const PhaseArgs a, f4* dst, int U, int wstride) {
+  const int n4 = a.n >> 2, cpi = 64 * U, nchunks = (n4 + cpi - 1) / cpi, ulast = (n4 - (nchunks - 1) * cpi) >> 6;
+  const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
+  const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
+  const int gi = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;     // e = r * n4 + column
+  if (e >= R * n4) return;
+  const int r = e / n4, c4 = e - r * n4;
+  const float* rp[R];
+  row_ptrs<MODE, R>(a, gi, a.n, rp);
+  const float* src = rp[0];
+#pragma unroll
+  for (int k = 1; k < R; ++k) src = (r == k) ? rp[k] : src;
+  const int ci = c4 / cpi, u = (c4 - ci * cpi) >> 6, ln = c4 & 63;
+  const int rnd = gi / wstride, place = gi - rnd * wstride, nwr = min(wstride, groups - rnd * wstride), uc = (ci == nchunks - 1) ? ulast : U;
+  dst[(size_t)rnd * wstride * R * n4 + (size_t)nwr * (R * cpi) * ci + (size_t)place * (R * 64) * uc + (r * uc + u) * 64 + ln] = reinterpret_cast<const f4*>(src)[c4];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -130,6 +130,7 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
 #endif
   if (use_small(c, MODE, a.rows, a.n)) return launch_small<MODE>(c, a, st);
   const Geo g = pick_geo(c, MODE, a.rows, a.n, a.dim);
+  if (!g.vec) a.wp = nullptr;
   const dim3 grid(g.grid), block(64 * g.nwaves);
   if (!g.vec) {
     const size_t lds = (((size_t)a.n * 4 + 15) & ~(size_t)15) + 64;
@@ -144,8 +145,12 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   const int round4 = g.pre * 64 * g.nwaves;                   // PRE * nthreads (kernels.hip.h)
   const int nstage4 = ((npad4 + round4 - 1) / round4) * round4;
   const size_t lds = (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
-#define L2_LAUNCH(UU, PP) do { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \
-                               launch_probed(c, phase_kernel<MODE, 2, UU, PP>, grid, block, lds, st, a, MODE == MODE_W13); } while (0)
+  // the repacked copy is only good for the geometry it was packed for (U = 2: the only batch width with more than one batch per row)
+  if (a.wp && !(g.U == 2 && g.U == c->packed[MODE].U && g.nwaves == c->packed[MODE].nwaves && g.grid == c->packed[MODE].grid)) a.wp = nullptr;
+#define L2_LAUNCH(UU, PP) do { if (UU == 2 && a.wp) { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, 2, PP, true>, lds); if (e_ != hipSuccess) return e_; \
+                                                      launch_probed(c, phase_kernel<MODE, 2, 2, PP, true>, grid, block, lds, st, a, MODE == MODE_W13); } \
+                               else { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \
+                                      launch_probed(c, phase_kernel<MODE, 2, UU, PP>, grid, block, lds, st, a, MODE == MODE_W13); } } while (0)
 #define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else if (g.pre == 4) L2_LAUNCH(UU, 4); else L2_LAUNCH(UU, 12); } while (0)
   if (g.U == 3) { if constexpr (MODE == MODE_CLS) { L2_LAUNCH_U(3); } }
   else if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);

@@ -83,6 +83,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   l2s::destroy(&c->samp);
   for (int k = 0; k < L2_T_COUNT; ++k)
     if (c->w[k] && !(k == L2_T_WCLS && c->shared)) hipFree(c->w[k]);  // shared wcls aliases the embedding table
+  for (auto& p : c->packed) if (p.buf) hipFree(p.buf);
   float* bufs[] = {c->x, c->xb, c->xb2, c->hb, c->hb2, c->q, c->k, c->v, c->att, c->logits, c->kc, c->vc, c->xn};
   for (float* b : bufs) if (b) hipFree(b);
   if (c->logits_loc && c->logits_loc != c->logits) hipFree(c->logits_loc);
@@ -147,6 +148,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->tune_nwaves = dev_int("L2_TUNE_NWAVES", 0);
   c->tune_gridcap = dev_int("L2_TUNE_GRIDCAP", 0);
   c->tune_rot = dev_int("L2_TUNE_ROT", 5);
+  c->opt_packed = dev_int("L2_PACKED", 1);
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !hook_int("L2_TP_FORCE_COMM")) ? 1 : 0);
   c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
@@ -346,6 +348,7 @@ extern "C" int l2_upload(l2_ctx* c, int kind, int layer, const float* host, size
     HIPCHK(hipMemcpy2D(dst, s.cols * sizeof(float), src, s.full_cols * sizeof(float), s.cols * sizeof(float), s.rows, hipMemcpyHostToDevice));
   }
   c->uploaded[kind][li] = 1;
+  c->packed_valid = false;
   return L2_OK;
 }
 
@@ -356,6 +359,10 @@ extern "C" int l2_upload(l2_ctx* c, int kind, int layer, const float* host, size
 
 // Enqueue one transformer() call (llama2.ts:205-303) reading {token,pos} from device memory.
 // PhaseArgs of each phase of layer l
+static const float* packed_of(const l2_ctx* c, int mode, int l) {
+  const l2_ctx::Packed& p = c->packed[mode];
+  return (c->packed_valid && p.buf) ? p.buf + p.layer_elems * (size_t)l : nullptr;
+}
 static PhaseArgs base_args(const l2_ctx* c) {
   PhaseArgs a;
   memset(&a, 0, sizeof(a));
@@ -374,6 +381,7 @@ static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs +
   a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff;
   if (c->opt_keep_state) { a.aux = c->k; a.aux2 = c->v; }     // RunState.k / v: the cache rows are what attention reads
   a.n = c->d; a.rows = c->d_loc + 2 * c->kvd_loc; a.dim = c->d_loc; a.kv_dim = c->kvd_loc;
+  a.wp = packed_of(c, MODE_QKV, l);
   return a;
 }
 static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (llama2.ts:270-273)
@@ -382,6 +390,7 @@ static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (lla
   a.in = c->xb; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; a.res = c->x; a.out = c->x; a.aux = c->opt_keep_state ? c->xb2 : nullptr;
   a.n = c->d_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
+  a.wp = packed_of(c, MODE_WO, l);
   return a;
 }
 static PhaseArgs w13_args(const l2_ctx* c, int l) {   // rmsnorm + w1,w3 GEMVs + SwiGLU (llama2.ts:276-289)
@@ -391,6 +400,7 @@ static PhaseArgs w13_args(const l2_ctx* c, int l) {   // rmsnorm + w1,w3 GEMVs +
   a.in = c->x; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * l;
   a.out = c->hb; a.aux = c->opt_keep_state ? c->hb2 : nullptr;
   a.n = c->d; a.rows = c->h_loc;
+  a.wp = packed_of(c, MODE_W13, l);
   return a;
 }
 static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (llama2.ts:292-295)
@@ -399,6 +409,7 @@ static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (lla
   a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = (c->tp_path || !c->opt_keep_state) ? nullptr : c->xb;
   a.n = c->h_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
+  a.wp = packed_of(c, MODE_W2, l);
   return a;
 }
 static PhaseArgs cls_args(const l2_ctx* c, bool to_host) {   // final rmsnorm + classifier (llama2.ts:299-302)
@@ -407,7 +418,48 @@ static PhaseArgs cls_args(const l2_ctx* c, bool to_host) {   // final rmsnorm + 
   a.in = c->x; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->opt_keep_state ? c->xn : nullptr;
   a.aux2 = (to_host && c->opt_zero_copy && !c->tp_path) ? c->h_logits_dev : nullptr;
   a.n = c->d; a.rows = c->V_loc;
+  a.wp = packed_of(c, MODE_CLS, 0);
   return a;
+}
+
+// Build (or rebuild after an upload) the repacked copies of the matrices the streaming form reads: kernels.hip.h, phase_body PK.
+// A phase is packed when its launch is the streaming form with two 64-lane sub-batches per batch and more than one batch per row
+// (n % 256 == 0, n > 512: every layer matrix and the classifier of Llama-2-7B; the small models' phases take the latency form).
+// No memory for the second copy: that phase streams the row-major tensor as before.
+template <int MODE>
+static int pack_phase(l2_ctx* c, int layers, PhaseArgs (*args_of)(const l2_ctx*, int)) {
+  l2_ctx::Packed& p = c->packed[MODE];
+  PhaseArgs a0 = args_of(c, 0);
+  const bool small = use_small(c, MODE, a0.rows, a0.n);
+  const Geo g = pick_geo(c, MODE, a0.rows, a0.n, a0.dim);
+  const int n4 = a0.n / 4, rpg = (MODE == MODE_W13) ? 1 : 2, groups = (a0.rows + rpg - 1) / rpg;
+  const bool want = c->opt_packed && !small && g.vec && g.U == 2 && n4 % 64 == 0 && n4 > 128;
+  if (!want) { if (p.buf) { hipFree(p.buf); p.buf = nullptr; } return L2_OK; }
+  const size_t elems = (size_t)groups * 2 * a0.n;
+  if (p.buf && !(p.layer_elems == elems && p.U == g.U && p.nwaves == g.nwaves && p.grid == g.grid)) { hipFree(p.buf); p.buf = nullptr; }
+  if (!p.buf) {
+    if (hipMalloc(&p.buf, elems * layers * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); p.buf = nullptr; return L2_OK; }
+    p.layer_elems = elems; p.U = g.U; p.nwaves = g.nwaves; p.grid = g.grid;
+  }
+  for (int l = 0; l < layers; ++l) {
+    const PhaseArgs a = args_of(c, l);
+    hipLaunchKernelGGL((pack_kernel<MODE, 2>), dim3((2 * n4 + 255) / 256, groups), dim3(256), 0, c->stream, a, reinterpret_cast<f4*>(p.buf + elems * (size_t)l), g.U, g.grid * g.nwaves);
+  }
+  LCHK(hipGetLastError());
+  return L2_OK;
+}
+static PhaseArgs cls_args_l(const l2_ctx* c, int) { return cls_args(c, false); }
+static int ensure_packed(l2_ctx* c) {
+  if (c->packed_valid) return L2_OK;
+  int rc;
+  if ((rc = pack_phase<MODE_QKV>(c, c->L, qkv_args))) return rc;
+  if ((rc = pack_phase<MODE_WO>(c, c->L, wo_args))) return rc;
+  if ((rc = pack_phase<MODE_W13>(c, c->L, w13_args))) return rc;
+  if ((rc = pack_phase<MODE_W2>(c, c->L, w2_args))) return rc;
+  if ((rc = pack_phase<MODE_CLS>(c, 1, cls_args_l))) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->packed_valid = true;
+  return L2_OK;
 }
 
 static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fold_argmax = false) {
@@ -474,7 +526,7 @@ static int ensure_ready(l2_ctx* c) {
       if (!c->uploaded[k][l]) return fail(L2_E_STATE, "tensor kind %d layer %zu was never uploaded", k, l);
   }
   if (c->p2p && !c->p2p_synced) { const int rc_ = p2p_first_sync(c); if (rc_) return rc_; }
-  return L2_OK;
+  return ensure_packed(c);
 }
 
 static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step: forward, argmax, advance

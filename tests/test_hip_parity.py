@@ -647,11 +647,13 @@ def test_sampler_serial_and_parallel_forms_agree(monkeypatch):
 @pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_ATTN_NW": "4"}), ("stories110M", {"L2_ATTN_NW": "8"}), ("stories15M", {"L2_ATTN_NW": "8"}),
                                       ("stories110M", {"L2_SMALL_MAX": "0"}), ("stories15M", {"L2_SMALL_MAX": "0"}),
                                       ("llama2_7b_L2", {"L2_TUNE_ROT": "0"}), ("llama2_7b_L2", {"L2_TUNE_ROT": "3"}),
+                                      ("llama2_7b_L2", {"L2_PACKED": "0"}), ("llama2_7b_L2", {"L2_PACKED": "0", "L2_TUNE_ROT": "0"}),
                                       ("stories110M", {"L2_SMALL_MAX": "0", "L2_TUNE_ROT": "7"})])
 def test_launch_geometry_variants_match_reference(monkeypatch, name, env):
     """The other geometry of the attention tile kernel (4 waves x 16 tiles / 8 waves x 8 tiles per round), the
-    streaming form of the GEMV phases on shapes that default to the latency form, and other starting columns of its rows:
-    same goldens, same tolerance, tokens exact."""
+    streaming form of the GEMV phases on shapes that default to the latency form, other starting columns of its rows, and the
+    row-major tensors streamed instead of their repacked copies (the default at this width): same goldens, same tolerance,
+    tokens exact."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     meta, g = load_gold(name)
@@ -667,3 +669,44 @@ def test_launch_geometry_variants_match_reference(monkeypatch, name, env):
     if meta["tokens_fed"] == [1] + meta["argmax"][:n - 1]:
         assert ctx.decode_greedy(1, 0, n).tolist() == meta["argmax"][:n]       # graph replay path too
     ctx.close()
+
+
+@pytest.mark.parametrize("hdr", [(1280, 2560, 2, 10, 10, -1000, 48), (1280, 2572, 2, 10, 10, 1000, 48), (2048, 5632, 1, 16, 16, -777, 32)])
+def test_repacked_matrices_equal_the_row_major_ones_and_follow_uploads(built, hdr, monkeypatch):
+    """The streaming form reads a second copy of its matrices, repacked on the device in the order the chip consumes them
+    (kernels.hip.h, pack_kernel): every column batch, short last batches (1280 = 2.5 batches of 512 columns), short last rounds
+    of row groups (2572 rows on 1288 waves), a phase that cannot be packed beside ones that are (2572 columns), against the
+    oracle and BIT for bit against a context that streams the row-major tensors -- then one matrix of every phase is uploaded
+    again and the packed copy has to follow."""
+    monkeypatch.setenv("L2_SMALL_MAX", "0")          # the streaming form at widths that default to the latency form
+    orc = O.Oracle(hdr, 11)
+    a = runtime.Context(hdr)
+    upload_from_oracle(a, orc)
+    monkeypatch.setenv("L2_PACKED", "0")
+    b = runtime.Context(hdr)
+    upload_from_oracle(b, orc)
+    monkeypatch.delenv("L2_PACKED")
+
+    def run(first_pos, steps, check_oracle):
+        tok = 1
+        for pos in range(first_pos, first_pos + steps):
+            la, lb = a.forward(tok, pos), b.forward(tok, pos)
+            assert np.array_equal(bits(la), bits(lb)), (hdr, pos)
+            if check_oracle:
+                want = orc.forward(tok, pos)
+                assert np.abs(la - want).max() <= TOL and runtime.argmax(la) == O.argmax(want), (hdr, pos)
+            tok = runtime.argmax(la)
+        return la
+    before = run(0, 6, True)
+    assert a.decode_greedy(1, 0, 12).tolist() == b.decode_greedy(1, 0, 12).tolist()
+    rng = np.random.default_rng(5)
+    cfg = a.cfg
+    for kind in (runtime.T_WQ, runtime.T_WO, runtime.T_W3, runtime.T_W2, runtime.T_WCLS if hdr[5] < 0 else runtime.T_TOKEN_EMBEDDING):
+        layers = dict((k, l) for k, l, _ in runtime.tensor_shapes(cfg))[kind]
+        layer = 1 if layers > 1 else (0 if layers else -1)
+        w = orc.weights(kind, layer).copy()
+        w *= rng.uniform(0.5, 1.5, size=w.shape).astype(np.float32)
+        a.upload(kind, layer, w); b.upload(kind, layer, w)
+    after = run(0, 6, False)
+    assert not np.array_equal(bits(before), bits(after))
+    a.close(); b.close(); orc.close()

@@ -7,6 +7,8 @@
 //   +stagger  the second row of the group half a row ahead of the first
 //   cols      one 512-thread workgroup per CU owns a block of row groups, wave w streams column batch w of each of them
 //   +fma      rows+rot with the GEMV's arithmetic (x from LDS, fp64 widening and FMA of every weight)
+//   packed    the rows loop, but the matrix REPACKED in the order the chip consumes it: [step][wave][row of the group][u][lane], so that
+//             what all waves ask for at one moment is one contiguous stretch (2048 waves x 4 KB = 8 MB), as in `stream`
 // With all waves marching through their rows in step, the requests in flight at one moment sit a whole row (16 / 44 KB)
 // apart; rotating the start spreads them over the HBM channels.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/mbr tools/microbench_rows.hip && /tmp/mbr
@@ -36,7 +38,9 @@ __global__ void __launch_bounds__(256) stream(const f4* w, size_t n4, const floa
 // PAIR: the group's two rows are row g of the first and of the second half of the matrix (w1 / w3); else rows 2g, 2g + 1
 // TAILPF: every wave, once its own rows are done, pulls TAILPF KiB of the NEXT link's matrix (plain loads: they allocate in L2 / the
 // Infinity Cache) -- in the pattern the next launch's first batches will ask for them -- so that the next launch finds its first bytes on chip
-template <bool PAIR, int ROT, bool STAGGER, int WORK = 0, int TAILPF = 0>
+// DRAIN: wait for everything in flight at the top of every iteration, as the library's loop did (hipcc put an s_waitcnt vmcnt(0) in
+// front of the first address computation of the iteration: it reuses the other register set's registers for it)
+template <bool PAIR, int ROT, bool STAGGER, int WORK = 0, int TAILPF = 0, int PACKED = 0, int DRAIN = 0>
 __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const float* carry_in, float* carry_out, const f4* next_w = nullptr) {
   constexpr int U = 2;
   const float c = carry_in[0];
@@ -51,6 +55,19 @@ __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n4 = n / 4, batches = (n4 + 64 * U - 1) / (64 * U), groups = rows / 2, tw = gridDim.x * 4;
   auto load = [&](f4 (&b)[2][U], int g, int ci) {
+    if (PACKED) {
+      const int gw = blockIdx.x * 4 + wave;
+      const size_t k = (size_t)((g - gw) / tw) * batches + ci;
+      size_t base = (k * tw + gw) * (size_t)(2 * U * 64);
+      const size_t lim = (size_t)rows * n4 - 2 * U * 64;
+      if (base > lim) base = lim;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        b[0][u] = __builtin_nontemporal_load(w + base + u * 64 + lane);
+        b[1][u] = __builtin_nontemporal_load(w + base + (U + u) * 64 + lane);
+      }
+      return;
+    }
     const f4* r0 = w + (size_t)(PAIR ? g : 2 * g) * n4;
     const f4* r1 = w + (size_t)(PAIR ? groups + g : 2 * g + 1) * n4;
     const int rot = ROT ? (g * ROT) % batches : 0;
@@ -66,6 +83,7 @@ __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const
   int g = blockIdx.x * 4 + wave, ci = 0;
   if (g < groups) load(A, g, 0);
   while (g < groups) {
+    if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int g2 = g, c2 = ci + 1;
     if (c2 == batches) { c2 = 0; g2 += tw; }
     load(B, g2 < groups ? g2 : g, g2 < groups ? c2 : ci);
@@ -155,33 +173,38 @@ __global__ void __launch_bounds__(512) cols8(const f4* w, int rows, int n, const
   if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int GRID = argc > 1 ? atoi(argv[1]) : 512;      // workgroups of the rows / packed variants (the library's balanced w1/w3 grid: 459)
   const size_t total = (size_t)6 << 30;
   f4* w; float* carry;
   (void)hipMalloc(&w, total); (void)hipMalloc(&carry, 1 << 16); (void)hipMemset(carry, 0, 1 << 16);
   hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, (float*)w, total / 4); (void)hipDeviceSynchronize();
   hipStream_t sa; (void)hipStreamCreate(&sa);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  printf("us per link of a chain of dependent streaming kernels (launch boundary included), 512 workgroups of 256 threads\n");
-  printf("%-34s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma", "cols", "fma+pf4K", "fma+pf8K");
+  printf("us per link of a chain of dependent streaming kernels (launch boundary included), %d workgroups of 256 threads\n", GRID);
+  printf("%-34s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma", "cols", "fma+pf4K", "fma+pf8K", "packed", "pack+fma", "rot+drn", "pack+drn");
   struct { const char* name; int rows, n; bool pair; } shapes[] = {{"w1+w3  2 x 11008 x 4096 (361 MB)", 22016, 4096, true}, {"wqkv   12288 x 4096 (201 MB)", 12288, 4096, false},
                                                                    {"w2     4096 x 11008 (180 MB)", 4096, 11008, false}, {"wo     4096 x 4096 (67 MB)", 4096, 4096, false},
                                                                    {"wcls   32000 x 4096 (524 MB)", 32000, 4096, false}};
   for (auto sh : shapes) {
     const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
     printf("%-34s", sh.name);
-    for (int var = 0; var < 10; ++var) {
+    for (int var = 0; var < 14; ++var) {
       if (var == 7 && sh.n != 4096) { printf(" %8s", "-"); continue; }            // eight column batches of 2 KB: 4096 columns
       float best = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0, sa);
         for (int k = 0; k < nk; ++k) {
           const f4* wk = w + (size_t)k * link4; const float* ci = carry + 16 * k; float* co = carry + 16 * (k + 1);
-          const dim3 g(512), b(256);
+          const dim3 g(GRID), b(256);
 #define ROWSW(R_, S_) do { if (sh.pair) hipLaunchKernelGGL((rows2<true, R_, S_, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, R_, S_, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); } while (0)
 #define ROWS(R_, S_) do { if (sh.pair) hipLaunchKernelGGL((rows2<true, R_, S_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, R_, S_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); } while (0)
-          if (var == 0) hipLaunchKernelGGL(stream, g, b, 0, sa, wk, link4, ci, co);
+          if (var == 0) hipLaunchKernelGGL(stream, dim3(512), b, 0, sa, wk, link4, ci, co);
           else if (var == 1) ROWS(0, false); else if (var == 2) ROWS(5, false); else if (var == 3) ROWS(5, true); else if (var == 4) ROWS(3, false); else if (var == 5) ROWS(7, false); else if (var == 6) ROWSW(5, false);
+          else if (var == 10) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 0, false, 0, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 0, false, 0, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
+          else if (var == 11) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 0, false, 1, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 0, false, 1, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
+          else if (var == 12) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 5, false, 1, 0, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 5, false, 1, 0, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
+          else if (var == 13) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 0, false, 1, 0, 1, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 0, false, 1, 0, 1, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
           else if (var >= 8) {
             const f4* nx = (k + 1 < nk) ? wk + link4 : nullptr;
             if (var == 8) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 5, false, 1, 4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co, nx); else hipLaunchKernelGGL((rows2<false, 5, false, 1, 4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co, nx); }
