@@ -40,13 +40,12 @@ __global__ void __launch_bounds__(256) stream(const f4* w, size_t n4, const floa
 // Infinity Cache) -- in the pattern the next launch's first batches will ask for them -- so that the next launch finds its first bytes on chip
 // DRAIN: wait for everything in flight at the top of every iteration, as the library's loop did (hipcc put an s_waitcnt vmcnt(0) in
 // front of the first address computation of the iteration: it reuses the other register set's registers for it)
-template <bool PAIR, int ROT, bool STAGGER, int WORK = 0, int TAILPF = 0, int PACKED = 0, int DRAIN = 0>
+template <bool PAIR, int ROT, bool STAGGER, int WORK = 0, int TAILPF = 0, int PACKED = 0, int DRAIN = 0, int U = 2>
 __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const float* carry_in, float* carry_out, const f4* next_w = nullptr) {
-  constexpr int U = 2;
   const float c = carry_in[0];
   f4 acc = {c, 0.f, 0.f, 0.f};
   // WORK 1: the GEMV's arithmetic as well -- x (n floats) staged in LDS, every weight widened to fp64 and multiplied in
-  __shared__ f4 xs[WORK ? 2752 : 1];
+  __shared__ f4 xs[WORK ? 2816 : 1];
   double d0 = 0.0, d1 = 0.0;
   if (WORK) {
     for (int i = threadIdx.x; i < n / 4; i += 256) { const float v = 1e-3f * (float)(i & 7); xs[i] = f4{v, v, v, v}; }
@@ -58,7 +57,10 @@ __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const
     if (PACKED) {
       const int gw = blockIdx.x * 4 + wave;
       const size_t k = (size_t)((g - gw) / tw) * batches + ci;
-      size_t base = (k * tw + gw) * (size_t)(2 * U * 64);
+      // PACKED = 1 + m: the waves' places within a step rotate by m workgroups (4 m waves) per step, so that the stretch an XCD reads
+      // (workgroup b runs on XCD b % 8) moves through all residues of the address instead of keeping one
+      const int place = PACKED > 1 ? (int)(((size_t)gw + (size_t)4 * (PACKED - 1) * k) % (size_t)tw) : gw;
+      size_t base = (k * tw + place) * (size_t)(2 * U * 64);
       const size_t lim = (size_t)rows * n4 - 2 * U * 64;
       if (base > lim) base = lim;
 #pragma unroll
@@ -140,6 +142,52 @@ __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const
   if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
 }
 
+// packed layout, D register sets: D - 1 batches always in flight per wave (rows2 keeps 1 - 2); the GEMV's arithmetic included
+template <int D>
+__global__ void __launch_bounds__(256) packdeep(const f4* w, int rows, int n, const float* carry_in, float* carry_out) {
+  constexpr int U = 2;
+  const float c = carry_in[0];
+  __shared__ f4 xs[2816];
+  for (int i = threadIdx.x; i < n / 4; i += 256) { const float v = 1e-3f * (float)(i & 7); xs[i] = f4{v, v, v, v}; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n4 = n / 4, batches = (n4 + 64 * U - 1) / (64 * U), groups = rows / 2, tw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+  const int mine = gw < groups ? (groups - gw + tw - 1) / tw : 0, T = mine * batches;       // this wave's steps
+  const size_t lim = (size_t)rows * n4 - 2 * U * 64;
+  f4 buf[D][2][U];
+  auto load = [&](f4 (&b)[2][U], int s) {
+    s = s < T ? s : T - 1;
+    size_t base = ((size_t)s * tw + gw) * (size_t)(2 * U * 64);
+    if (base > lim) base = lim;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { b[0][u] = __builtin_nontemporal_load(w + base + u * 64 + lane); b[1][u] = __builtin_nontemporal_load(w + base + (U + u) * 64 + lane); }
+  };
+  double d0 = 0.0, d1 = 0.0;
+  auto use = [&](const f4 (&b)[2][U], int s) {
+    const int c0 = s % batches;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f4 xv = xs[min(c0 * 64 * U + u * 64 + lane, n4 - 1)];
+      const double x0 = xv.x, x1 = xv.y, x2 = xv.z, x3 = xv.w;
+      d0 += (double)b[0][u].x * x0; d0 += (double)b[0][u].y * x1; d0 += (double)b[0][u].z * x2; d0 += (double)b[0][u].w * x3;
+      d1 += (double)b[1][u].x * x0; d1 += (double)b[1][u].y * x1; d1 += (double)b[1][u].z * x2; d1 += (double)b[1][u].w * x3;
+    }
+  };
+  if (T > 0) {
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load(buf[d], d);
+    for (int s = 0; s < T; s += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        load(buf[(d + D - 1) % D], s + d + D - 1);
+        if (s + d < T) use(buf[d], s + d);
+      }
+    }
+  }
+  if ((float)(d0 + d1) == 12345.678f) carry_out[1] = 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
+}
+
 // cols: one 512-thread workgroup per CU owns a contiguous block of row groups; wave w streams column batch w (2 KB per row)
 // of every group of the block -- every wave moves the same number of bytes, nothing is left to a last round
 template <bool PAIR>
@@ -182,14 +230,33 @@ int main(int argc, char** argv) {
   hipStream_t sa; (void)hipStreamCreate(&sa);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   printf("us per link of a chain of dependent streaming kernels (launch boundary included), %d workgroups of 256 threads\n", GRID);
-  printf("%-34s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma", "cols", "fma+pf4K", "fma+pf8K", "packed", "pack+fma", "rot+drn", "pack+drn");
+  printf("%-34s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s %8s\n", "shape", "stream", "rows", "rot 5", "rot 5+st", "rot 3", "rot 7", "rot5+fma", "cols", "fma+pf4K", "fma+pf8K", "packed", "pack+fma", "rot+drn", "pack+drn", "pack U=4", "pack U=1", "deep 2", "deep 3", "deep 4", "deep 6");
   struct { const char* name; int rows, n; bool pair; } shapes[] = {{"w1+w3  2 x 11008 x 4096 (361 MB)", 22016, 4096, true}, {"wqkv   12288 x 4096 (201 MB)", 12288, 4096, false},
                                                                    {"w2     4096 x 11008 (180 MB)", 4096, 11008, false}, {"wo     4096 x 4096 (67 MB)", 4096, 4096, false},
                                                                    {"wcls   32000 x 4096 (524 MB)", 32000, 4096, false}};
+  if (argc > 2) {   // soak: the packed w1/w3 stand-in for ~2 s without a pause -- does a link get slower once the chip has been streaming for a while?
+    const auto sh = shapes[0];
+    const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
+    const int reps = atoi(argv[2]);
+    printf("soak, packed + fma, w1+w3: us per link at repetition");
+    for (int rep = 0; rep < reps; ++rep) {
+      (void)hipEventRecord(e0, sa);
+      for (int k = 0; k < nk; ++k)
+        hipLaunchKernelGGL((rows2<true, 0, false, 1, 0, 1>), dim3(GRID), dim3(256), 0, sa, w + (size_t)k * link4, sh.rows, sh.n, carry + 16 * k, carry + 16 * (k + 1));
+      (void)hipEventRecord(e1, sa);
+      if (rep < 4 || rep % (reps / 16 ? reps / 16 : 1) == 0 || rep == reps - 1) {
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("  %d: %.2f", rep, ms * 1e3 / nk);
+      }
+    }
+    printf("\n");
+    return 0;
+  }
   for (auto sh : shapes) {
     const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
     printf("%-34s", sh.name);
-    for (int var = 0; var < 14; ++var) {
+    for (int var = 0; var < 20; ++var) {
       if (var == 7 && sh.n != 4096) { printf(" %8s", "-"); continue; }            // eight column batches of 2 KB: 4096 columns
       float best = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
@@ -205,6 +272,13 @@ int main(int argc, char** argv) {
           else if (var == 11) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 0, false, 1, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 0, false, 1, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
           else if (var == 12) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 5, false, 1, 0, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 5, false, 1, 0, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
           else if (var == 13) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 0, false, 1, 0, 1, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 0, false, 1, 0, 1, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
+          else if (var == 14) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 0, false, 1, 0, 1, 0, 4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 0, false, 1, 0, 1, 0, 4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
+          else if (var == 15) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 0, false, 1, 0, 1, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 0, false, 1, 0, 1, 0, 1>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); }
+#define PKROT(M_) do { if (sh.pair) hipLaunchKernelGGL((rows2<true, 0, false, 1, 0, 1 + M_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); else hipLaunchKernelGGL((rows2<false, 0, false, 1, 0, 1 + M_>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co); } while (0)
+          else if (var == 16) hipLaunchKernelGGL((packdeep<2>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co);
+          else if (var == 17) hipLaunchKernelGGL((packdeep<3>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co);
+          else if (var == 18) hipLaunchKernelGGL((packdeep<4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co);
+          else if (var == 19) hipLaunchKernelGGL((packdeep<6>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co);
           else if (var >= 8) {
             const f4* nx = (k + 1 < nk) ? wk + link4 : nullptr;
             if (var == 8) { if (sh.pair) hipLaunchKernelGGL((rows2<true, 5, false, 1, 4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co, nx); else hipLaunchKernelGGL((rows2<false, 5, false, 1, 4>), g, b, 0, sa, wk, sh.rows, sh.n, ci, co, nx); }
