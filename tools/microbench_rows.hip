@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ void fill(float* p, size_t n) { for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; p[i] = ((float)(x & 0xffff) - 32768.0f) * 1e-6f; } }
 
@@ -144,12 +145,38 @@ __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const
 
 // packed layout, D register sets: D - 1 batches always in flight per wave (rows2 keeps 1 - 2); the GEMV's arithmetic included
 template <int D>
+__device__ __forceinline__ void packdeep_body(const f4* w, int rows, int n, const f4* xs, float* carry_out);
+
+// DS sets for the workgroups on the XCDs of `slow_mask`, DF for the others; `stamp` (or null): per workgroup {XCD, end - start in 10 ns}
+template <int DF, int DS>
+__global__ void __launch_bounds__(256) packmix(const f4* w, int rows, int n, const float* carry_in, float* carry_out, unsigned slow_mask, unsigned* stamp) {
+  const float c = carry_in[0];
+  __shared__ f4 xs[2816];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = threadIdx.x; i < n / 4; i += 256) { const float v = 1e-3f * (float)(i & 7) + c; xs[i] = f4{v, v, v, v}; }
+  __syncthreads();
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 0xf;
+  if ((slow_mask >> xcc) & 1) packdeep_body<DS>(w, rows, n, xs, carry_out); else packdeep_body<DF>(w, rows, n, xs, carry_out);
+  __syncthreads();
+  if (stamp && threadIdx.x == 0) { stamp[2 * blockIdx.x] = xcc; stamp[2 * blockIdx.x + 1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0); }
+  if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
+}
+
+template <int D>
 __global__ void __launch_bounds__(256) packdeep(const f4* w, int rows, int n, const float* carry_in, float* carry_out) {
-  constexpr int U = 2;
   const float c = carry_in[0];
   __shared__ f4 xs[2816];
   for (int i = threadIdx.x; i < n / 4; i += 256) { const float v = 1e-3f * (float)(i & 7); xs[i] = f4{v, v, v, v}; }
   __syncthreads();
+  packdeep_body<D>(w, rows, n, xs, carry_out);
+  if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
+}
+
+template <int D>
+__device__ __forceinline__ void packdeep_body(const f4* w, int rows, int n, const f4* xs, float* carry_out) {
+  constexpr int U = 2;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n4 = n / 4, batches = (n4 + 64 * U - 1) / (64 * U), groups = rows / 2, tw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
   const int mine = gw < groups ? (groups - gw + tw - 1) / tw : 0, T = mine * batches;       // this wave's steps
@@ -185,7 +212,6 @@ __global__ void __launch_bounds__(256) packdeep(const f4* w, int rows, int n, co
     }
   }
   if ((float)(d0 + d1) == 12345.678f) carry_out[1] = 1.0f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
 }
 
 // cols: one 512-thread workgroup per CU owns a contiguous block of row groups; wave w streams column batch w (2 KB per row)
@@ -234,6 +260,36 @@ int main(int argc, char** argv) {
   struct { const char* name; int rows, n; bool pair; } shapes[] = {{"w1+w3  2 x 11008 x 4096 (361 MB)", 22016, 4096, true}, {"wqkv   12288 x 4096 (201 MB)", 12288, 4096, false},
                                                                    {"w2     4096 x 11008 (180 MB)", 4096, 11008, false}, {"wo     4096 x 4096 (67 MB)", 4096, 4096, false},
                                                                    {"wcls   32000 x 4096 (524 MB)", 32000, 4096, false}};
+  if (argc > 2 && !strcmp(argv[2], "xcd")) {   // when do the workgroups of the packed stand-in end, by XCD -- and does a deeper pipeline on the late XCDs even it out?
+    unsigned* stamp; (void)hipMalloc(&stamp, 8 * 1024);
+    unsigned host[2048];
+    const unsigned masks[] = {0u, 0x28u, 0xaau, 0xffu};
+    for (int si = 0; si < 4; ++si) {
+      const auto sh = shapes[si == 3 ? 1 : 0];
+      const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
+      for (unsigned mask : masks) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+          (void)hipEventRecord(e0, sa);
+          for (int k = 0; k < nk; ++k) hipLaunchKernelGGL((packmix<2, 3>), dim3(GRID), dim3(256), 0, sa, w + (size_t)k * link4, sh.rows, sh.n, carry + 16 * k, carry + 16 * (k + 1), mask, k == nk - 1 ? stamp : nullptr);
+          (void)hipEventRecord(e1, sa); (void)hipEventSynchronize(e1);
+          float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+        }
+        (void)hipMemcpy(host, stamp, GRID * 8, hipMemcpyDeviceToHost);
+        printf("%-32s 3 sets on XCD mask 0x%02x: %6.2f us per link; workgroup lifetime by XCD (median):", sh.name, mask, best * 1e3 / nk);
+        for (unsigned x = 0; x < 8; ++x) {
+          float v[1024]; int m = 0;
+          for (int b = 0; b < GRID; ++b) if (host[2 * b] == x) v[m++] = host[2 * b + 1] / 100.0f;
+          for (int i = 1; i < m; ++i) for (int j = i; j > 0 && v[j] < v[j - 1]; --j) { float t = v[j]; v[j] = v[j - 1]; v[j - 1] = t; }
+          printf(" %5.1f", m ? v[m / 2] : 0.f);
+        }
+        float mx = 0; for (int b = 0; b < GRID; ++b) if (host[2 * b + 1] / 100.0f > mx) mx = host[2 * b + 1] / 100.0f;
+        printf("  max %5.1f\n", mx);
+      }
+      if (si == 0) si = 2;
+    }
+    return 0;
+  }
   if (argc > 2) {   // soak: the packed w1/w3 stand-in for ~2 s without a pause -- does a link get slower once the chip has been streaming for a while?
     const auto sh = shapes[0];
     const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
