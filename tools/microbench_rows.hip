@@ -145,7 +145,27 @@ __global__ void __launch_bounds__(256) rows2(const f4* w, int rows, int n, const
 
 // packed layout, D register sets: D - 1 batches always in flight per wave (rows2 keeps 1 - 2); the GEMV's arithmetic included
 template <int D>
-__device__ __forceinline__ void packdeep_body(const f4* w, int rows, int n, const f4* xs, float* carry_out);
+__device__ __forceinline__ void packdeep_body(const f4* w, int rows, int n, const f4* xs, float* carry_out, int gw_ = -1, int tw_ = 0);
+
+// Fewer workgroups on the odd XCDs: 8 * S workgroups are launched (workgroup b lands on XCD b % 8, S per XCD), those with slot b / 8 >= n_odd on an
+// odd XCD leave at once, the others share the work as 8 * S - 4 * (S - n_odd) dense workgroups.
+__global__ void __launch_bounds__(256) packskew(const f4* w, int rows, int n, const float* carry_in, float* carry_out, int n_odd, unsigned* stamp) {
+  const float c = carry_in[0];
+  __shared__ f4 xs[2816];
+  const int S = gridDim.x / 8, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  if (blockIdx.x == 0 && threadIdx.x == 0) carry_out[0] = c * 0.5f + 1.0f;
+  if ((x & 1) && slot >= n_odd) { if (stamp && threadIdx.x == 0) { stamp[2 * blockIdx.x] = 99; stamp[2 * blockIdx.x + 1] = 0; } return; }
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = threadIdx.x; i < n / 4; i += 256) { const float v = 1e-3f * (float)(i & 7) + c; xs[i] = f4{v, v, v, v}; }
+  __syncthreads();
+  const int dense = slot < n_odd ? slot * 8 + x : n_odd * 8 + (slot - n_odd) * 4 + (x >> 1);
+  const int working = 8 * S - 4 * (S - n_odd);
+  packdeep_body<2>(w, rows, n, xs, carry_out, dense * 4 + (int)(threadIdx.x >> 6), working * 4);
+  __syncthreads();
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (stamp && threadIdx.x == 0) { stamp[2 * blockIdx.x] = xcc & 0xf; stamp[2 * blockIdx.x + 1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0); }
+}
 
 // DS sets for the workgroups on the XCDs of `slow_mask`, DF for the others; `stamp` (or null): per workgroup {XCD, end - start in 10 ns}
 template <int DF, int DS>
@@ -175,10 +195,10 @@ __global__ void __launch_bounds__(256) packdeep(const f4* w, int rows, int n, co
 }
 
 template <int D>
-__device__ __forceinline__ void packdeep_body(const f4* w, int rows, int n, const f4* xs, float* carry_out) {
+__device__ __forceinline__ void packdeep_body(const f4* w, int rows, int n, const f4* xs, float* carry_out, int gw_, int tw_) {
   constexpr int U = 2;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n4 = n / 4, batches = (n4 + 64 * U - 1) / (64 * U), groups = rows / 2, tw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+  const int n4 = n / 4, batches = (n4 + 64 * U - 1) / (64 * U), groups = rows / 2, tw = tw_ ? tw_ : gridDim.x * 4, gw = gw_ >= 0 ? __builtin_amdgcn_readfirstlane(gw_) : blockIdx.x * 4 + wave;
   const int mine = gw < groups ? (groups - gw + tw - 1) / tw : 0, T = mine * batches;       // this wave's steps
   const size_t lim = (size_t)rows * n4 - 2 * U * 64;
   f4 buf[D][2][U];
@@ -260,6 +280,35 @@ int main(int argc, char** argv) {
   struct { const char* name; int rows, n; bool pair; } shapes[] = {{"w1+w3  2 x 11008 x 4096 (361 MB)", 22016, 4096, true}, {"wqkv   12288 x 4096 (201 MB)", 12288, 4096, false},
                                                                    {"w2     4096 x 11008 (180 MB)", 4096, 11008, false}, {"wo     4096 x 4096 (67 MB)", 4096, 4096, false},
                                                                    {"wcls   32000 x 4096 (524 MB)", 32000, 4096, false}};
+  if (argc > 2 && !strcmp(argv[2], "skew")) {   // 512 working workgroups, fewer of them on the odd XCDs
+    unsigned* stamp; (void)hipMalloc(&stamp, 16 * 1024);
+    unsigned host[4096];
+    for (int si = 0; si < 4; ++si) {
+      const auto sh = shapes[si];
+      const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
+      for (int n_odd = 64; n_odd >= 56; n_odd -= 2) {
+        const int S = 128 - n_odd;                           // 4 * n_odd + 4 * S = 512 working workgroups
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+          (void)hipEventRecord(e0, sa);
+          for (int k = 0; k < nk; ++k) hipLaunchKernelGGL(packskew, dim3(8 * S), dim3(256), 0, sa, w + (size_t)k * link4, sh.rows, sh.n, carry + 16 * k, carry + 16 * (k + 1), n_odd, k == nk - 1 ? stamp : nullptr);
+          (void)hipEventRecord(e1, sa); (void)hipEventSynchronize(e1);
+          float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+        }
+        (void)hipMemcpy(host, stamp, 8 * S * 8, hipMemcpyDeviceToHost);
+        printf("%-32s %2d workgroups per odd XCD, %2d per even: %6.2f us per link; lifetime by XCD (median):", sh.name, n_odd, S, best * 1e3 / nk);
+        for (unsigned x = 0; x < 8; ++x) {
+          float v[1024]; int m = 0;
+          for (int b = 0; b < 8 * S; ++b) if (host[2 * b] == x) v[m++] = host[2 * b + 1] / 100.0f;
+          for (int i = 1; i < m; ++i) for (int j = i; j > 0 && v[j] < v[j - 1]; --j) { float t = v[j]; v[j] = v[j - 1]; v[j - 1] = t; }
+          printf(" %5.1f", m ? v[m / 2] : 0.f);
+        }
+        float mx = 0; for (int b = 0; b < 8 * S; ++b) if (host[2 * b] != 99 && host[2 * b + 1] / 100.0f > mx) mx = host[2 * b + 1] / 100.0f;
+        printf("  max %5.1f\n", mx);
+      }
+    }
+    return 0;
+  }
   if (argc > 2 && !strcmp(argv[2], "xcd")) {   // when do the workgroups of the packed stand-in end, by XCD -- and does a deeper pipeline on the late XCDs even it out?
     unsigned* stamp; (void)hipMalloc(&stamp, 8 * 1024);
     unsigned host[2048];
