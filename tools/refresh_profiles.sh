@@ -28,5 +28,5 @@ for c in stories110M stories110M stories15M llama2_7b_L2; do python tools/sample
 bash tools/sampler_profile.sh > $out/sampler_kernels.txt 2>&1
 # the experiments of this round that were measured and not kept
 hipcc --offload-arch=gfx950 -O3 -o /tmp/mbo tools/microbench_overlap.hip 2>/dev/null && timeout 300 /tmp/mbo > $out/microbench_overlap.txt 2>&1
-hipcc --offload-arch=gfx950 -O3 -o /tmp/mbr tools/microbench_rows.hip 2>/dev/null && timeout 400 /tmp/mbr > $out/microbench_rows_with_tail_prefetch.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -o /tmp/mbr tools/microbench_rows.hip 2>/dev/null && timeout 400 /tmp/mbr > $out/microbench_rows.txt 2>&1
 cat $out/pytest_gpu.txt
