@@ -280,14 +280,17 @@ int main(int argc, char** argv) {
   struct { const char* name; int rows, n; bool pair; } shapes[] = {{"w1+w3  2 x 11008 x 4096 (361 MB)", 22016, 4096, true}, {"wqkv   12288 x 4096 (201 MB)", 12288, 4096, false},
                                                                    {"w2     4096 x 11008 (180 MB)", 4096, 11008, false}, {"wo     4096 x 4096 (67 MB)", 4096, 4096, false},
                                                                    {"wcls   32000 x 4096 (524 MB)", 32000, 4096, false}};
-  if (argc > 2 && !strcmp(argv[2], "skew")) {   // 512 working workgroups, fewer of them on the odd XCDs
+  if (argc > 2 && !strcmp(argv[2], "skew")) {   // fewer workgroups on the odd XCDs: 8 * n_even are launched, the odd XCDs keep n_odd each
     unsigned* stamp; (void)hipMalloc(&stamp, 16 * 1024);
     unsigned host[4096];
-    for (int si = 0; si < 4; ++si) {
+    const int total_wg = argc > 3 ? atoi(argv[3]) : 512;                  // working workgroups = 4 * (n_even + n_odd)
+    for (int si = 0; si < 5; ++si) {
       const auto sh = shapes[si];
       const size_t link4 = (size_t)sh.rows * sh.n / 4; const int nk = (int)(total / 16 / link4);
-      for (int n_odd = 64; n_odd >= 56; n_odd -= 2) {
-        const int S = 128 - n_odd;                           // 4 * n_odd + 4 * S = 512 working workgroups
+      for (int d = 0; d <= 8; d += 2) {
+        const int n_even = total_wg / 8 + d / 2 + (total_wg % 8 ? 1 : 0), n_odd = total_wg / 4 - n_even;
+        if (n_even > 64) break;
+        const int S = n_even;
         float best = 1e30f;
         for (int rep = 0; rep < 4; ++rep) {
           (void)hipEventRecord(e0, sa);
@@ -296,7 +299,7 @@ int main(int argc, char** argv) {
           float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
         }
         (void)hipMemcpy(host, stamp, 8 * S * 8, hipMemcpyDeviceToHost);
-        printf("%-32s %2d workgroups per odd XCD, %2d per even: %6.2f us per link; lifetime by XCD (median):", sh.name, n_odd, S, best * 1e3 / nk);
+        printf("%-32s %2d workgroups per even XCD, %2d per odd: %6.2f us per link; lifetime by XCD (median):", sh.name, n_even, n_odd, best * 1e3 / nk);
         for (unsigned x = 0; x < 8; ++x) {
           float v[1024]; int m = 0;
           for (int b = 0; b < 8 * S; ++b) if (host[2 * b] == x) v[m++] = host[2 * b + 1] / 100.0f;
