@@ -485,7 +485,9 @@ def main():
         "config": {"workload": "%s batch-1 greedy decode, %d tokens from BOS (-t 0 -s 1 -n %d)" % (args.config, K, K),
                    "header": list(hdr), "parallelism": ("tp%d" % world) if shards else ("replicas%d" % world if world > 1 else "single"),
                    "loop": ("device-resident (forward + argmax on GPU); tensor-parallel step: %s" % ctx.tp_mode()
-                            if shards else "device-resident (forward + argmax on GPU, one hipGraph replay per token)")},
+                            if shards else "device-resident (forward + argmax on GPU, one hipGraph replay per token)"),
+                   "weights": "fp32 row-major as the checkpoint stores them + %d MiB of repacked copies for the streaming kernels (DESIGN.md section 3)"
+                              % ctx.get_option(runtime.OPT_PACKED_MIB)},
         "device_ms_per_step": round(dev_ms / K, 5),
         "algorithmic_bytes_per_token": int(bpt),
         "hbm_gbs_end_to_end": round(bpt * value / 1e9 / per_gpu_streams, 2),

@@ -64,10 +64,12 @@ enum {
   L2_OPT_EXACT_ATTENTION = 1, /* 1: value-accumulate rounds to fp32 at every timestep in t order, exactly as
                                  llama2.ts:260-265 does (bit-faithful, slower); 0 (default): fp64 partial sums */
   L2_OPT_USE_GRAPH = 2,       /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
-  L2_OPT_KEEP_STATE = 3       /* 1: the RunState fields that only transformer() itself reads (llama2.ts:131-146: att, k, v, hb2, xb2,
+  L2_OPT_KEEP_STATE = 3,      /* 1: the RunState fields that only transformer() itself reads (llama2.ts:131-146: att, k, v, hb2, xb2,
                                  the xb of the FFN half, the final-normed x) are also written out for l2_read_state (parity
                                  tests); 0 (default): they stay on chip and reading them AFTER a forward returns L2_E_STATE -- q, hb, logits and
                                  the KV caches are always there */
+  L2_OPT_PACKED_MIB = 4       /* read-only (l2_get_option): MiB of device memory held by the repacked second copies of the matrices the
+                                 streaming kernels read; 0 before the first step and for models that need none */
 };
 
 typedef struct l2_ctx l2_ctx;

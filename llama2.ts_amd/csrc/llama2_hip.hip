@@ -767,6 +767,7 @@ extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
       return L2_OK;
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
     case L2_OPT_KEEP_STATE: if (c->opt_keep_state != !!value) { c->opt_keep_state = !!value; destroy_graphs(c); } return L2_OK;
+    case L2_OPT_PACKED_MIB: return fail(L2_E_ARG, "option %d is read-only", key);
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }
@@ -777,6 +778,12 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
     case L2_OPT_EXACT_ATTENTION: *value = c->opt_exact; return L2_OK;
     case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
     case L2_OPT_KEEP_STATE: *value = c->opt_keep_state; return L2_OK;
+    case L2_OPT_PACKED_MIB: {
+      size_t floats = 0;
+      if (c->packed_valid) for (int m = 0; m < 5; ++m) if (c->packed[m].buf) floats += c->packed[m].layer_elems * (size_t)(m == MODE_CLS ? 1 : c->L);
+      *value = (int)(floats * sizeof(float) >> 20);
+      return L2_OK;
+    }
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }

@@ -697,7 +697,11 @@ def test_repacked_matrices_equal_the_row_major_ones_and_follow_uploads(built, hd
                 assert np.abs(la - want).max() <= TOL and runtime.argmax(la) == O.argmax(want), (hdr, pos)
             tok = runtime.argmax(la)
         return la
+    assert a.get_option(runtime.OPT_PACKED_MIB) == 0          # built with the first step
     before = run(0, 6, True)
+    assert a.get_option(runtime.OPT_PACKED_MIB) > 0 and b.get_option(runtime.OPT_PACKED_MIB) == 0
+    with pytest.raises(runtime.L2Error):
+        a.set_option(runtime.OPT_PACKED_MIB, 1)
     assert a.decode_greedy(1, 0, 12).tolist() == b.decode_greedy(1, 0, 12).tolist()
     rng = np.random.default_rng(5)
     cfg = a.cfg
