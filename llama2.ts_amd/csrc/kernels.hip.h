@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const PhaseArgs a, f4* dst, i
   const int n4 = a.n >> 2, cpi = 64 * U, nchunks = (n4 + cpi - 1) / cpi, ulast = (n4 - (nchunks - 1) * cpi) >> 6;
   const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
   const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
-  const int gi = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;     // e = r * n4 + column
+  const int gi = blockIdx.x, e = blockIdx.y * 256 + threadIdx.x;     // e = r * n4 + column (row groups in x: a vocabulary has more than 65535 of them)
   if (e >= R * n4) return;
   const int r = e / n4, c4 = e - r * n4;
   const float* rp[R];

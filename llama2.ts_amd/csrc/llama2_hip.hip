@@ -443,7 +443,7 @@ static int pack_phase(l2_ctx* c, int layers, PhaseArgs (*args_of)(const l2_ctx*,
   }
   for (int l = 0; l < layers; ++l) {
     const PhaseArgs a = args_of(c, l);
-    hipLaunchKernelGGL((pack_kernel<MODE, 2>), dim3((2 * n4 + 255) / 256, groups), dim3(256), 0, c->stream, a, reinterpret_cast<f4*>(p.buf + elems * (size_t)l), g.U, g.grid * g.nwaves);
+    hipLaunchKernelGGL((pack_kernel<MODE, 2>), dim3(groups, (2 * n4 + 255) / 256), dim3(256), 0, c->stream, a, reinterpret_cast<f4*>(p.buf + elems * (size_t)l), g.U, g.grid * g.nwaves);
   }
   LCHK(hipGetLastError());
   return L2_OK;

@@ -671,11 +671,13 @@ def test_launch_geometry_variants_match_reference(monkeypatch, name, env):
     ctx.close()
 
 
-@pytest.mark.parametrize("hdr", [(1280, 2560, 2, 10, 10, -1000, 48), (1280, 2572, 2, 10, 10, 1000, 48), (2048, 5632, 1, 16, 16, -777, 32)])
+@pytest.mark.parametrize("hdr", [(1280, 2560, 2, 10, 10, -1000, 48), (1280, 2572, 2, 10, 10, 1000, 48), (2048, 5632, 1, 16, 16, -777, 32),
+                                 (1280, 1280, 1, 10, 10, -140001, 16)])
 def test_repacked_matrices_equal_the_row_major_ones_and_follow_uploads(built, hdr, monkeypatch):
     """The streaming form reads a second copy of its matrices, repacked on the device in the order the chip consumes them
     (kernels.hip.h, pack_kernel): every column batch, short last batches (1280 = 2.5 batches of 512 columns), short last rounds
-    of row groups (2572 rows on 1288 waves), a phase that cannot be packed beside ones that are (2572 columns), against the
+    of row groups (2572 rows on 1288 waves), a phase that cannot be packed beside ones that are (2572 columns), a classifier
+    with more than 65535 row groups and an odd row count, against the
     oracle and BIT for bit against a context that streams the row-major tensors -- then one matrix of every phase is uploaded
     again and the packed copy has to follow."""
     monkeypatch.setenv("L2_SMALL_MAX", "0")          # the streaming form at widths that default to the latency form
