@@ -434,9 +434,10 @@ static int pack_phase(l2_ctx* c, int layers, PhaseArgs (*args_of)(const l2_ctx*,
   const Geo g = pick_geo(c, MODE, a0.rows, a0.n, a0.dim);
   const int n4 = a0.n / 4, rpg = (MODE == MODE_W13) ? 1 : 2, groups = (a0.rows + rpg - 1) / rpg;
   const bool want = c->opt_packed && !small && g.vec && g.U == 2 && n4 % 64 == 0 && n4 > 128;
-  if (!want) { if (p.buf) { hipFree(p.buf); p.buf = nullptr; } return L2_OK; }
+  // (a copy that goes away takes the captured graphs with it: they hold its address)
+  if (!want) { if (p.buf) { destroy_graphs(c); hipFree(p.buf); p.buf = nullptr; } return L2_OK; }
   const size_t elems = (size_t)groups * 2 * a0.n;
-  if (p.buf && !(p.layer_elems == elems && p.U == g.U && p.nwaves == g.nwaves && p.grid == g.grid)) { hipFree(p.buf); p.buf = nullptr; }
+  if (p.buf && !(p.layer_elems == elems && p.U == g.U && p.nwaves == g.nwaves && p.grid == g.grid)) { destroy_graphs(c); hipFree(p.buf); p.buf = nullptr; }
   if (!p.buf) {
     if (hipMalloc(&p.buf, elems * layers * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); p.buf = nullptr; return L2_OK; }
     p.layer_elems = elems; p.U = g.U; p.nwaves = g.nwaves; p.grid = g.grid;
