@@ -15,8 +15,6 @@ struct Sampler {
   float* probs_sorted = nullptr; // (V) descending (top-p)
   int* idx = nullptr;            // (V) 0..V-1
   int* idx_sorted = nullptr;     // (V) token ids in descending-probability order, ties by id (stable sort)
-  void* sort_temp = nullptr;
-  size_t sort_temp_bytes = 0;
   double* params = nullptr;      // device {temperature, topp}
   unsigned long long* rng = nullptr;   // device xorshift* state (the reference's BigInt rng_seed)
   // whole-chip form: tiles of 1024 elements (sampler.hip)
@@ -35,7 +33,7 @@ struct Sampler {
   unsigned long long* cq = nullptr;   // (G * 1024) per element: grid composite since the start of its run
   int* cm = nullptr;
   unsigned* mxkey = nullptr;     // max of the scaled logits (order-preserving key), zero between tokens
-  bool own_sort = false;         // top-p order by tile sort + rank merge (vocabularies up to 40 960); else rocPRIM radix sort
+  int rank_tg = 0;               // sorted tiles the rank merge holds in LDS at a time
   bool serial = false;           // L2_SAMPLER_SERIAL=1: one lane accumulates (the straightforward form, kept for A/B)
 };
 

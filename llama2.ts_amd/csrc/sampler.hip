@@ -19,11 +19,10 @@
 // (probability, id) keys per tile followed by one rank-by-binary-search merge of the 32 sorted tiles out of LDS.
 //
 // L2_SAMPLER_SERIAL=1 keeps the straightforward form for A/B: ONE lane adds in index order (~10 cycles per element,
-// ~130 us per pass over 32 000 values) inside a single 1024-thread workgroup, rocPRIM's radix sort for top-p.
+// ~130 us per pass over 32 000 values) inside a single 1024-thread workgroup (top-p: behind the same tile sort + rank merge).
 #include "sampler.h"
 #include "exact_sum.h"
 
-#include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 
 namespace l2s {
@@ -120,29 +119,29 @@ hipError_t create(Sampler* s, int V) {
   L2S(hipMalloc(&s->mxkey, sizeof(unsigned)));
   L2S(hipMemset(s->mxkey, 0, sizeof(unsigned)));
   { const char* g_ = getenv("L2_TEST_HOOKS"); const char* e_ = getenv("L2_SAMPLER_SERIAL"); s->serial = g_ && atoi(g_) != 0 && e_ && atoi(e_) != 0; }   // A/B form, development gate
-  // the rank merge holds every tile in LDS: 4 bytes per (padded) element of the 160 KB
-  const size_t rank_lds = padded * 4 + (size_t)s->G * 8;
-  s->own_sort = !s->serial && rank_lds <= 160 * 1024;
-  if (s->own_sort) L2S(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
-  s->sort_temp_bytes = 0;
-  if (!s->own_sort) {
-    L2S(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, s->sort_temp_bytes, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, V, 0, 32, nullptr));
-    L2S(hipMalloc(&s->sort_temp, s->sort_temp_bytes ? s->sort_temp_bytes : 16));
-  }
+  // the rank merge holds up to RANK_TG sorted tiles in LDS at a time
+  s->rank_tg = (int)((padded / STILE) < (size_t)RANK_TG ? (padded / STILE) : (size_t)RANK_TG);
+  L2S(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RANK_TG * STILE * 4 + (MAX_VOCAB / TILE) * 8));
 #undef L2S
   return hipSuccess;
 }
 
 void destroy(Sampler* s) {
-  void* bufs[] = {s->probs, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->sort_temp, s->part, s->part_sorted,
+  void* bufs[] = {s->probs, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->part, s->part_sorted,
                   s->recs, s->recs2, s->cnt, s->cnt2, s->off, s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->mxkey};
   for (void* b : bufs) if (b) (void)hipFree(b);
   *s = Sampler();
 }
 
-__global__ void iota_kernel(int* idx, int V) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < V) idx[i] = i;
+// Descending stable order of V values (probabilities, or exps still to be divided by their exact total when `fused`): sorted tiles, then the
+// rank merge writes probs_sorted / idx_sorted and adds every value to the sum of the 1024-element tile it lands in (part_sorted).
+static hipError_t sort_descending(const Sampler& s, const float* values, const ChainArgs& exps, bool fused, hipStream_t st) {
+  const int gs = (s.V + STILE - 1) / STILE, n = gs * STILE;
+  if (fused) hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
+  else hipLaunchKernelGGL(sort_tile_kernel<false>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
+  hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT), dim3(RT), (size_t)s.rank_tg * STILE * 4 + s.G * sizeof(double), st, s.run_p, s.idx, gs, s.G, s.rank_tg,
+                     s.probs_sorted, s.idx_sorted, s.part_sorted);
+  return hipGetLastError();
 }
 
 hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, unsigned long long* amax, hipStream_t st) {
@@ -152,11 +151,9 @@ hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* t
       hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.rng, tokpos, tokens_out);
       return hipGetLastError();
     }
-    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.idx);
+    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, (int*)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    size_t bytes = s.sort_temp_bytes;
-    e = hipcub::DeviceRadixSort::SortPairsDescending(s.sort_temp, bytes, s.probs, s.probs_sorted, s.idx, s.idx_sorted, s.V, 0, 32, st);
-    if (e != hipSuccess) return e;
+    if ((e = sort_descending(s, s.probs, ChainArgs(), false, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(topp_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.rng, tokpos, tokens_out);
     return hipGetLastError();
   }
@@ -170,25 +167,12 @@ hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* t
     // exact total -> probabilities -> their runs, in one launch; then sample (:368-376)
     hipLaunchKernelGGL(normalise_runs_kernel, dim3(s.G), dim3(TN), 0, st, exps, s.probs_n, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
     pick = chain_args(s, s.probs_n, s.part, true);
-  } else if (s.own_sort) {
+  } else {
     // sample_topp (:378-394): exact total -> probabilities -> sorted tiles in one launch, rank merge, runs of the sorted order
-    const int gs = (s.V + STILE - 1) / STILE, n = gs * STILE;
-    hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(gs), dim3(TN), 0, st, exps, s.probs, s.V, s.run_p, s.idx);
-    hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT), dim3(RT), (size_t)n * 4 + s.G * sizeof(double), st, s.run_p, s.idx, gs, s.G, s.probs_sorted,
-                       s.idx_sorted, s.part_sorted);
+    if ((e = sort_descending(s, s.probs, exps, true, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(runs_kernel<true>, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part_sorted, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
     pick = chain_args(s, s.probs_sorted, s.part_sorted, true);
     pick.part_sorted = s.part_sorted;
-  } else {
-    // vocabularies beyond the rank merge's LDS: rocPRIM's radix sort
-    hipLaunchKernelGGL(normalise_runs_kernel, dim3(s.G), dim3(TN), 0, st, exps, s.probs_n, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
-    hipLaunchKernelGGL(iota_kernel, dim3((s.V + 255) / 256), dim3(256), 0, st, s.idx, s.V);
-    size_t bytes = s.sort_temp_bytes;
-    e = hipcub::DeviceRadixSort::SortPairsDescending(s.sort_temp, bytes, s.probs_n, s.probs_sorted, s.idx, s.idx_sorted, s.V, 0, 32, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_sums_kernel, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part);
-    hipLaunchKernelGGL(runs_kernel<true>, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
-    pick = chain_args(s, s.probs_sorted, s.part, true);
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
   pick.tokpos = tokpos; pick.tokens_out = tokens_out; pick.amax = amax;

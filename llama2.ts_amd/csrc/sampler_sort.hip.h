@@ -72,50 +72,58 @@ __global__ void __launch_bounds__(TN) sort_tile_kernel(ChainArgs a, const float*
 // Every element's place in the merged order: its place in its own tile + the number of elements of every other tile
 // in front of it (ties: the tile with the smaller ids first), by binary search in the G sorted tiles held in LDS.
 constexpr int RT = 512;                                           // threads = elements per workgroup of the rank merge (256 and 1024: the same time)
+constexpr int RANK_TG = 38;                                       // sorted tiles a workgroup holds in LDS at a time (152 KB of the 160)
 // Also adds every element to the sum of the tile of the merged order it lands in (part[], zero on entry): the approximate
 // prefix of the next stage.  fp64 atomics in no fixed order -- the prefix only has to be approximate (exact_sum.h).
-__global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const int* run_id, int GS, int G, float* sorted, int* ids, double* part) {
-  extern __shared__ int lds_p[];                                // GS * STILE probability bit patterns (pads: negative), then G tile sums
+// Vocabularies of more than TG tiles (38 912 entries) go through LDS in groups of TG tiles, the ranks adding up over the groups.
+__global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const int* run_id, int GS, int G, int TG, float* sorted, int* ids, double* part) {
+  extern __shared__ int lds_p[];                                // TG * STILE probability bit patterns (pads: negative), then G tile sums
   const int tid = threadIdx.x, n = GS * STILE;
-  double* lpart = reinterpret_cast<double*>(lds_p + n);
-  if (tid < G) lpart[tid] = 0.0;
-  // every workgroup pulls all G tiles; measured: one 16-byte load in flight per thread (8 KB per workgroup) beats 4, 8 and 16
-  // (+5 / +5 / +8 us) -- the same lines are wanted by every CU at once and deeper queues only lengthen the wait behind them;
-  // an LDS-DMA fill (global_load_lds_dwordx4, every 1 KB chunk in flight at once) takes the same time as this loop
-  for (int j = tid * 4; j < n; j += RT * 4) *reinterpret_cast<int4*>(lds_p + j) = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(run_p) + j);
+  double* lpart = reinterpret_cast<double*>(lds_p + TG * STILE);
+  for (int j = tid; j < G; j += RT) lpart[j] = 0.0;
   const int e = blockIdx.x * RT + tid;
   const int my_id = e < n ? run_id[e] : -1;
-  __syncthreads();
-  const int mine = e < n ? lds_p[e] : -1;
-  if (mine >= 0) {                                              // not a pad
+  const int mine = e < n ? reinterpret_cast<const int*>(run_p)[e] : -1;
   const int own = e / STILE;
   int rank = e - own * STILE;
-  constexpr int U = 8;                                          // searches in flight per thread
-  for (int b0 = 0; b0 < GS; b0 += U) {
-    int lo[U], thr[U];
+  for (int g0 = 0; g0 < GS; g0 += TG) {
+    const int gt = min(TG, GS - g0), gn = gt * STILE;           // tiles g0 .. g0 + gt - 1 in LDS
+    if (g0) __syncthreads();
+    // every workgroup pulls all the tiles; measured: one 16-byte load in flight per thread (8 KB per workgroup) beats 4, 8 and 16
+    // (+5 / +5 / +8 us) -- the same lines are wanted by every CU at once and deeper queues only lengthen the wait behind them;
+    // an LDS-DMA fill (global_load_lds_dwordx4, every 1 KB chunk in flight at once) takes the same time as this loop
+    for (int j = tid * 4; j < gn; j += RT * 4) *reinterpret_cast<int4*>(lds_p + j) = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(run_p) + (size_t)g0 * STILE + j);
+    __syncthreads();
+    if (mine >= 0) {                                            // not a pad
+      constexpr int U = 8;                                      // searches in flight per thread
+      for (int b0 = 0; b0 < gt; b0 += U) {
+        int lo[U], thr[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int b = min(b0 + u, GS - 1);
-      lo[u] = b * STILE;
-      thr[u] = mine - (b < own ? 1 : 0);                        // earlier tile: elements >= mine come first; later tile: only > mine
-    }
+        for (int u = 0; u < U; ++u) {
+          const int b = min(b0 + u, gt - 1);
+          lo[u] = b * STILE;
+          thr[u] = mine - (g0 + b < own ? 1 : 0);               // earlier tile: elements >= mine come first; later tile: only > mine
+        }
 #pragma unroll
-    for (int s = STILE / 2; s > 0; s >>= 1) {
+        for (int s = STILE / 2; s > 0; s >>= 1) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) if (lds_p[lo[u] + s - 1] > thr[u]) lo[u] += s;
-    }
+          for (int u = 0; u < U; ++u) if (lds_p[lo[u] + s - 1] > thr[u]) lo[u] += s;
+        }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int b = min(b0 + u, GS - 1);
-      int cnt = lo[u] - b * STILE;
-      if (cnt == STILE - 1 && lds_p[lo[u]] > thr[u]) cnt = STILE;
-      if (b0 + u < GS && b != own) rank += cnt;
+        for (int u = 0; u < U; ++u) {
+          const int b = min(b0 + u, gt - 1);
+          int cnt = lo[u] - b * STILE;
+          if (cnt == STILE - 1 && lds_p[lo[u]] > thr[u]) cnt = STILE;
+          if (b0 + u < gt && g0 + b != own) rank += cnt;
+        }
+      }
     }
   }
-  sorted[rank] = __int_as_float(mine);
-  ids[rank] = my_id;
-  atomicAdd(lpart + rank / TILE, (double)__int_as_float(mine));
+  if (mine >= 0) {
+    sorted[rank] = __int_as_float(mine);
+    ids[rank] = my_id;
+    atomicAdd(lpart + rank / TILE, (double)__int_as_float(mine));
   }
   __syncthreads();
-  if (tid < G && lpart[tid] != 0.0) atomicAdd(part + tid, lpart[tid]);
+  for (int j = tid; j < G; j += RT) if (lpart[j] != 0.0) atomicAdd(part + j, lpart[j]);
 }
