@@ -139,7 +139,8 @@ extern "C" int l2_prefill(l2_ctx* c, const int32_t* tokens, int n_tokens, int po
   for (int i = 0; i < n_tokens; ++i) if (tokens[i] < 0 || tokens[i] >= c->V) return fail(L2_E_ARG, "token %d outside [0, vocab_size=%d)", tokens[i], c->V);
   int rc = ensure_ready(c);
   if (rc) return rc;
-  if (!can_prefill(c)) {   // shapes the 16x16 tiles do not cover: the reference's own one-token-per-call loop
+  // a single token: the decode step streams the weights once at full rate; the 16-token tile pass does not (7.7 against 4.3 ms at 7B)
+  if (n_tokens == 1 || !can_prefill(c)) {   // and shapes the 16x16 tiles do not cover: the reference's own one-token-per-call loop
     for (int i = 0; i < n_tokens; ++i) { rc = l2_forward(c, tokens[i], pos0 + i, (i == n_tokens - 1) ? logits_out : nullptr); if (rc) return rc; }
     return L2_OK;
   }
