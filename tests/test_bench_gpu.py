@@ -23,6 +23,7 @@ def test_bench_json_contract():
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 32 and j["warmup"] == 4 and j["unit"] == "tokens/s" and j["vs_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
+    assert "+ 0 MiB of repacked copies" in j["config"]["weights"]          # stories15M: latency-form phases, a one-batch classifier
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = j["cpu_baseline"]
@@ -113,6 +114,7 @@ def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
         assert len(lines) == 1, lines
         j = json.loads(lines[0])
         assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong" and j["value"] > 0
+        assert "MiB of repacked copies" in j["config"]["weights"] and "+ 0 MiB" not in j["config"]["weights"]     # 7B width: the streaming kernels' second copy
         assert "note" in j and "no RCCL" in j["note"]
         assert j["tp"]["ranks"] == 2 and j["tp"]["sharded"] and j["tp"]["l2_tp_mode"] == [3] and j["tp"]["devices"] == [0, 0]
     _retry_once(attempt)
@@ -125,3 +127,4 @@ def test_bench_gpus_one_stays_in_process():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["config"]["parallelism"] == "single" and "tp" not in j
+    assert "+ 0 MiB of repacked copies" in j["config"]["weights"]
