@@ -122,6 +122,74 @@ def pmc_traffic(name, seed):
                         "WRITE_SIZE KiB x 1024; per launch, mean of %d)" % len(vals))
 
 
+def kernel_trace_us(name, seed):
+    """Average duration of the dominant kernel as a kernel trace reports it (rocprofv3 --kernel-trace, no counters): a child of
+    this script decodes 24 tokens with eager launches.  Quoted next to the HIP-event figure: on a 5 us kernel the event pair
+    itself costs about 1 us."""
+    if under_profiler():
+        return None
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    work = tempfile.mkdtemp(prefix="l2_kt_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", work, "-o", "k", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--trace-child", "--config", name, "--seed", str(seed)]
+        env = clean_child_env(TMPDIR="/tmp", L2_USE_GRAPH="0", L2_PROFILE_SYNC="1", L2_TEST_HOOKS="1")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        files = glob.glob(os.path.join(work, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None
+        durs = []
+        for row in csv.DictReader(open(files[0])):
+            kn = row["Kernel_Name"]
+            if "phase_kernel<2," in kn or "phase_small_kernel<2," in kn:
+                durs.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
+        durs = durs[len(durs) // 4:]     # the first quarter is warm-up (clocks, caches)
+        return round(sum(durs) / len(durs), 3) if durs else None
+    except Exception:   # noqa: BLE001 -- a missing profiler must not fail the benchmark
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def trace_child(name, seed):
+    ctx = runtime.Context(configs.header(name))
+    ctx.synth_fill(seed)
+    ctx.decode_greedy(1, 0, min(24, configs.header(name)[6]))
+    ctx.close()
+
+
+# ---- parity of the run that was timed ---------------------------------------------------------------------------
+def golden_argmax(name, seed):
+    """The tokens the REAL reference chose on this synthetic checkpoint (tests/golden/<config>.json, written by
+    oracle/make_goldens.py from a run of /root/reference/llama2.ts): data, so it travels to the GPU box."""
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", name + ".json")))
+    except (OSError, ValueError):
+        return None
+    if g.get("seed") != seed or g.get("prompt") is not None or g.get("tokens_fed", [None])[0] != 1:
+        return None
+    return list(g["argmax"])
+
+
+def parity_block(name, seed, tokens):
+    """Compare the tokens of the TIMED decode with the reference's golden tokens, step by step."""
+    gold = golden_argmax(name, seed)
+    if gold is None:
+        return {"steps_checked": 0, "equal_to_reference_golden": None, "why": "no reference golden for this config / seed"}
+    n = min(len(gold), len(tokens))
+    got = [int(t) for t in tokens[:n]]
+    ok = got == gold[:n]
+    out = {"steps_checked": n, "steps_timed": len(tokens), "equal_to_reference_golden": ok,
+           "golden": "tests/golden/%s.json (%d steps of the real reference, -t 0 -s 1)" % (name, len(gold)),
+           "what": "tokens of the timed device-resident decode (l2_bench_tokens) vs the reference's argmax per step"}
+    if not ok:
+        first = next(i for i in range(n) if got[i] != gold[i])
+        out["first_mismatch"] = {"step": first, "got": got[first], "reference": gold[first]}
+    return out
+
+
 # ---- CPU baseline ------------------------------------------------------------------------------------------------
 def mem_available_gb():
     try:
@@ -179,6 +247,10 @@ def cpu_baseline(name, hdr, seed):
     out = {"value": round(1.0 / sec, 4), "unit": "tokens/s", "cores": 1, "kind": "port", "sample": sample, "extrapolated": extrapolated,
            "host_cpu": host_cpu_model()}
     out.update(reference_js_figure(name))
+    if out.get("reference_js_tok_s"):
+        out["port_vs_reference_js"] = round(out["value"] / out["reference_js_tok_s"], 2)
+        out["note"] = ("the C port on this box's host core runs %.1fx the reference's own runtime (Node, build container): GPU / reference-runtime "
+                       "ratios are that much larger than GPU / port ratios" % out["port_vs_reference_js"])
     return out
 
 
@@ -207,17 +279,24 @@ def reference_js_figure(name):
 
 
 # ---- one config on one GPU: decode loop + roofline + CPU baseline ------------------------------------------------
-def roofline_block(ctx, cfg, K, traffic, traffic_how):
+def roofline_block(ctx, cfg, K, traffic, traffic_how, trace_us=None):
     iters = 200 if cfg.dim * cfg.hidden_dim < (1 << 24) else 50
     kms_isolated = ctx.bench_gemv(runtime.T_W1, cfg.n_layers // 2, iters)
     kus, nlaunch = ctx.bench_dominant_in_situ(1, 0, min(K, 128))    # HIP events on every dispatch of the kernel, eager launches of the same kernels
     kb = dominant_kernel_bytes(cfg)
     ach = kb / (kus * 1e-6) / 1e9
-    return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_how": traffic_how,
-            "kernel": DOMINANT, "bytes_per_launch": kb, "avg_launch_us": round(kus, 3), "launches_timed": nlaunch,
-            "how": "HIP start/stop events attached to every dispatch of this kernel inside a decode run on the library's stream (hipExtLaunchKernelGGL)",
-            "isolated_back_to_back_us": round(kms_isolated * 1e3, 3)}
+    out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_how": traffic_how,
+           "kernel": DOMINANT, "bytes_per_launch": kb, "avg_launch_us": round(kus, 3), "launches_timed": nlaunch,
+           "duration_used": "avg_launch_us: HIP start/stop events on every dispatch, in situ (an event pair adds about 1 us to a dispatch: "
+                            "an upper bound on the kernel's own time, within 2 % at 50 us, tens of percent at 5 us)",
+           "how": "HIP start/stop events attached to every dispatch of this kernel inside a decode run on the library's stream (hipExtLaunchKernelGGL)",
+           "isolated_back_to_back_us": round(kms_isolated * 1e3, 3)}
+    if trace_us:
+        out["kernel_trace_us"] = trace_us
+        out["frac_kernel_trace"] = round(kb / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        out["kernel_trace_how"] = "rocprofv3 --kernel-trace over a child of this run decoding 24 tokens with eager launches: End - Start of every dispatch of this kernel, mean of the last three quarters"
+    return out
 
 
 def per_kernel_block(ctx, cfg):
@@ -231,7 +310,7 @@ def per_kernel_block(ctx, cfg):
     return out
 
 
-def secondary_config(name, seed, device, with_cpu, traffic):
+def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None):
     """BASELINE.json's metric names stories110M next to 7B: the same measurement as a block of the same JSON line."""
     hdr = configs.header(name)
     ctx = runtime.Context(hdr, device=device)
@@ -246,12 +325,24 @@ def secondary_config(name, seed, device, with_cpu, traffic):
     t0 = time.perf_counter()
     ctx.bench_decode(1, 0, K)
     wall = time.perf_counter() - t0
+    parity = parity_block(name, seed, ctx.bench_tokens(K))
     bpt = avg_bytes_per_token(hdr, 0, K)
     out = {"value": round(K / wall, 2), "unit": "tokens/s", "steps": K, "ms_per_step": round(1e3 * wall / K, 5),
            "algorithmic_bytes_per_token": int(bpt),
            "hbm_gbs_end_to_end": round(bpt * K / wall / 1e9, 2),
            "hbm_frac_end_to_end": round(bpt * K / wall / 1e9 / HBM_PEAK_GBS, 4),
-           "roofline": roofline_block(ctx, cfg, K, traffic[0], traffic[1])}
+           "parity": parity}
+    # the same K steps through the blocking drop-in boundary (llama2.ts:468 -> 478: logits to the host every token, argmax there)
+    tok = 1
+    ctx.forward(1, 0)
+    t0 = time.perf_counter()
+    dropin_tokens = []
+    for pos in range(K):
+        tok = int(np.argmax(ctx.forward(tok, pos, view=True)))
+        dropin_tokens.append(tok)
+    out["dropin_tok_s"] = round(K / (time.perf_counter() - t0), 2)
+    out["parity"]["dropin_equal_to_reference_golden"] = parity_block(name, seed, dropin_tokens)["equal_to_reference_golden"]
+    out["roofline"] = roofline_block(ctx, cfg, K, traffic[0], traffic[1], trace_us)
     out["per_kernel"] = per_kernel_block(ctx, cfg)      # back-to-back launches of each GEMV phase: us and GB/s of its matrix bytes
     S = hdr[6]
     ms = ctx.bench_decode(1, 0, S)
@@ -266,6 +357,41 @@ def secondary_config(name, seed, device, with_cpu, traffic):
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(name, hdr, seed)
     return out
+
+
+def tp_prediction(hdr, seed, device, single_ms):
+    """What the scaling curve should look like, measured on ONE GPU (no multi-GPU node is reachable in development): for G = 2, 4, 8
+    one rank's shard of the step ALONE on this GPU -- 1/G of every matrix, the 2L + 1 exchange kernels of the step running against the
+    rank's own inbox, so every launch, store and flag of the product step is there and every wait is satisfied at once (l2_create_tp
+    with L2_TP_SOLO_ID).  That is the step with a zero-latency exchange: an UPPER bound on tok/s.  What a node adds per exchange is the
+    xGMI hop (remote uncached stores + the flag's way back) and the ranks' skew; the table prices it at 2 and 5 us per exchange."""
+    out = {"how": "one rank's shard step alone on this GPU (exchange kernels against its own inbox: l2_tp_mode 5), 64 tokens from BOS; "
+                  "tok_s_zero_latency = 1 / that; the other columns add 2 us / 5 us per exchange (2L + 1 per token) for the xGMI hop and rank skew",
+           "exchanges_per_token": 2 * hdr[2] + 1, "1": {"shard_step_ms": round(single_ms, 4), "tok_s": round(1e3 / single_ms, 2)}}
+    for G in (2, 4, 8):
+        try:
+            c = runtime.Context(hdr, device=device, tp_rank=0, tp_size=G, nccl_id=runtime.TP_SOLO_ID)
+            c.synth_fill(seed)
+            n = min(64, hdr[6])
+            c.bench_decode(1, 0, n)
+            ms = c.bench_decode(1, 0, n) / n
+            c.close()
+            nx = 2 * hdr[2] + 1
+            out[str(G)] = {"shard_step_ms": round(ms, 4), "tok_s_zero_latency": round(1e3 / ms, 2),
+                           "tok_s_2us_per_exchange": round(1e3 / (ms + nx * 2e-3), 2), "tok_s_5us_per_exchange": round(1e3 / (ms + nx * 5e-3), 2)}
+        except Exception as e:   # noqa: BLE001 -- a prediction that cannot be made must not fail the benchmark
+            out[str(G)] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def committed_prediction(name, world):
+    """The prediction for this group size from the last single-GPU run whose line was committed (profiles/tp_predicted.json): a
+    multi-GPU run cannot make it itself (every GPU is busy being a rank), so the first real curve is compared with this."""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", "tp_predicted.json")))[name]
+        return {"from": "profiles/tp_predicted.json (single-GPU run, shard step alone)", "how": p.get("how"), str(world): p.get(str(world)), "1": p.get("1")}
+    except (OSError, ValueError, KeyError):
+        return {"from": None}
 
 
 def spawn_ranks(n):
@@ -309,9 +435,16 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the l2_forward (host round trip per token) loop")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    # the host driver of this pool only supports dmabuf IPC: without this, RCCL and hipIpcGetMemHandle fail in ranks a launcher
+    # other than spawn_ranks() started (set before the first HIP call of the process)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.pmc_child:
         pmc_child(args.config, args.seed)
+        return
+    if args.trace_child:
+        trace_child(args.config, args.seed)
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -329,18 +462,20 @@ def main():
 
     # counter passes first: they are child processes, and nothing in THIS process has touched the GPU yet
     traffic = {args.config: (None, "skipped (--no-pmc)")}
+    trace_us = {}
     if extras and not args.no_pmc:
         traffic[args.config] = pmc_traffic(args.config, args.seed)
+        trace_us[args.config] = kernel_trace_us(args.config, args.seed)
         if not args.no_extra and args.config == "llama2_7b":
             traffic["stories110M"] = pmc_traffic("stories110M", args.seed)
+            trace_us["stories110M"] = kernel_trace_us("stories110M", args.seed)
 
     dist = None
     tp = None
     shards = world > 1 and args.config.startswith("llama2_7b")
     if world > 1:
-        # the second-chance rendezvous below (ranks meeting through files, L2_TP_IPC_DIR) is one of the library's gated hooks;
-        # the gate is read once per process, so it is opened before the first context exists
-        os.environ.setdefault("L2_TEST_HOOKS", "1")
+        # (the second-chance rendezvous below -- ranks meeting through files -- has a switch of its own in the library,
+        # L2_TP_FILE_RENDEZVOUS, set only around that attempt: the development gate L2_TEST_HOOKS stays closed in a measured run)
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo")   # rendezvous + barriers only; the data path is inside the library
@@ -373,6 +508,10 @@ def main():
         ipc_base = os.environ.get("L2_TP_IPC_DIR")      # set from outside (tests): every attempt then meets in a directory of its own
 
         def attempt(env, fresh_id=True):
+            """Two phases, each ended by a report of every rank over gloo: (1) create the context (communicator, peer mappings,
+            start-up self-test) -- if ANY rank failed, every rank closes and nobody enters a collective; (2) fill and decode three
+            tokens.  (RCCL has no timeout: a rank that entered an all-reduce its peer never reaches would hang the job instead of
+            printing the fallback line.)"""
             err, c, toks = "", None, []
             attempts[0] += 1
             env = dict(env)
@@ -380,6 +519,7 @@ def main():
                 sub = os.path.join(ipc_base, "attempt%d" % attempts[0])     # files of an earlier, failed formation must not be read again
                 os.makedirs(sub, exist_ok=True)
                 env["L2_TP_IPC_DIR"] = sub
+            saved = {k: os.environ.get(k) for k in env}      # whatever the caller had set is put back afterwards
             for k, v in env.items():
                 os.environ[k] = v
             try:
@@ -393,15 +533,27 @@ def main():
                             idb = torch.frombuffer(bytearray(b.raw), dtype=torch.uint8).clone()
                     dist.broadcast(idb, 0)
                     nid = bytes(idb.numpy().tobytes())
+                # ---- phase 1: create
                 try:
                     if fresh_id and not any(nid):
                         raise RuntimeError("rank 0 could not create an RCCL id (%s)" % runtime.lib().l2_last_error().decode("utf8", "replace"))
                     c = runtime.Context(hdr, device=device, tp_rank=tp["rank"], tp_size=tp["size"], nccl_id=nid)
-                    c.synth_fill(args.seed)
-                    toks = c.decode_greedy(1, 0, min(3, K)).tolist()
                 except Exception as e:      # noqa: BLE001 -- whatever it is, the other ranks have to hear about it
                     err = "%s: %s" % (type(e).__name__, e)
-                mine = {"rank": rank, "err": err, "tokens": toks, "mode": c.tp_mode_id() if (c is not None and not err) else -1}
+                created = [None] * world
+                dist.all_gather_object(created, {"rank": rank, "err": err})
+                errs = [r["err"] for r in created if r["err"]]
+                if errs:
+                    if c is not None:
+                        c.close()
+                    return None, errs[0], None
+                # ---- phase 2: every rank has a context: fill, decode, compare
+                try:
+                    c.synth_fill(args.seed)
+                    toks = c.decode_greedy(1, 0, min(3, K)).tolist()
+                except Exception as e:      # noqa: BLE001
+                    err = "%s: %s" % (type(e).__name__, e)
+                mine = {"rank": rank, "err": err, "tokens": toks, "mode": c.tp_mode_id() if not err else -1}
                 every = [None] * world
                 dist.all_gather_object(every, mine)
                 errs = [r["err"] for r in every if r["err"]]
@@ -410,16 +562,17 @@ def main():
                 ok = not errs and same and (gold is None or every[0]["tokens"] == gold)
                 why = "" if ok else (errs[0] if errs else ("ranks decoded different tokens: %s" % [r["tokens"] for r in every] if not same
                                                          else "tokens %s differ from the reference golden %s" % (every[0]["tokens"], gold)))
-                if not ok and c is not None:
+                if not ok:
                     c.close()
                     c = None
                 proof = {"tokens": every[0]["tokens"], "same_on_every_rank": same, "equals_reference_golden": (None if gold is None else every[0]["tokens"] == gold)}
                 return c, why, proof
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
-                if ipc_base:
-                    os.environ["L2_TP_IPC_DIR"] = ipc_base
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
 
         notes = []
         ctx, why, tp_proof = attempt({})
@@ -430,7 +583,7 @@ def main():
             notes.append("RCCL collectives only: %s" % why)
             meet = [tempfile.mkdtemp(prefix="l2_meet_") if rank == 0 else None]
             dist.broadcast_object_list(meet, 0)
-            ctx, why, tp_proof = attempt({"L2_TP_IPC_DIR": meet[0]}, fresh_id=False)
+            ctx, why, tp_proof = attempt({"L2_TP_IPC_DIR": meet[0], "L2_TP_FILE_RENDEZVOUS": "1"}, fresh_id=False)
             if ctx is not None:
                 notes.append("the ranks met through files and exchange peer to peer (no RCCL)")
         if ctx is None:
@@ -465,6 +618,7 @@ def main():
     dev_ms = ctx.bench_decode(1, 0, K)         # EXACTLY K timed steps, HIP events on the library's stream
     sync_all()
     wall = time.perf_counter() - t0
+    timed_tokens = ctx.bench_tokens(K)         # what the timed run decoded (checked against the reference's golden below)
     if dist is not None:
         import torch
         t = torch.tensor([wall, dev_ms], dtype=torch.float64)
@@ -494,6 +648,8 @@ def main():
         "hbm_frac_end_to_end": round(bpt * value / 1e9 / per_gpu_streams / HBM_PEAK_GBS / (world if shards else 1), 4),
     }
 
+    # the tokens of the TIMED run against the real reference's tokens for this checkpoint (fixtures are data: they travel)
+    out["parity"] = parity_block(args.config, args.seed, timed_tokens)
     if dist is not None:
         # what actually ran, rank by rank, so a reader of the line can see the group had N members: l2_tp_mode
         # (0 single GPU, 1 RCCL eager, 3 peer-to-peer exchange in one hipGraph per token) and the device of every rank
@@ -502,6 +658,8 @@ def main():
         dist.all_gather_object(ranks, mine)
         out["tp"] = {"ranks": world, "sharded": bool(shards), "l2_tp_mode": sorted({r["tp_mode"] for r in ranks}),
                      "devices": [r["device"] for r in ranks], "step": ctx.tp_mode(), "proved_before_timing": tp_proof}
+    if shards:
+        out["tp_predicted"] = committed_prediction(args.config, world)
     if tp_note:
         out["note"] = tp_note
     if extras:
@@ -509,10 +667,13 @@ def main():
             tok = 1
             ctx.forward(1, 0)
             t0 = time.perf_counter()
+            dropin_tokens = []
             for pos in range(K):
                 tok = int(np.argmax(ctx.forward(tok, pos, view=True)))
+                dropin_tokens.append(tok)
             out["dropin_tok_s"] = round(K / (time.perf_counter() - t0), 3)
-        out["roofline"] = roofline_block(ctx, cfg, K, *traffic[args.config])
+            out["parity"]["dropin_equal_to_reference_golden"] = parity_block(args.config, args.seed, dropin_tokens)["equal_to_reference_golden"]
+        out["roofline"] = roofline_block(ctx, cfg, K, *traffic[args.config], trace_us.get(args.config))
         out["per_kernel"] = per_kernel_block(ctx, cfg)
         S = hdr[6]
         if not args.no_extra:
@@ -546,17 +707,28 @@ def main():
                 out[key] = round(n_p / (time.perf_counter() - t0), 1)
     ctx.close()
 
+    if extras and not args.no_extra and args.config.startswith("llama2_7b"):
+        out["tp_predicted"] = tp_prediction(hdr, args.seed, device, 1e3 * wall / K)
     if extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config, hdr, args.seed)
     if extras and not args.no_extra and args.config == "llama2_7b":
         out["stories110M"] = secondary_config("stories110M", args.seed, local_rank, not args.no_cpu_baseline,
-                                              traffic.get("stories110M", (None, "skipped")))
+                                              traffic.get("stories110M", (None, "skipped")), trace_us.get("stories110M"))
 
+    # a timed run that decoded other tokens than the reference is not a measurement: the line is still printed (it says where
+    # the first mismatch is), the exit code says no
+    bad = [nm for nm, blk in (("main", out), ("stories110M", out.get("stories110M") or {}))
+           if (blk.get("parity") or {}).get("equal_to_reference_golden") is False
+           or (blk.get("parity") or {}).get("dropin_equal_to_reference_golden") is False]
     if rank == 0:
         print(json.dumps(out))
+        if bad:
+            print("bench.py: PARITY FAILURE in %s: the timed decode does not reproduce the reference's golden tokens" % ", ".join(bad), file=sys.stderr)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

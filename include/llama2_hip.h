@@ -101,9 +101,13 @@ int l2_create_ex(const int32_t cfg[7], int device, unsigned flags, l2_ctx** out)
 int l2_tp_unique_id(void* id_out_128);
 /* How this context's tensor-parallel step runs: 0 not tensor parallel, 1 eager launches with RCCL collectives (this RCCL
  * refused stream capture, or L2_USE_GRAPH=0), 2 one hipGraph per token with the RCCL collectives captured in it, 3 one hipGraph
- * per token with the one-shot peer-to-peer all-reduce, 4 loopback test group (L2_TEST_HOOKS). */
+ * per token with the one-shot peer-to-peer all-reduce, 4 loopback test group (L2_TEST_HOOKS), 5 shard-timing context (L2_TP_SOLO_ID). */
 int l2_tp_mode(l2_ctx* ctx);
 int l2_create_tp(const int32_t cfg[7], int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out);
+/* Measurement only: a 128-byte id that starts with this text creates ONE rank of a tp_size group with no peers -- its shard of the
+ * weights and of the step, the exchange kernels running against its own inbox (every wait satisfied at once).  It times a rank's
+ * share of the step without a multi-GPU node (bench.py `tp_predicted`); what it decodes is meaningless (l2_tp_mode 5). */
+#define L2_TP_SOLO_ID "L2-SOLO-SHARD-TIMING"
 
 /* Replaces the hand-over of one Float32Array of TransformerWeights (readWeights, llama2.ts:112-129):
  * call once per array right after FileHandleReader.getF32Array returns it (llama2.ts:51-59).
@@ -190,6 +194,9 @@ int l2_bench_gemv(l2_ctx* ctx, int tensor_kind, int layer, int iters, float* avg
 int l2_bench_dominant_in_situ(l2_ctx* ctx, int first_token, int pos0, int steps, float* avg_us, int* launches);
 /* `steps` forwards (greedy feed, device-resident) timed with events: total device ms. */
 int l2_bench_decode(l2_ctx* ctx, int first_token, int pos0, int steps, float* total_ms);
+/* The first `n` tokens the last device-resident run (l2_bench_decode, l2_decode_greedy, l2_decode_sample) chose: lets a benchmark
+ * check the very run it timed against the reference's tokens (llama2.ts:476-478 picks them on the host). */
+int l2_bench_tokens(l2_ctx* ctx, int32_t* tokens_out, int n);
 
 #ifdef __cplusplus
 }

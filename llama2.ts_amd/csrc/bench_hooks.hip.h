@@ -7,6 +7,17 @@ extern "C" int l2_bench_decode(l2_ctx* c, int first_token, int pos0, int steps, 
   return run_greedy(c, first_token, pos0, steps, true, total_ms);
 }
 
+// The tokens the last device-resident run chose (l2_bench_decode keeps them on the device like l2_decode_greedy does): bench.py
+// checks the run it TIMED against the reference's golden tokens, not a second run.
+extern "C" int l2_bench_tokens(l2_ctx* c, int32_t* tokens_out, int n) {
+  if (!c || (!tokens_out && n > 0)) return fail(L2_E_ARG, "null argument");
+  if (n < 0 || n > c->S) return fail(L2_E_ARG, "%d tokens asked for, a run holds at most seq_len = %d", n, c->S);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (n > 0) HIPCHK(hipMemcpy(tokens_out, c->d_tokens, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  return L2_OK;
+}
+
 // The dominant kernel (rmsnorm + w1/w3 GEMV + SwiGLU) timed IN SITU: `steps` greedy decode steps launched eagerly
 // with a HIP event pair around every one of its launches on the library's stream; mean duration in microseconds.
 extern "C" int l2_bench_dominant_in_situ(l2_ctx* c, int first_token, int pos0, int steps, float* avg_us, int* launches) {

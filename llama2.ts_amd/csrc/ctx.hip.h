@@ -113,6 +113,7 @@ struct P2PArgs {
   int* err;
   int G, rank, n;              // n: elements of this exchange (d, or V_loc)
   unsigned long long wait_ticks;   // bound of a flag wait, in 100 MHz ticks
+  int solo;                    // shard-timing context (l2_create_tp with the L2_TP_SOLO_ID id): every "peer" is this rank itself
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -146,6 +147,7 @@ struct l2_ctx {
   bool p2p_peers_ready = false;
   bool rccl_graph = false;           // the RCCL collectives of the step are captured into the per-token hipGraph (cleared if capture is refused)
   unsigned long long p2p_wait_ticks = 3000000000ull;   // L2_TP_WAIT_S (default 30 s) on the 100 MHz clock
+  bool solo = false;                 // shard-timing context: one rank of G alone, the exchange kernels run against its own inbox (timing only, sums are G x the partial)
   bool p2p_synced = false;           // the ranks have met once (host side) right before the first exchange of a step
   bool broken = false;               // a peer-to-peer wait gave up: this rank's epochs no longer match its peers'
 
@@ -194,12 +196,32 @@ struct l2_ctx {
   int tune_R = 0, tune_U = 0, tune_nwaves = 0, tune_gridcap = 0, tune_rot = 5;
   // Streaming-form matrices repacked in consumption order (kernels.hip.h, phase_body PK): a second copy, per phase (MODE_*),
   // built on the device from the row-major tensors (which prefill, the embedding gather and l2_read_tensor keep using).
-  struct Packed { float* buf = nullptr; size_t layer_elems = 0; int U = 0, nwaves = 0, grid = 0; } packed[5];
-  bool packed_valid = false;        // false after any upload: rebuilt before the next step
+  struct Packed { float* buf = nullptr; size_t layer_elems = 0; int U = 0, nwaves = 0, grid = 0; std::vector<uint8_t> dirty; bool noted = false; } packed[5];
+  bool packed_valid = false;        // false after an upload of a matrix a packed phase reads: its (phase, layer) slices are rebuilt before the next step
   int opt_packed = 1;               // L2_PACKED=0: stream the row-major tensors (A/B)
 };
 
 static bool is_layered(int kind) { return kind >= L2_T_RMS_ATT && kind <= L2_T_W3; }
+
+// An upload dirties only the repacked slice (phase, layer) that holds that matrix; vectors and tables dirty nothing.
+// layer < 0: every layer of the tensor.
+static void mark_dirty(l2_ctx* c, int kind, int layer) {
+  int m = -1;
+  switch (kind) {
+    case L2_T_WQ: case L2_T_WK: case L2_T_WV: m = MODE_QKV; break;
+    case L2_T_WO: m = MODE_WO; break;
+    case L2_T_W1: case L2_T_W3: m = MODE_W13; break;
+    case L2_T_W2: m = MODE_W2; break;
+    case L2_T_WCLS: m = MODE_CLS; layer = 0; break;
+    case L2_T_TOKEN_EMBEDDING: if (c->shared) { m = MODE_CLS; layer = 0; } break;
+    default: break;
+  }
+  if (m < 0) return;
+  std::vector<uint8_t>& d = c->packed[m].dirty;
+  if (layer < 0) { for (auto& b : d) b = 1; }
+  else if ((size_t)layer < d.size()) d[layer] = 1;
+  c->packed_valid = false;
+}
 
 // Local (per-rank) shape of one layer of a tensor: rows x cols, plus where the slice sits in the
 // full tensor (row0/col0) so l2_upload can cut it out of the caller's full array.
@@ -236,4 +258,11 @@ static bool hooks_on() { static const bool on = env_int("L2_TEST_HOOKS", 0) != 0
 static int hook_int(const char* name) { return hooks_on() ? env_int(name, 0) : 0; }
 // development switches (launch geometry, attention split policy, A/B forms): the same gate, with the shipped default otherwise
 static int dev_int(const char* name, int dflt) { return hooks_on() ? env_int(name, dflt) : dflt; }
-static const char* hook_str(const char* name) { const char* s = hooks_on() ? getenv(name) : nullptr; return (s && *s) ? s : nullptr; }
+// The file rendezvous of a tensor-parallel group (ranks that cannot share an RCCL communicator meet in a directory) has a switch of
+// its own, L2_TP_FILE_RENDEZVOUS=1 + L2_TP_IPC_DIR=<dir>, read at every create: bench.py's last-resort attempt needs it without
+// opening the whole development gate in a measured run.
+static const char* ipc_dir_env() {
+  if (!hooks_on() && env_int("L2_TP_FILE_RENDEZVOUS", 0) == 0) return nullptr;
+  const char* s = getenv("L2_TP_IPC_DIR");
+  return (s && *s) ? s : nullptr;
+}

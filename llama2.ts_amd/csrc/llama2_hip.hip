@@ -105,6 +105,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
 
 static int p2p_alloc(l2_ctx* c);
 static int p2p_connect_ipc(l2_ctx* c);
+static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits);
 
 static int create_impl(const int32_t cfg[7], int device, int rank, int G, const void* nccl_id, l2_ctx** out, unsigned flags = 0) {
   if (!cfg || !out) return fail(L2_E_ARG, "null argument");
@@ -224,7 +225,15 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipStreamSynchronize(c->stream));
 #undef CK
   if (c->tp_path && !hook_int("L2_TP_NO_COMM")) { const int rc_ = p2p_alloc(c); if (rc_) { l2_destroy(c); return rc_; } }
-  if (G > 1 && hook_int("L2_TP_NO_COMM")) {
+  if (G > 1 && nccl_id && !memcmp(nccl_id, L2_TP_SOLO_ID, sizeof(L2_TP_SOLO_ID) - 1)) {
+    // shard timing (bench.py's tp_predicted): this rank's shard of the step alone on its GPU, the exchange kernels running against
+    // its own inbox -- same launches, same stores, same flags, every wait satisfied at once.  The sums are G x the partial, so what
+    // such a context decodes is meaningless; l2_tp_mode reports 5.
+    if (!c->p2p_base) { l2_destroy(c); return fail(L2_E_COMM, "shard-timing context: no peer-to-peer inbox (G > %d, or L2_TP_ALLREDUCE=rccl)", (int)P2P_MAXG); }
+    c->solo = true;
+    for (int r = 0; r < G; ++r) p2p_set_peer(c, r, c->p2p_base, c->logits);
+    c->p2p = true; c->p2p_peers_ready = true; c->p2p_synced = true;
+  } else if (G > 1 && hook_int("L2_TP_NO_COMM")) {
     // shard-layout tests on a single GPU: the slices are real, the communicator is absent and every
     // forward on this context fails with L2_E_COMM
   } else if (G > 1 && hook_int("L2_TP_LOOPBACK")) {
@@ -237,8 +246,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     c->loop = grp;
     grp->p2p_base[rank] = c->p2p_base; grp->p2p_logits[rank] = c->logits;
     c->p2p = c->p2p_base != nullptr;          // peers resolved at the first step, once every rank has registered
-  } else if (G > 1 && hook_str("L2_TP_IPC_DIR")) {
-    c->ipc_dir = hook_str("L2_TP_IPC_DIR");
+  } else if (G > 1 && ipc_dir_env()) {
+    c->ipc_dir = ipc_dir_env();
     const int rc = p2p_connect_ipc(c);
     if (rc) { l2_destroy(c); return rc; }
   } else if (c->tp_path) {
@@ -306,6 +315,7 @@ extern "C" int l2_tp_unique_id(void* id_out_128) {
 
 extern "C" int l2_tp_mode(l2_ctx* c) {
   if (!c || !c->tp_path) return 0;
+  if (c->solo) return 5;
   if (c->loop) return 4;
   if (c->p2p) return 3;
   return (c->rccl_graph && c->opt_graph) ? 2 : 1;
@@ -348,7 +358,7 @@ extern "C" int l2_upload(l2_ctx* c, int kind, int layer, const float* host, size
     HIPCHK(hipMemcpy2D(dst, s.cols * sizeof(float), src, s.full_cols * sizeof(float), s.cols * sizeof(float), s.rows, hipMemcpyHostToDevice));
   }
   c->uploaded[kind][li] = 1;
-  c->packed_valid = false;
+  mark_dirty(c, kind, li);
   return L2_OK;
 }
 
@@ -435,16 +445,27 @@ static int pack_phase(l2_ctx* c, int layers, PhaseArgs (*args_of)(const l2_ctx*,
   const int n4 = a0.n / 4, rpg = (MODE == MODE_W13) ? 1 : 2, groups = (a0.rows + rpg - 1) / rpg;
   const bool want = c->opt_packed && !small && g.vec && g.U == 2 && n4 % 64 == 0 && n4 > 128;
   // (a copy that goes away takes the captured graphs with it: they hold its address)
-  if (!want) { if (p.buf) { destroy_graphs(c); hipFree(p.buf); p.buf = nullptr; } return L2_OK; }
+  if (!want) { if (p.buf) { destroy_graphs(c); hipFree(p.buf); p.buf = nullptr; } p.dirty.clear(); return L2_OK; }
   const size_t elems = (size_t)groups * 2 * a0.n;
   if (p.buf && !(p.layer_elems == elems && p.U == g.U && p.nwaves == g.nwaves && p.grid == g.grid)) { destroy_graphs(c); hipFree(p.buf); p.buf = nullptr; }
   if (!p.buf) {
-    if (hipMalloc(&p.buf, elems * layers * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); p.buf = nullptr; return L2_OK; }
+    if (hipMalloc(&p.buf, elems * layers * sizeof(float)) != hipSuccess) {
+      (void)hipGetLastError(); p.buf = nullptr; p.dirty.clear();
+      if (!p.noted) {   // said once: the phase still runs (it streams the row-major tensor), only slower
+        fprintf(stderr, "libllama2hip: no device memory for the repacked copy of phase %d (%zu MiB): streaming the row-major tensors instead\n", MODE, elems * layers * sizeof(float) >> 20);
+        p.noted = true;
+      }
+      return L2_OK;
+    }
     p.layer_elems = elems; p.U = g.U; p.nwaves = g.nwaves; p.grid = g.grid;
+    p.dirty.assign(layers, 1);
   }
+  if ((int)p.dirty.size() != layers) p.dirty.assign(layers, 1);
   for (int l = 0; l < layers; ++l) {
+    if (!p.dirty[l]) continue;       // only the slices whose matrices were uploaded since the last step
     const PhaseArgs a = args_of(c, l);
     hipLaunchKernelGGL((pack_kernel<MODE, 2>), dim3(groups, (2 * n4 + 255) / 256), dim3(256), 0, c->stream, a, reinterpret_cast<f4*>(p.buf + elems * (size_t)l), g.U, g.grid * g.nwaves);
+    p.dirty[l] = 0;
   }
   LCHK(hipGetLastError());
   return L2_OK;
@@ -511,8 +532,10 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
 static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
 
 static int ensure_ready(l2_ctx* c) {
+  // everything below may allocate and launch (ensure_packed): the context's device first, whatever the calling thread had current
+  HIPCHK(hipSetDevice(c->device));
   if (c->broken) return fail(L2_E_COMM, "tensor-parallel context is unusable: an earlier peer-to-peer exchange timed out");
-  if (c->tp_path && !c->comm && !c->loop && !(c->p2p && !c->ipc_dir.empty())) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
+  if (c->tp_path && !c->comm && !c->loop && !c->solo && !(c->p2p && !c->ipc_dir.empty())) return fail(L2_E_COMM, "tensor-parallel context has no communicator (L2_TP_NO_COMM)");
   if (c->loop && c->p2p && !c->p2p_peers_ready) {
     if (!c->loop->wait()) return fail(L2_E_COMM, "loopback group: a rank never arrived");
     for (int r = 0; r < c->G; ++r) {

@@ -88,7 +88,7 @@ extern "C" int l2_load_checkpoint(const char* path, int device, int tp_rank, int
       }
       (void)full_layer;
       c->uploaded[kind][layer] = 1;
-      c->packed_valid = false;
+      mark_dirty(c, kind, (int)layer);
     }
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) return cleanup(fail(L2_E_HIP, "upload sync failed"));
@@ -179,7 +179,7 @@ extern "C" int l2_synth_fill(l2_ctx* c, uint32_t seed) {
       HIPCHK(hipGetLastError());
     }
     for (auto& u : c->uploaded[kind]) u = 1;
-    c->packed_valid = false;
+    mark_dirty(c, kind, -1);
     off += n;
   }
   HIPCHK(hipStreamSynchronize(c->stream));

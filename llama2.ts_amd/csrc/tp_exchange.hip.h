@@ -25,7 +25,8 @@ __device__ __forceinline__ void p2p_raise(const P2PArgs& a, unsigned long long e
   const int par = (int)(e & 1), b = blockIdx.x;
   __threadfence_system();
   __syncthreads();
-  if (tid < a.G) __hip_atomic_store(a.pr.flags[tid] + ((size_t)(par * P2P_MAXG + a.rank) * P2P_FB + b), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (solo: the G flags this rank would receive, raised by itself in its own inbox)
+  if (tid < a.G) __hip_atomic_store(a.pr.flags[a.solo ? a.rank : tid] + ((size_t)(par * P2P_MAXG + (a.solo ? tid : a.rank)) * P2P_FB + b), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ... then wait for every source's flag in the local inbox
 __device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e, int tid) {
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, con
   if (PART != 2) {
     for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
       const double v = partial[i];
-      for (int p = 0; p < a.G; ++p) a.pr.inbox[p][slot + (size_t)a.rank * a.n + i] = v;
+      for (int p = 0; p < a.G; ++p) a.pr.inbox[a.solo ? a.rank : p][slot + (size_t)(a.solo ? p : a.rank) * a.n + i] = v;
     }
   }
   if (PART == 1) { p2p_raise(a, e, tid); return; }
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256) tp_p2p_gather_kernel(const P2PArgs a, con
   if (PART != 2) {
     for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
       const float v = mine[i];
-      for (int p = 0; p < a.G; ++p) a.pr.logits[p][(size_t)a.rank * a.n + i] = v;
+      for (int p = 0; p < a.G; ++p) a.pr.logits[a.solo ? a.rank : p][(size_t)(a.solo ? p : a.rank) * a.n + i] = v;
     }
   }
   if (PART == 1) { p2p_raise(a, e, tid); return; }
@@ -126,7 +127,7 @@ static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits) {
 static P2PArgs p2p_args(const l2_ctx* c, int n) {
   P2PArgs a;
   a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = (unsigned*)(c->p2p_epoch + 1); a.err = c->p2p_err_dev;
-  a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks;
+  a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks; a.solo = c->solo ? 1 : 0;
   return a;
 }
 static int p2p_grid(int n) { const int b = (n + 255) / 256; return b > P2P_FB ? P2P_FB : (b < 1 ? 1 : b); }

@@ -27,12 +27,13 @@ STATE_IDS = dict(x=S_X, xb=S_XB, xb2=S_XB2, hb=S_HB, hb2=S_HB2, q=S_Q, k=S_K, v=
                  key_cache=S_KEY_CACHE, value_cache=S_VALUE_CACHE)
 OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_KEEP_STATE, OPT_PACKED_MIB = 1, 2, 3, 4
 F_GQA, F_GENERATE_ROPE = 1, 2     # l2_create_ex flags
+TP_SOLO_ID = b"L2-SOLO-SHARD-TIMING"   # l2_create_tp id of a shard-timing context (include/llama2_hip.h: L2_TP_SOLO_ID)
 
 # every symbol include/llama2_hip.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
                "l2_decode_greedy", "l2_decode_sample", "l2_debug_running_sums", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
-               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ", "l2_tp_mode", "l2_create_ex"]
+               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ", "l2_tp_mode", "l2_create_ex", "l2_bench_tokens"]
 
 
 class L2Error(RuntimeError):
@@ -84,6 +85,7 @@ def lib():
     L.l2_tp_mode.argtypes = [vp]
     L.l2_create_ex.argtypes = [vp, i32, u32, C.POINTER(vp)]
     L.l2_tp_mode.restype = i32
+    L.l2_bench_tokens.argtypes = [vp, vp, i32]
     for name in ABI_SYMBOLS:   # fail at load time, not at first use, if the .so is stale
         getattr(L, name)
     _lib = L
@@ -271,12 +273,18 @@ class Context:
         return {0: "single GPU", 1: "eager launches, 2L RCCL fp64 all-reduces + 1 all-gather per token",
                 2: "one hipGraph per token with the RCCL collectives captured in it",
                 3: "one hipGraph per token, one-shot peer-to-peer fp64 all-reduce inside the residual kernels",
-                4: "loopback test group"}.get(lib().l2_tp_mode(self._h), "?")
+                4: "loopback test group", 5: "shard timing only (one rank alone, exchange against its own inbox)"}.get(lib().l2_tp_mode(self._h), "?")
 
     def bench_decode(self, first_token, pos0, steps):
         ms = C.c_float()
         _check(lib().l2_bench_decode(self._h, first_token, pos0, steps, C.byref(ms)))
         return ms.value
+
+    def bench_tokens(self, n):
+        """The first n tokens the last device-resident run (bench_decode / decode_greedy / decode_sample) chose."""
+        out = np.zeros(n, dtype=np.int32)
+        _check(lib().l2_bench_tokens(self._h, out.ctypes.data, int(n)))
+        return out
 
 
 class TransformerWeights:

@@ -29,6 +29,28 @@ def test_bench_json_contract():
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert abs(j["value"] - 1e3 / j["ms_per_step"]) / j["value"] < 0.01
+    # the run that was TIMED is checked against the real reference's tokens (tests/golden/stories15M.json), and so is the drop-in loop
+    pr = j["parity"]
+    assert pr["steps_checked"] == 32 and pr["equal_to_reference_golden"] is True and pr["dropin_equal_to_reference_golden"] is True
+    assert rf["kernel_trace_us"] is None or 0 < rf["kernel_trace_us"] <= rf["avg_launch_us"] * 1.2
+    assert "duration_used" in rf
+
+
+def test_bench_exits_nonzero_when_the_timed_tokens_are_not_the_references(tmp_path):
+    """A benchmark that decodes other tokens than the reference did is not a measurement: same shape, another seed for the weights,
+    the golden file of the default seed forged to claim that seed -> the line carries the first mismatch and the exit code is 3."""
+    import shutil
+    work = tmp_path / "repo"
+    shutil.copytree(ROOT, work, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "__pycache__", "*.npz", "tools"))
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "stories15M.json")))
+    g["seed"] = g["seed"] + 1
+    json.dump(g, open(work / "tests" / "golden" / "stories15M.json", "w"))
+    r = subprocess.run([sys.executable, str(work / "bench.py"), "--config", "stories15M", "--steps", "16", "--warmup", "2", "--seed", str(g["seed"]),
+                        "--no-cpu-baseline", "--no-pmc", "--no-extra", "--no-dropin"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr.decode()[-1500:])
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert j["parity"]["equal_to_reference_golden"] is False and "first_mismatch" in j["parity"]
+    assert "PARITY FAILURE" in r.stderr.decode()
 
 
 def test_bench_two_ranks_replicas_on_one_gpu():
@@ -45,13 +67,21 @@ def test_bench_two_ranks_replicas_on_one_gpu():
     assert j["value"] > 0
 
 
+CO_RESIDENCY = ("never raised its flag", "did not arrive", "failed its self-test", "exchange timed out")
+
+
 def _retry_once(fn):
     """Two ranks' exchange kernels on ONE GPU wait for each other without a guarantee of being resident together (the product runs one
-    rank per GPU); a bounded wait that gives up there says nothing about the code under test, so these stand-ins get a second try."""
+    rank per GPU); a BOUNDED WAIT that gives up there says nothing about the code under test, so these stand-ins get a second try --
+    for that failure only: wrong tokens, a golden mismatch or a missing marker fail at once (a race in the flag protocol must not
+    pass on its second run)."""
     try:
         return fn(0)
     except AssertionError as e:
-        print("\n[two ranks on one GPU] first attempt failed (%s); retrying once" % str(e)[:300])
+        if not any(m in str(e) for m in CO_RESIDENCY):
+            raise
+        import warnings
+        warnings.warn("two ranks on one GPU: a bounded wait gave up on the first attempt (co-residency); retried once: %s" % str(e)[:300])
         return fn(1)
 
 
@@ -74,8 +104,8 @@ def test_bench_tensor_parallel_flow_with_two_processes_on_one_gpu(tmp_path):
         meet = tmp_path / ("meet%d" % k)
         meet.mkdir()
         j = _two_ranks({"L2_TP_IPC_DIR": str(meet), "L2_TP_WAIT_S": "10"}, tmp_path, 29613 + 20 * k)
-        assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["parallelism"] == "tp2" and j["value"] > 0
-        assert "peer-to-peer" in j["config"]["loop"] and "note" not in j
+        assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["parallelism"] == "tp2" and j["value"] > 0, j.get("note")
+        assert "peer-to-peer" in j["config"]["loop"] and "note" not in j, j.get("note")
     _retry_once(attempt)
 
 
@@ -85,7 +115,7 @@ def test_bench_second_chance_without_rccl(tmp_path):
     all, with a note that names every step."""
     def attempt(k):
         j = _two_ranks({"L2_TP_WAIT_S": "10"}, tmp_path, 29615 + 20 * k)
-        assert j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong"
+        assert j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong", j.get("note")
         assert "RCCL + peer-to-peer exchange:" in j["note"] and "RCCL collectives only:" in j["note"] and "no RCCL" in j["note"]
         # every formation is proved before it is timed: all ranks decoded the same tokens, and they are the real reference's
         pr = j["tp"]["proved_before_timing"]
@@ -113,7 +143,7 @@ def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
         lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
         assert len(lines) == 1, lines
         j = json.loads(lines[0])
-        assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong" and j["value"] > 0
+        assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong" and j["value"] > 0, j.get("note")
         assert "MiB of repacked copies" in j["config"]["weights"] and "+ 0 MiB" not in j["config"]["weights"]     # 7B width: the streaming kernels' second copy
         assert "note" in j and "no RCCL" in j["note"]
         assert j["tp"]["ranks"] == 2 and j["tp"]["sharded"] and j["tp"]["l2_tp_mode"] == [3] and j["tp"]["devices"] == [0, 0]
@@ -128,3 +158,26 @@ def test_bench_gpus_one_stays_in_process():
     j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["config"]["parallelism"] == "single" and "tp" not in j
     assert "+ 0 MiB of repacked copies" in j["config"]["weights"]
+
+
+def test_bench_gpus_8_forms_an_eight_rank_group_by_itself(tmp_path):
+    """What the driver's scaling run does for N = 8, on the one GPU of this box: plain `python bench.py --gpus 8 --config llama2_7b_L2`,
+    eight processes through bench's OWN launcher, and WITHOUT the development gate (L2_TEST_HOOKS unset): RCCL refuses eight ranks on
+    one device, so the ranks meet through files under the library's narrow switch (L2_TP_FILE_RENDEZVOUS, set by bench.py around that
+    attempt only).  The line must show an 8-rank sharded group that was proved against the reference's golden before it was timed, and
+    the timed run's tokens checked too (llama2.ts:270, 292 are the reduce points)."""
+    def attempt(k):
+        env = dict(os.environ, L2_BENCH_FORCE_DEVICE="0", L2_TP_WAIT_S="20")
+        for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "L2_TEST_HOOKS", "HSA_ENABLE_IPC_MODE_LEGACY", "L2_TP_IPC_DIR"):
+            env.pop(v, None)        # HSA_ENABLE_IPC_MODE_LEGACY: bench.py sets its own default
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "llama2_7b_L2", "--steps", "16",
+                            "--warmup", "2", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+        assert j["n_gpus"] == 8 and j["config"]["parallelism"] == "tp8" and j["scaling"] == "strong" and j["value"] > 0, j.get("note")
+        assert j["tp"]["ranks"] == 8 and j["tp"]["sharded"] and j["tp"]["l2_tp_mode"] == [3] and j["tp"]["devices"] == [0] * 8
+        pr = j["tp"]["proved_before_timing"]
+        assert pr["same_on_every_rank"] and pr["equals_reference_golden"] is True
+        assert j["parity"]["equal_to_reference_golden"] is True and j["parity"]["steps_checked"] == 16
+        assert "tp_predicted" in j
+    _retry_once(attempt)

@@ -236,9 +236,11 @@ print("rank", rank, "ok", flush=True)
     # G kernels of G PROCESSES that wait for each other's flags are not guaranteed to be resident together on ONE GPU (the
     # product runs one rank per GPU): if the GPU's process scheduler serialises them a bounded wait gives up (seen once in several
     # hundred runs, on a freshly started box).  That is a property of this one-GPU stand-in, so the group gets a second try.
+    # Only THAT failure is retried: wrong tokens, a golden mismatch or a missing marker fail at once.
     bad = run_group(meet)
-    if bad:
-        print("\n[process group of %d on one GPU] first attempt failed, retrying once:\n%s" % (G, bad[0][-800:]))
+    if bad and all(any(m in b for m in ("never raised its flag", "did not arrive", "failed its self-test", "exchange timed out")) for b in bad):
+        import warnings
+        warnings.warn("process group of %d on one GPU: a bounded wait gave up on the first attempt (co-residency); retried once" % G)
         meet2 = tmp_path / "meet2"
         meet2.mkdir()
         bad = run_group(meet2)
