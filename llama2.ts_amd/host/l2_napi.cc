@@ -38,6 +38,7 @@ struct Api {
   decltype(&l2_load_checkpoint) load_checkpoint;
   decltype(&l2_get_header) get_header;
   decltype(&l2_prefill) prefill;
+  decltype(&l2_read_tensor) read_tensor;
 } api;
 
 std::string g_load_error;
@@ -57,7 +58,7 @@ bool load_library(const char* hint) {
   api.name = (decltype(api.name))dlsym(api.so, "l2_" #name);               \
   if (!api.name) { g_load_error = "missing symbol l2_" #name; dlclose(api.so); api.so = nullptr; return false; }
   BIND(abi_version) BIND(device_count) BIND(last_error) BIND(create) BIND(destroy) BIND(upload) BIND(synth_fill)
-  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(decode_sample) BIND(read_state) BIND(set_option) BIND(load_checkpoint) BIND(get_header) BIND(prefill)
+  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(decode_sample) BIND(read_state) BIND(set_option) BIND(load_checkpoint) BIND(get_header) BIND(prefill) BIND(read_tensor)
 #undef BIND
   if (api.abi_version() != L2_ABI_VERSION) { g_load_error = "ABI version mismatch"; dlclose(api.so); api.so = nullptr; return false; }
   return true;
@@ -360,6 +361,22 @@ napi_value ReadState(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// readTensor(handle, kind, layer, offset, Float32Array)      (what l2_upload stored: tests of the hand-over of llama2.ts:51-59's views)
+napi_value ReadTensor(napi_env env, napi_callback_info info) {
+  ARGS(5)
+  l2_ctx* c;
+  int32_t kind, layer;
+  int64_t offset;
+  float* out;
+  size_t n;
+  if (!get_ctx(env, argv[0], &c) || !get_i32(env, argv[1], &kind) || !get_i32(env, argv[2], &layer)) return nullptr;
+  if (napi_get_value_int64(env, argv[3], &offset) != napi_ok || offset < 0) return throw_err(env, "offset must be a non-negative integer");
+  if (!get_f32_array(env, argv[4], &out, &n, false)) return nullptr;
+  int rc = api.read_tensor(c, kind, layer, (size_t)offset, out, n);
+  if (rc) return throw_l2(env, rc);
+  return nullptr;
+}
+
 napi_value SetOption(napi_env env, napi_callback_info info) {
   ARGS(3)
   l2_ctx* c;
@@ -381,7 +398,7 @@ napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"upload", Upload}, {"synthFill", SynthFill},
       {"forward", Forward}, {"logitsBuffer", LogitsBuffer}, {"decodeGreedy", DecodeGreedy}, {"decodeSample", DecodeSample}, {"readState", ReadState},
-      {"setOption", SetOption}, {"deviceCount", DeviceCount}, {"loadCheckpoint", LoadCheckpoint}, {"prefill", Prefill}};
+      {"setOption", SetOption}, {"deviceCount", DeviceCount}, {"loadCheckpoint", LoadCheckpoint}, {"prefill", Prefill}, {"readTensor", ReadTensor}};
   for (auto& f : fns) {
     napi_value v;
     napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);

@@ -29,6 +29,8 @@ export function decodeGreedy(ctx: L2Handle, firstToken: number, pos0: number, st
 export function decodeSample(ctx: L2Handle, firstToken: number, pos0: number, steps: number, temperature: number, topp: number, rng: Uint32Array): Int32Array;
 /** Parity reads of RunState fields (L2_S_* of include/llama2_hip.h); fields only transformer() reads need setOption(ctx, 3, 1) first. */
 export function readState(ctx: L2Handle, which: number, layer: number, out: Float32Array): void;
+/** Read back `out.length` floats at float offset `offset` of a weight tensor as l2_upload stored it (tests). */
+export function readTensor(ctx: L2Handle, kind: number, layer: number, offset: number, out: Float32Array): void;
 /** L2_OPT_* of include/llama2_hip.h: 1 exact attention, 2 use hipGraph, 3 keep state. */
 export function setOption(ctx: L2Handle, key: number, value: number): void;
 export function deviceCount(): number;

@@ -109,6 +109,63 @@ def test_native_loader_prints_the_same(workdir):
     assert text_of(res["tokens"]) == want
 
 
+def test_metrics_line_on_stderr(workdir):
+    """--metrics: one JSON line on stderr (tok/s, algorithmic bytes per token, GB/s, fraction of the 8 TB/s peak) -- stdout stays the ids."""
+    from llama2_ts_amd import configs
+    flags, prompt_ids, want = reference_run("cli_greedy")
+    for loop in ("host", "device"):
+        rc, res, err = run_ids(workdir, argv_for(flags, prompt_ids, loop, ("--metrics",)))
+        assert rc == 0, err
+        assert text_of(res["tokens"]) == want
+        m = json.loads([l for l in err.splitlines() if l.startswith("{")][-1])["metrics"]
+        hdr = json.load(open(os.path.join(GOLD, "cli_greedy.json")))["header"]
+        n = m["tokens_timed"]
+        assert n == int(flags["-n"]) and m["loop"] == loop and m["hbm_peak_gb_s"] == 8000
+        want_bytes = sum(configs.algorithmic_bytes_per_token(tuple(hdr), p) for p in range(n)) / n
+        assert abs(m["algorithmic_bytes_per_token"] - want_bytes) <= 1
+        assert m["tok_s"] > 0 and abs(m["hbm_gb_s"] - m["tok_s"] * m["algorithmic_bytes_per_token"] / 1e9) / m["hbm_gb_s"] < 1e-3
+        assert abs(m["hbm_frac"] - m["hbm_gb_s"] / 8000) < 1e-9
+
+
+def test_offset_views_through_the_real_addon(workdir, tmp_path):
+    """llama2.ts:56 makes its Float32Arrays as views (buffer.buffer, buffer.byteOffset, n): the addon must hand the VIEW's bytes to
+    l2_upload.  Arrays with byteOffset != 0 (a plain ArrayBuffer view, and a pooled Buffer the way the reference builds it) go up
+    through the real addon into HBM and come back through readTensor; the bytes around the views are poison."""
+    js = tmp_path / "offset.js"
+    js.write_text("""
+const a = require(%r); a.open(%r);
+const ctx = a.create(new Int32Array([64, 176, 2, 4, 4, 512, 64]), 0);
+const n = 64 * 64, off = 40;
+const buf = new ArrayBuffer(off + n * 4 + 24);
+new Float32Array(buf, 0, 10).fill(9e9); new Float32Array(buf, off + n * 4, 6).fill(-9e9);
+const v = new Float32Array(buf, off, n);
+for (let i = 0; i < n; ++i) v[i] = i * 0.25 - 3;
+a.upload(ctx, 2, 1, v);                                        // wq[1]
+const back = new Float32Array(new ArrayBuffer(n * 4 + 8), 8, n);
+a.readTensor(ctx, 2, 1, 0, back);
+let bad = 0;
+for (let i = 0; i < n; ++i) if (back[i] !== v[i]) ++bad;
+// the reference's own construction on a pooled Buffer (small allocUnsafe buffers share one ArrayBuffer: byteOffset != 0)
+let b = Buffer.allocUnsafe(64 * 4), tries = 0;
+while (b.byteOffset == 0 && ++tries < 64) b = Buffer.allocUnsafe(64 * 4);
+const w = new Float32Array(b.buffer, b.byteOffset, 64);
+for (let i = 0; i < 64; ++i) w[i] = 1 + i / 64;
+a.upload(ctx, 1, 0, w);                                        // rms_att_weight[0]
+const back2 = new Float32Array(64);
+a.readTensor(ctx, 1, 0, 0, back2);
+let bad2 = 0;
+for (let i = 0; i < 64; ++i) if (back2[i] !== w[i]) ++bad2;
+const tail = new Float32Array(3);
+a.readTensor(ctx, 2, 1, n - 3, tail);                          // an offset read of the tensor's end
+console.log(JSON.stringify({ viewOffset: v.byteOffset, bad, pooledOffset: w.byteOffset, bad2, tail: Array.from(tail), want: [v[n - 3], v[n - 2], v[n - 1]] }));
+a.destroy(ctx);
+""" % (os.path.join(ROOT, "llama2.ts_amd", "host", "l2_napi.node"), os.path.join(ROOT, "llama2.ts_amd", "lib", "libllama2hip.so")))
+    r = subprocess.run(["node", str(js)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    j = json.loads(r.stdout.decode())
+    assert j["viewOffset"] == 40 and j["bad"] == 0 and j["pooledOffset"] != 0 and j["bad2"] == 0 and j["tail"] == j["want"]
+
+
 def test_errors_surface_as_exit_code_one(workdir):
     r = subprocess.run(["node", HOST], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and "usage" in r.stderr.decode()

@@ -47,7 +47,7 @@ def test_addon_exports_and_fails_without_gpu(built, tmp_path):
         os.path.join(ROOT, "llama2.ts_amd", "lib", "libllama2hip.so"))
     r = subprocess.run(["node", "-e", js], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     out = r.stdout.decode().splitlines()
-    assert out[0] == "create,decodeGreedy,decodeSample,destroy,deviceCount,forward,loadCheckpoint,logitsBuffer,open,prefill,readState,setOption,synthFill,upload"
+    assert out[0] == "create,decodeGreedy,decodeSample,destroy,deviceCount,forward,loadCheckpoint,logitsBuffer,open,prefill,readState,readTensor,setOption,synthFill,upload"
     import torch
     if not torch.cuda.is_available():
         assert out[1].startswith("ERR libllama2hip: no HIP device visible")
@@ -74,3 +74,34 @@ def test_typescript_declarations_cover_the_addon(built):
     r = subprocess.run(["node", "-e", js], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
     assert declared == r.stdout.decode().strip().split(",")
+
+
+def test_typescript_twin_erases_to_the_module(built, tmp_path):
+    """`host stays TypeScript` taken literally: l2_backend.ts is the same module in erasable-syntax TypeScript.  Stripping its types
+    with the stripper the reference itself ships (sucrase inside /root/reference/t348.mjs -- what the reference's own loader does to
+    llama2.ts at import) must give l2_backend.mjs back token for token (comments and whitespace aside), and the stripped file must
+    load under this box's Node with the same exports."""
+    import re
+    import sys
+    if not os.path.exists("/root/reference/t348.mjs"):
+        pytest.skip("the reference (and its bundled type stripper) is not on this box")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_goldens as mg
+    host = os.path.join(ROOT, "llama2.ts_amd", "host")
+    out = tmp_path / "l2_backend.stripped.mjs"
+    mg.strip_types(os.path.join(host, "l2_backend.ts"), str(out))
+
+    def code(src):
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r'(^|[^:"])//[^\n]*', r"\1", src)
+        return re.sub(r"\s+", "", src)
+    assert code(out.read_text()) == code(open(os.path.join(host, "l2_backend.mjs")).read())
+    ts = open(os.path.join(host, "l2_backend.ts")).read()
+    for banned in ("enum ", "namespace ", "constructor(private", "constructor(public", "import type"):     # erasable syntax only
+        assert banned not in ts
+    js = ("import * as a from %r; import * as b from %r; console.log(Object.keys(a).sort().join(',') == Object.keys(b).sort().join(','), Object.keys(a).length)"
+          % (str(out), os.path.join(host, "l2_backend.mjs")))
+    probe = tmp_path / "probe.mjs"
+    probe.write_text(js)
+    r = subprocess.run(["node", str(probe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout.decode().split()[0] == "true", r.stderr.decode()[-800:]
