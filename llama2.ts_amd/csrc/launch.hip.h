@@ -84,6 +84,7 @@ static void launch_probed(const l2_ctx* c, K kernel, dim3 grid, dim3 block, size
 // 8 float4 per lane; everything else (Llama-2-7B's phases, every classifier) streams through phase_kernel.
 static bool use_small(const l2_ctx* c, int mode, int rows, int n) {
   if (n % 4 || n > 2048 || mode == MODE_CLS) return false;
+  if (mode == MODE_W13 && n > 1536) return false;      // two matrices x 8 float4 of x per lane do not fit the register file (the instance spilled): stream
   const long long elems = (long long)rows * n * (mode == MODE_W13 ? 2 : 1);
   return elems <= (long long)c->small_max;
 }
@@ -116,7 +117,7 @@ static hipError_t launch_small(const l2_ctx* c, const PhaseArgs& a, hipStream_t 
     case 3: return launch_small_xv<MODE, 3>(c, a, st);
     case 4: return launch_small_xv<MODE, 4>(c, a, st);
     case 5: case 6: return launch_small_xv<MODE, 6>(c, a, st);
-    default: return launch_small_xv<MODE, 8>(c, a, st);
+    default: if constexpr (MODE == MODE_W13) return hipErrorInvalidValue; else return launch_small_xv<MODE, 8>(c, a, st);   // use_small() keeps W13 out
   }
 }
 
@@ -175,10 +176,14 @@ static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
 #endif
 }
 
-// Lanes per cache row: head_size / 4 rounded up to a power of two (attention.hip.h); waves per workgroup: 8 from
-// 128-wide heads (a round is then 256 rows), else 4.
+// Lanes per cache row: head_size / 4 rounded up to a power of two (attention.hip.h); waves per workgroup: 8 for heads of
+// 65 .. 128 floats (a round is then 256 rows), else 4 -- heads wider than 128 (a whole wave per row) keep the 4-wave form:
+// their 8-wave instance needs more than 256 registers and spilled.
 static int attn_lr(int hs) { int l = 4; while (l * 4 < hs) l <<= 1; return l; }
-static int attn_nw(const l2_ctx* c) { return (c->attn_nw == 4 || c->attn_nw == 8) ? c->attn_nw : (c->hs > 64 ? 8 : 4); }
+static int attn_nw(const l2_ctx* c) {
+  if (c->hs > 128) return 4;
+  return (c->attn_nw == 4 || c->attn_nw == 8) ? c->attn_nw : (c->hs > 64 ? 8 : 4);
+}
 
 // One launch of the tile kernel; ny = splits (decode) or queries of the chunk (prefill, pos0 >= 0).
 static hipError_t launch_attn_tile(const l2_ctx* c, const AttnArgs& a, int ny, int pos0, hipStream_t st) {
@@ -196,7 +201,7 @@ static hipError_t launch_attn_tile(const l2_ctx* c, const AttnArgs& a, int ny, i
     case 8: L2_AT_NW(8); break;
     case 16: L2_AT_NW(16); break;
     case 32: L2_AT_NW(32); break;
-    default: L2_AT_NW(64); break;
+    default: L2_AT(64, 4, 16); break;     // attn_nw(): never 8 waves for these
   }
 #undef L2_AT_NW
 #undef L2_AT

@@ -37,8 +37,8 @@ static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int
     }
   }
   const dim3 grid(a.rows / 16);
-  // four token tiles: the LDS form's 8-block register sets (32 activation fragments) leave one spilled wave per SIMD: 3200 vs 3490 tok/s
-  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && (tt < 4 || c->pf_lds >= 3)) {
+  // (four token tiles never take the LDS form: its 8-block register sets spilled -- 3200 vs 3490 tok/s -- and that instance is gone)
+  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && tt < 4) {
     const size_t tiles = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
     const size_t parts = (size_t)4 * 2 * 3 * 4 * 64 * 8;
     const size_t lds = tiles > parts ? tiles : parts;
@@ -46,19 +46,17 @@ static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int
     if (!attr) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
-    if (tt == 4) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 4>), grid, dim3(256), lds, st, a);
-    else if (tt == 2) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 2>), grid, dim3(256), lds, st, a);
+    if (tt == 2) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 2>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 1>), grid, dim3(256), lds, st, a);
     return;
   }
-#define L2_PFG(NW) do { if (tt == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 4>), grid, dim3(64 * NW), 0, st, a); \
-                        else if (tt == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 2>), grid, dim3(64 * NW), 0, st, a); \
-                        else hipLaunchKernelGGL((pf_gemm_kernel<MODE, NW, 1>), grid, dim3(64 * NW), 0, st, a); } while (0)
-  if (nw <= 4) L2_PFG(4); else L2_PFG(8);
-#undef L2_PFG
+  // four waves split K (the eight-wave instances spilled and were never launched: removed)
+  (void)nw;
+  if (tt == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE, 4, 4>), grid, dim3(256), 0, st, a);
+  else if (tt == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE, 4, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((pf_gemm_kernel<MODE, 4, 1>), grid, dim3(256), 0, st, a);
 }
 
 // One launch sequence for up to PF_S chunks of PF_T prompt positions (n tokens at pos0 ...): every GEMM sees all of them.

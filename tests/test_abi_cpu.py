@@ -105,3 +105,35 @@ def test_bun_ffi_snippet_matches_the_header():
         rt = m.group(1).strip()
         want = "cstring" if "char" in rt else ("void" if rt.endswith("void") else "i32")
         assert ret == want, (name, rt, ret)
+
+
+def test_no_shipped_kernel_spills_registers(tmp_path):
+    """Every gfx950 kernel in libllama2hip.so runs out of registers only: the code object's metadata must report no scratch
+    (private segment) and no spilled VGPR for any of them (scalar registers parked in spare VGPR lanes -- sgpr_spill_count with no
+    private segment -- cost a lane move each and are listed, not refused) -- a spilling instance is correct and slow, and nothing else
+    would notice (three such instances off the benchmark shapes were found by a reviewer's -S build, not by a test)."""
+    import re
+    import shutil
+    import subprocess
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("no ROCm llvm tools here")
+    so = tmp_path / "lib.so"
+    shutil.copy(runtime.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path))
+    objs = [p for p in os.listdir(tmp_path) if "gfx950" in p]
+    assert objs, "no gfx950 code object in the library"
+    kernels, bad = 0, []
+    for o in objs:
+        notes = subprocess.check_output([readelf, "--notes", str(tmp_path / o)]).decode()
+        for blk in notes.split(".name:")[1:]:
+            name = blk.split()[0]
+            m = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count):\s+(\d+)", blk)}
+            if "private_segment_fixed_size" not in m:
+                continue          # an argument's .name, not a kernel's
+            kernels += 1
+            if m["private_segment_fixed_size"] or m.get("vgpr_spill_count"):
+                bad.append((name, m))
+            elif m.get("sgpr_spill_count"):
+                print("scalar registers kept in VGPR lanes:", m["sgpr_spill_count"], name)
+    assert kernels > 100 and not bad, bad

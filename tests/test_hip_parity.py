@@ -130,7 +130,13 @@ def _random_headers(count, seed):
     return out
 
 
-@pytest.mark.parametrize("hdr", _random_headers(14, 20261003))
+# shapes that take a kernel instance nothing else reaches: heads wider than 128 floats (a whole wave per cache row: the 4-wave
+# attention form), input widths of 1537 .. 2048 floats (w1 / w3 leave the latency form for the streaming one there, the other
+# phases take the latency form's widest instance)
+WIDE_SHAPES = [(512, 640, 1, 2, 2, 300, 150), (384, 1000, 2, 2, 2, -211, 40), (1792, 2304, 1, 14, 14, 257, 24), (2048, 1600, 1, 16, 16, -130, 20)]
+
+
+@pytest.mark.parametrize("hdr", _random_headers(14, 20261003) + WIDE_SHAPES)
 def test_random_shapes_match_the_oracle(built, hdr):
     """Shapes nobody tuned for -- odd hidden sizes, head sizes that are not powers of two or not multiples of 4 (scalar kernels),
     one head, vocabularies that are not multiples of anything, shared and unshared classifiers, contexts shorter than a tile --
