@@ -34,11 +34,55 @@ struct AttnArgs {
   unsigned* counter;     // split form: [H] merge tickets (one per 128-byte line), zero between launches
   int dim, head_size, seq_len, n_heads, nsplit;
   int kv_dim, kv_mul;    // floats of a cache row; query heads per cache head (1 unless the context honours n_kv_heads < n_heads)
+  int cmax, ns_shift;    // (seq_len + nsplit - 1) / nsplit; log2(nsplit) when it is a power of two, else -1 (the kernels' prologue does not divide)
   double inv_sqrt_hs;    // 1 / sqrt(head_size)
   int exact;             // 1: fp32-rounded t-sequential value accumulate (llama2.ts:263); never with nsplit > 1
   int pos_plus1;         // scalar fallback kernel, prefill: non-zero = the queries are pos0 + blockIdx.y (else tokpos)
+  // fused QKV + attention launch (qkv_attn_small_kernel): q, k, v of THIS position arrive as hand-off granules from the workgroups
+  // of the same launch that compute them (kernels.hip.h: granule_store)
+  const unsigned long long* gran;   // [dim + 2 kv_dim] words, tag = *gran_ep + 1
+  unsigned* gran_ep;               // launch counter: read by every workgroup at its start, advanced once per launch by whoever finishes head 0
+  int* herr;                       // host-mapped: set when a granule wait gave up
+  unsigned long long wait_ticks;   // bound of that wait on the 100 MHz clock
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
 };
+
+// A wave's wait for its hand-off granules (fused launch): every lane has up to N words to collect; all L1-bypassing loads of a pass
+// are issued together (ONE round trip per pass), and the wave leaves when every lane has every value.  Bounded by wall time: the
+// producers are workgroups of the same launch with LOWER block ids, already dispatched when this workgroup runs, so the wait can
+// only give up if the launch itself is broken -- then the host hears about it (herr) instead of the GPU hanging.
+template <int N>
+__device__ __forceinline__ void granules_wait(const unsigned long long* const (&g)[N], float (&v)[N], unsigned tag, int* herr, unsigned long long wait_ticks) {
+  unsigned spins = 0;
+  unsigned long long t0 = 0;
+  for (;;) {
+    unsigned long long x[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = __hip_atomic_load(g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { ok = ok && (unsigned)(x[k] >> 32) == tag; v[k] = __uint_as_float((unsigned)x[k]); }
+    if (__all(ok)) return;
+    if ((++spins & 255u) == 0) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (!t0) t0 = now;
+      else if (now - t0 > wait_ticks) { *herr = 1; return; }
+    }
+  }
+}
+
+// Fused launch: every head has a launch counter of its own, gran_ep[h]; the granules of head h carry tag gran_ep[h] + 1.  The
+// workgroup that finishes head h (its only one, or the merger of its splits) stores the new number when it is done -- a plain
+// store nobody waits for.  Every reader of gran_ep[h] in this launch has read it by then: the attention workgroups of head h read
+// it before they take their ticket, and a QKV wave reads it before it stores a granule that head h waits for.
+__device__ __forceinline__ void fused_head_done(const AttnArgs& a, int h, unsigned tag, int tid) {
+  if (tid == 0) a.gran_ep[h] = tag;
+}
+
+// rows of a split: ceil(T / nsplit) -- a shift for the split counts in use (1, 8)
+__device__ __forceinline__ int attn_chunk(const AttnArgs& a, int T) {
+  return a.ns_shift >= 0 ? (T + a.nsplit - 1) >> a.ns_shift : (T + a.nsplit - 1) / a.nsplit;
+}
 
 constexpr int ATT_PS = 65;       // doubles per tile slot in the transpose buffer (odd: conflict-free reads)
 
@@ -51,15 +95,19 @@ __host__ __device__ inline size_t attn_tile_lds(int S, int nsplit, int NW, int N
   return (size_t)((cmax + 3) & ~3) * 4 + 32 * 8 + (size_t)NW * NT * ATT_PS * 8;
 }
 
-template <int LR, int NW, int NT>
+// FUSED: this workgroup runs in the launch that computes q, k, v of position `pos` (qkv_attn_small_kernel).  Cache rows 0 .. pos - 1
+// are requested at once like always (the descriptor ends at row pos: the row being written reads as zeros and contributes
+// nothing); q, then k and v of row pos come as granules: the score of row pos is one wave's dot product of the q and k granules,
+// its share of the output att[pos] * v[pos] is added where the partial sums are folded -- fp64, one rounding, like every other row.
+template <int LR, int NW, int NT, bool FUSED = false>
 __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, const int h, const int sp, const int pos) {
   constexpr int RPT = 64 / LR;             // rows per tile
   constexpr int RG = NT * RPT;         // rows per wave per round
   constexpr int RR = NW * RG;              // rows per workgroup per round
   constexpr int NTH = 64 * NW;
   const int S = a.seq_len, hs = a.head_size, dim = a.kv_dim, NS = a.nsplit;   // `dim`: the stride of the cache rows
-  const int hk = h / a.kv_mul;                                                // this head's columns of a cache row
-  const int cmax = (S + NS - 1) / NS;
+  const int hk = a.kv_mul == 1 ? h : h / a.kv_mul;                            // this head's columns of a cache row
+  const int cmax = a.cmax;
   float* sc = reinterpret_cast<float*>(smem);
   double* red = reinterpret_cast<double*>(smem + (size_t)((cmax + 3) & ~3) * 4);
   double* P = red + 32;
@@ -67,7 +115,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = pos + 1;
-  const int chunk = (T + NS - 1) / NS;
+  const int chunk = attn_chunk(a, T);
   const int t0 = sp * chunk, t1 = min(T, t0 + chunk);
   const int n = max(t1 - t0, 0);                       // rows of this workgroup
   const int rounds = (n + RR - 1) / RR;
@@ -75,14 +123,16 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   const bool cl = 4 * c < hs;                           // lanes past the head's width carry zeros
   const int cc4 = cl ? 4 * c : 0;
 
-  STAMP_INIT(a.dbg);
+  STAMP_INIT_SEL(a.dbg, FUSED ? ((h == 0 && sp == 0) ? 2 : -1) : -2);      // fused launch: head 0's workgroup is the stamped one
   STAMP(0);
   // ---- requests first: K tiles of round 0, then q, then (single round) the V tiles of round 0.
   // Buffer loads: ONE 32-bit lane offset for all 16 tiles of a set (the tile stride goes in the scalar offset), and
   // the descriptor ends at row t1, so rows past this workgroup's slice read as zeros -- no clamps, no predicates.
   f4 ra[NT], rb[NT];
   auto row_of = [&](int rd, int j) { return ((rd * NT + j) * NW + wave) * RPT + r; };   // relative to t0
-  const unsigned slab = (unsigned)max(t1, 0) * (unsigned)dim * 4u;
+  const bool own_pos = FUSED && t1 == T && n > 0;      // this split ends with the row of this position
+  const int n_tile = own_pos ? n - 1 : n;               // rows that come through the cache tiles
+  const unsigned slab = (unsigned)max(FUSED ? min(t1, pos) : t1, 0) * (unsigned)dim * 4u;
   const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.kc), 0, slab, 0x00020000);
   const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vc), 0, slab, 0x00020000);
   const unsigned voff = (unsigned)(((size_t)(t0 + wave * RPT + r) * dim + (size_t)hk * hs + cc4) * 4);
@@ -93,8 +143,26 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       buf[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(values ? vrs : krs, voff, (unsigned)(rd * NT + j) * tstride, 0));
   };
   issue(ra, false, 0);
-  const f4 q4 = *reinterpret_cast<const f4*>(a.q + (size_t)h * hs + cc4);
+  f4 q4;
+  if (!FUSED) q4 = *reinterpret_cast<const f4*>(a.q + (size_t)h * hs + cc4);
   if (rounds <= 1) issue(rb, true, 0);
+  // FUSED: the cache tiles are in flight; now ONE wait for everything of this position the lane will need: its four q values,
+  // and -- the wave that scores row pos -- q[i] and k[i], and -- the threads that fold the output -- v[i] (hs <= 64: one each)
+  float gk_q = 0.0f, gk_k = 0.0f, gv = 0.0f;
+  unsigned ftag = 0;
+  if (FUSED) {
+    const unsigned tag = ftag = const_cast<const unsigned*>(a.gran_ep)[h] + 1u;      // advanced by an EARLIER launch (and again only when this head is done)
+    const unsigned long long* gq = a.gran + (size_t)h * hs + cc4;
+    const bool need_k = own_pos && wave == NW - 1 && lane < hs, need_v = own_pos && tid < hs;
+    const unsigned long long* const gp[7] = {gq, gq + 1, gq + 2, gq + 3,
+        need_k ? a.gran + (size_t)h * hs + lane : gq, need_k ? a.gran + (size_t)a.dim + (size_t)hk * hs + lane : gq,
+        need_v ? a.gran + (size_t)a.dim + a.kv_dim + (size_t)hk * hs + tid : gq};
+    float gvals[7];
+    granules_wait<7>(gp, gvals, tag, a.herr, a.wait_ticks);
+    STAMP(6);
+    q4.x = gvals[0]; q4.y = gvals[1]; q4.z = gvals[2]; q4.w = gvals[3];
+    gk_q = need_k ? gvals[4] : 0.0f; gk_k = need_k ? gvals[5] : 0.0f; gv = need_v ? gvals[6] : 0.0f;
+  }
   const double q0 = cl ? (double)q4.x : 0.0, q1 = cl ? (double)q4.y : 0.0, q2 = cl ? (double)q4.z : 0.0, q3 = cl ? (double)q4.w : 0.0;
   const double rsq = a.inv_sqrt_hs;             // 1 / sqrt(head_size), rounded once by the host (llama2.ts:253 divides)
   double* Pw = P + (size_t)wave * NT * ATT_PS;
@@ -119,10 +187,16 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
       for (int k = 0; k < LR; k += 4) { s0 += pp[k]; s1 += pp[k + 1]; s2 += pp[k + 2]; s3 += pp[k + 3]; }
-      if (tr < n) sc[tr] = (float)(((s0 + s1) + (s2 + s3)) * rsq);
+      if (tr < n_tile) sc[tr] = (float)(((s0 + s1) + (s2 + s3)) * rsq);
     }
     __builtin_amdgcn_wave_barrier();
   };
+  if (FUSED) {
+    if (own_pos && wave == NW - 1) {   // score of row pos from the handed-off q and k (llama2.ts:249-253), by the wave with the fewest tile rows
+      const double s = wave_sum((double)gk_q * (double)gk_k);
+      if (lane == 0) sc[n - 1] = (float)(s * rsq);
+    }
+  }
   if (rounds <= 1) {
     score_round(ra, 0);
   } else {
@@ -191,7 +265,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int tr = row_of(rd, j);
-      const double at = (tr < n) ? (double)sc[tr] : 0.0;
+      const double at = (tr < n_tile) ? (double)sc[tr] : 0.0;
       if (j & 1) { e0 += at * (double)buf[j].x; e1 += at * (double)buf[j].y; e2 += at * (double)buf[j].z; e3 += at * (double)buf[j].w; }
       else { o0 += at * (double)buf[j].x; o1 += at * (double)buf[j].y; o2 += at * (double)buf[j].z; o3 += at * (double)buf[j].w; }
     }
@@ -224,9 +298,12 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
         c0 += pacc[(size_t)g * hs + i]; c1 += pacc[(size_t)(g + 1) * hs + i];
         c2 += pacc[(size_t)(g + 2) * hs + i]; c3 += pacc[(size_t)(g + 3) * hs + i];
       }
-      a.xb[(size_t)h * hs + i] = (float)((c0 + c1) + (c2 + c3));   // ONE rounding of the fp64 sum
+      double own = 0.0;
+      if (FUSED) { if (own_pos) own = (double)sc[n - 1] * (double)gv; }      // hs <= 64 <= NTH: i == tid
+      a.xb[(size_t)h * hs + i] = (float)(((c0 + c1) + (c2 + c3)) + own);   // ONE rounding of the fp64 sum
     }
     STAMP(5);
+    if (FUSED) fused_head_done(a, h, ftag, tid);
     return;
   }
 
@@ -240,7 +317,9 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       c0 += pacc[(size_t)g * hs + i]; c1 += pacc[(size_t)(g + 1) * hs + i];
       c2 += pacc[(size_t)(g + 2) * hs + i]; c3 += pacc[(size_t)(g + 3) * hs + i];
     }
-    st_sc1(mypart + i, (c0 + c1) + (c2 + c3));
+    double own = 0.0;
+    if (FUSED) { if (own_pos) own = (double)sc[n - 1] * (double)gv; }
+    st_sc1(mypart + i, ((c0 + c1) + (c2 + c3)) + own);
   }
   if (tid == 0) { st_sc1(mypart + hs, sum); st_sc1(mypart + hs + 1, (double)mx); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
@@ -293,19 +372,48 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
     }
   }
   if (tid == 0) __hip_atomic_store(a.counter + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every split has its ticket: re-arm
+  if (FUSED) fused_head_done(a, h, ftag, tid);
 }
 
 // Tiles per wave per round by the rows this workgroup has: a short context requests (and pays address-path cycles
 // for) only the tiles it has -- NT / 4, NT / 2 or NT (one round covers NW * NT * 64 / LR rows).
-template <int LR, int NW, int NT>
+template <int LR, int NW, int NT, bool FUSED = false>
 __device__ __forceinline__ void attn_tile_dispatch(const AttnArgs& a, char* smem, const int h, const int sp, const int pos) {
-  const int T = pos + 1, NS = a.nsplit;
-  const int chunk = (T + NS - 1) / NS;
+  const int T = pos + 1;
+  const int chunk = attn_chunk(a, T);
   const int n = min(T, sp * chunk + chunk) - sp * chunk;
   constexpr int RQ = NW * (NT / 4) * (64 / LR);
-  if (n <= RQ) attn_tile_body<LR, NW, NT / 4>(a, smem, h, sp, pos);
-  else if (n <= 2 * RQ) attn_tile_body<LR, NW, NT / 2>(a, smem, h, sp, pos);
-  else attn_tile_body<LR, NW, NT>(a, smem, h, sp, pos);
+  if (n <= RQ) attn_tile_body<LR, NW, NT / 4, FUSED>(a, smem, h, sp, pos);
+  else if (n <= 2 * RQ) attn_tile_body<LR, NW, NT / 2, FUSED>(a, smem, h, sp, pos);
+  else attn_tile_body<LR, NW, NT, FUSED>(a, smem, h, sp, pos);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ONE launch for the two phases whose edge is head-local (llama2.ts:216-240 -> 244-267): the first gridDim.x - H * nsplit
+// workgroups are the latency-form QKV phase (rmsnorm + q, k, v GEMVs + RoPE + cache rows), the LAST H * nsplit are the attention
+// workgroups of the heads.  An attention workgroup requests its cache rows the moment it starts -- they depend on nothing of
+// this position -- and the three vectors that do arrive as hand-off granules straight from the waves that compute them: no
+// launch boundary between the phases, and the cache rows' way from HBM is hidden behind the GEMV.  Workgroups are dispatched in
+// block order, so every producer is resident (or done) before a consumer starts to wait: nothing here can deadlock, and the
+// wait is bounded anyway.  Needs one cache head per query head (no grouped queries) and the latency form's 512-thread workgroups.
+template <int XV, int LR, int NT>
+__global__ void __launch_bounds__(512) qkv_attn_small_kernel(const PhaseArgs a, const AttnArgs at, const int nattn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Every kernel argument either role needs is fetched HERE, in one batch: left alone, hipcc sinks the argument loads into the
+  // role branches and fetches them in four or five dependent rounds (the scalar cache is cold at the start of a launch: ~0.2 us a
+  // round, ~1 us before the first weight request -- seen with tools/stamps_fused.py).  An empty asm statement that names the
+  // values as scalar inputs makes them due before the branch.
+#define L2_PIN4(x0, x1, x2, x3) asm volatile("" ::"s"(x0), "s"(x1), "s"(x2), "s"(x3))
+  L2_PIN4(a.w0, a.w1, a.w2, a.in); L2_PIN4(a.emb, a.rmsw, a.out, a.out_k); L2_PIN4(a.out_v, a.fr, a.fi, a.tokpos);
+  L2_PIN4(a.n, a.rows, a.dim, a.kv_dim); L2_PIN4(a.head_size, a.gran, a.gran_ep, a.inv_n); asm volatile("" ::"s"(a.gran_hmagic)); asm volatile("" ::"s"(a.aux), "s"(a.aux2));
+  L2_PIN4(at.kc, at.vc, at.att, at.xb); L2_PIN4(at.tokpos, at.part, at.counter, at.dim); L2_PIN4(at.head_size, at.seq_len, at.n_heads, at.nsplit);
+  L2_PIN4(at.kv_dim, at.kv_mul, at.cmax, at.ns_shift); L2_PIN4(at.inv_sqrt_hs, at.gran, at.gran_ep, at.herr); L2_PIN4(at.wait_ticks, at.exact, nattn, at.dbg);
+#undef L2_PIN4
+  const int nq = (int)gridDim.x - nattn;
+  if ((int)blockIdx.x < nq) { phase_small_body<MODE_QKV, XV, 2>(a, smem, blockIdx.x, nq); return; }
+  int sp = 0, h = (int)blockIdx.x - nq;
+  while (h >= at.n_heads) { h -= at.n_heads; ++sp; }               // (split, head) without a division: at most nsplit steps
+  attn_tile_dispatch<LR, 8, NT, true>(at, smem, h, sp, at.tokpos[1]);
 }
 
 template <int LR, int NW, int NT>
@@ -324,7 +432,7 @@ __global__ void __launch_bounds__(64 * NW) pf_attn_tile_kernel(const AttnArgs a,
   b.q = a.q + (size_t)p * a.dim;
   b.xb = a.xb + (size_t)p * a.dim;
   b.att = nullptr;
-  b.nsplit = 1;
+  b.nsplit = 1; b.cmax = a.seq_len; b.ns_shift = 0;
   attn_tile_dispatch<LR, NW, NT>(b, smem, blockIdx.x, 0, pos0 + p);
 }
 

@@ -161,6 +161,12 @@ struct l2_ctx {
   double* partial = nullptr;
   double* attn_part = nullptr;      // split attention partials [H][NS][rec]
   unsigned* attn_counter = nullptr; // [H] arrival tickets, zero between launches
+  unsigned long long* gran = nullptr;   // fused QKV + attention launch: [d + 2 kvd] hand-off granules (kernels.hip.h: granule_store)
+  unsigned* gran_ep = nullptr;          // {launch counter the granule tags come from, heads done in this launch}
+  int* h_herr = nullptr;                // pinned + mapped: a granule wait gave up
+  int* h_herr_dev = nullptr;
+  int opt_fuse = 1;                     // L2_FUSE_QKV_ATTN=0: two launches (A/B, development switch)
+  int opt_fuse_splits = 0;              // L2_FUSE_SPLITS=1: the fused launch also at the split level (A/B, tests: it is slower there)
   unsigned long long* amax = nullptr;   // greedy loop: 8 argmax keys, one per 128-byte line, zero between tokens
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int pf3 = 1;                      // L2_PF3: 1 (default) register-blocked prefill GEMMs where the shape allows, 0: the 16-row-tile kernels everywhere (A/B, tests)
@@ -168,6 +174,7 @@ struct l2_ctx {
   int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int cur_splits = 1;               // split count of the step being enqueued / captured
   int split_rows = 144;             // L2_ATTN_SPLIT_ROWS: cached rows of a head beyond which attention runs 8 workgroups per head
+  bool split_rows_set = false;      // the switch was given: it also overrides the fused launch's 256
   int attn_nw = 0;                  // L2_ATTN_NW: waves per attention workgroup (0: by head size)
   int small_max = 0;                // L2_SMALL_MAX: largest matrix (floats) that takes the latency-form GEMV
   int n_cus = 256;

@@ -38,14 +38,14 @@ struct Stamps {
   unsigned long long* dst;
   unsigned long long* wg;      // every workgroup: {start, end} on the constant 100 MHz clock all XCDs share (s_memrealtime)
   unsigned long long rt0;
-  __device__ __forceinline__ Stamps(unsigned long long* dbg, unsigned long long* dbg_wg = nullptr) {
+  __device__ __forceinline__ Stamps(unsigned long long* dbg, unsigned long long* dbg_wg = nullptr, int force_sel = -2) {
     wg = (dbg_wg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) ? dbg_wg + 2 * blockIdx.x : nullptr;
     rt0 = __builtin_readcyclecounter();
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0));
 #pragma unroll
     for (int k = 0; k < L2_NSTAMP; ++k) t[k] = 0;
     const int b = blockIdx.x, nb = gridDim.x, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int sel = (b == 0) ? 0 : (b == nb / 2) ? 1 : (b == nb - 1) ? 2 : -1;
+    const int sel = force_sel != -2 ? force_sel : (b == 0) ? 0 : (b == nb / 2) ? 1 : (b == nb - 1) ? 2 : -1;
     const int ws = (w == 0) ? 0 : (w == 1) ? 1 : (w == nw - 1) ? 2 : -1;     // waves 0, 1 and the last one
     dst = (dbg && sel >= 0 && ws >= 0 && (threadIdx.x & 63) == 0 && blockIdx.y == 0) ? dbg + (sel * 3 + ws) * L2_NSTAMP : nullptr;
   }
@@ -61,15 +61,18 @@ struct Stamps {
     if (dst) {
 #pragma unroll
       for (int k = 0; k < L2_NSTAMP; ++k) dst[k] = t[k];
+      dst[L2_NSTAMP - 1] = rt0;      // the wave's start on the 100 MHz clock all XCDs share (stamp 11 is not used by any kernel)
     }
   }
 };
 #define STAMP_INIT(dbg) Stamps st_(dbg)
 #define STAMP_INIT_WG(dbg, wg) Stamps st_(dbg, wg)
+#define STAMP_INIT_SEL(dbg, sel) Stamps st_(dbg, nullptr, sel)
 #define STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_.t[k])::"memory")
 #else
 #define STAMP_INIT(dbg) do { } while (0)
 #define STAMP_INIT_WG(dbg, wg) do { } while (0)
+#define STAMP_INIT_SEL(dbg, sel) do { } while (0)
 #define STAMP(k) do { } while (0)
 #endif
 
@@ -100,9 +103,20 @@ struct PhaseArgs {
   int rot;            // streaming form: row group g starts its rows at column batch (g * rot) % batches and wraps (0: every row from column 0)
   const float* wp;    // streaming form: this launch's matrix (matrices) repacked in the order the chip consumes it (pack_kernel), or null
   unsigned long long* amax;  // CLS of the greedy loop: 8 argmax keys (one per 128-byte line) the workgroups fold their best logit into, or null
+  unsigned long long* gran;  // QKV of the fused QKV + attention launch: [dim + 2 kv_dim] hand-off granules {value, tag} for q, k, v of this position, or null
+  const unsigned* gran_ep;   // per head: the launch counter the granule tags of that head come from (tag = gran_ep[h] + 1)
+  unsigned gran_hmagic;      // ceil(2^20 / head_size): row / head_size without a division
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
   unsigned long long* dbg_wg;  // the same: {start, end} of every workgroup
 };
+
+// Hand-off granule of the fused QKV + attention launch (attention.hip.h): ONE naturally aligned 8-byte word {fp32 value, tag},
+// written by ONE write-through store (relaxed, agent scope = sc1) and only ever read by L1-bypassing loads: the data is its own
+// flag, no fence on either side (MI355X guide, hand-off recipe R2).  tag = number of this launch (a device counter the launch
+// itself advances when its last head is done), so a granule of an earlier launch never matches and nothing has to be zeroed.
+__device__ __forceinline__ void granule_store(unsigned long long* g, float v, unsigned tag) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Cross-lane reductions on the DPP path (register-to-register, ~10 cycles a step) instead of
@@ -293,11 +307,11 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // Epilogue operands that do not depend on the GEMV (RoPE table entries of the row pair, residual value of the row):
 // lane p's operands for pair / row p of row group g.  The latency kernel requests them with the weights; the
 // streaming kernel loads them in the epilogue (there the extra live registers cost more than the L2 round trip).
-struct EpiPre { float e0, e1; };
+struct EpiPre { float e0, e1; unsigned tag; };   // tag: hand-off granules of the fused QKV + attention launch
 
 template <int MODE, int R>
 __device__ __forceinline__ EpiPre epi_prefetch(const PhaseArgs& a, int g, int lane, int token, int pos) {
-  EpiPre e = {0.0f, 0.0f};
+  EpiPre e = {0.0f, 0.0f, 0u};
   if (MODE == MODE_QKV) {
     int m, i0;
     qkv_group(a, g, R, m, i0);
@@ -332,6 +346,7 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
           float* vc = a.out_v + (size_t)pos * a.kv_dim;
           vc[i] = s0; vc[i + 1] = s1;
           if (a.aux2) { a.aux2[i] = s0; a.aux2[i + 1] = s1; }
+          if (a.gran) { unsigned long long* gp = a.gran + a.dim + a.kv_dim + i; granule_store(gp, s0, pre.tag); granule_store(gp + 1, s1, pre.tag); }
         } else {       // RoPE on the adjacent pair (llama2.ts:224-235)
           double fcr, fci;
           if (PREF) { fcr = pre.e0; fci = pre.e1; }
@@ -344,6 +359,7 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
             kc[i] = o0; kc[i + 1] = o1;
             if (a.aux) { a.aux[i] = o0; a.aux[i + 1] = o1; }
           }
+          if (a.gran) { unsigned long long* gp = a.gran + (m == 0 ? 0 : a.dim) + i; granule_store(gp, o0, pre.tag); granule_store(gp + 1, o1, pre.tag); }
         }
       }
     }
@@ -558,7 +574,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   __syncthreads();
   STAMP(4);
 
-  const EpiPre nopre = {0.0f, 0.0f};
+  const EpiPre nopre = {0.0f, 0.0f, 0u};
   unsigned long long best = 0;      // CLS: this lane's best (logit, index) so far
   // The epilogue of a finished row group (reduction across the lanes, RoPE / SwiGLU / residual, stores) runs AFTER the next
   // batch has been requested, from a copy of the sums: both register sets stay in flight while it computes (with the
@@ -664,22 +680,24 @@ __global__ void __launch_bounds__(256) pack_kernel(const PhaseArgs a, f4* dst, i
 //     (RoPE entries, residual value) behind them, so nothing is requested after a reduction.
 // Numerics are those of the streaming form: fp64 accumulate, one fp32 rounding per stored element.
 template <int MODE, int XV, int R>
-__global__ void __launch_bounds__(512) phase_small_kernel(const PhaseArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem, const int vblock, const int vgrid) {
   constexpr int NC = 7;                             // compute waves; wave 0 is the x wave
   f4* xs4 = reinterpret_cast<f4*>(smem);            // 64 * XV float4, zero padded
   const int n = a.n, n4 = n >> 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int RPG = (MODE == MODE_W13) ? R / 2 : R;   // output rows per group
   const int groups = (a.rows + RPG - 1) / RPG;
-  const int gstride = gridDim.x * NC;
+  const int gstride = vgrid * NC;
 
   STAMP_INIT(a.dbg);
   STAMP(0);
   int token = 0, pos = 0;
   f4 bufA[R][XV], bufB[R][XV];
-  EpiPre preA = {0.0f, 0.0f}, preB = {0.0f, 0.0f};
-  const int g0 = (wave - 1) * gridDim.x + blockIdx.x;      // consecutive row groups go to different CUs
+  EpiPre preA = {0.0f, 0.0f, 0u}, preB = {0.0f, 0.0f, 0u};
+  // the wave's k-th row group (`groups` = none): consecutive row groups go to different CUs
+  const int g0 = (wave - 1) * vgrid + vblock;
+  auto nth = [&](int k) -> int { const int g = g0 + k * gstride; return g < groups ? g : groups; };
+  const int gA0 = nth(0), gB0 = nth(1);
   auto issue = [&](f4 (&buf)[R][XV], int gi) {
     const float* rp[R];
     row_ptrs<MODE, R>(a, gi, n, rp);
@@ -728,7 +746,7 @@ __global__ void __launch_bounds__(512) phase_small_kernel(const PhaseArgs a) {
         o.z = (float)((double)wr[u].z * (ss * (double)xr[u].z));
         o.w = (float)((double)wr[u].w * (ss * (double)xr[u].w));
         xs4[u * 64 + lane] = o;
-        if (MODE == MODE_CLS && blockIdx.x == 0 && a.aux && u * 64 + lane < n4) reinterpret_cast<f4*>(a.aux)[u * 64 + lane] = o;   // llama2.ts:299
+        if (MODE == MODE_CLS && vblock == 0 && a.aux && u * 64 + lane < n4) reinterpret_cast<f4*>(a.aux)[u * 64 + lane] = o;   // llama2.ts:299
         if (u == 0) STAMP(8);
       }
       STAMP(9);
@@ -736,19 +754,26 @@ __global__ void __launch_bounds__(512) phase_small_kernel(const PhaseArgs a) {
 #pragma unroll
       for (int u = 0; u < XV; ++u) xs4[u * 64 + lane] = (u * 64 + lane < n4) ? xr[u] : zero4;
     }
-  } else if (g0 < groups) {
+  } else if (gA0 < groups) {
     // ---- compute waves: the first two row groups + their epilogue operands (wave-uniform branches: a wave without
     // a second group requests nothing for it -- duplicate requests cost address-path cycles, 16 per KiB per CU)
-    issue(bufA, g0);
-    if (g0 + gstride < groups) issue(bufB, g0 + gstride);
+    issue(bufA, gA0);
+    if (gB0 < groups) issue(bufB, gB0);
   }
   STAMP(1);
   __syncthreads();
   STAMP(3);
-  if (wave == 0 || g0 >= groups) return;
+  if (wave == 0 || gA0 >= groups) return;
   if (MODE == MODE_QKV || MODE == MODE_WO) { token = a.tokpos[0]; pos = a.tokpos[1]; }
-  preA = epi_prefetch<MODE, R>(a, g0, lane, token, pos);
-  if (g0 + gstride < groups) preB = epi_prefetch<MODE, R>(a, g0 + gstride, lane, token, pos);
+  // hand-off tag of a row group = its head's launch counter + 1 (advanced by an EARLIER launch: an ordinary load)
+  auto gtag = [&](int gi) -> unsigned {
+    if (!(MODE == MODE_QKV) || !a.gran) return 0u;
+    int m, i0;
+    qkv_group(a, gi, R, m, i0);
+    return a.gran_ep[((unsigned)i0 * a.gran_hmagic) >> 20] + 1u;
+  };
+  preA = epi_prefetch<MODE, R>(a, gA0, lane, token, pos); preA.tag = gtag(gA0);
+  if (gB0 < groups) { preB = epi_prefetch<MODE, R>(a, gB0, lane, token, pos); preB.tag = gtag(gB0); }
   double xd[XV][4];
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
@@ -783,14 +808,24 @@ __global__ void __launch_bounds__(512) phase_small_kernel(const PhaseArgs a) {
     finish_group<MODE, R, true>(a, gi, acc, lane, token, pos, pre, nobest);
     STAMP(7);
   };
-  for (int g = g0; g < groups; g += 2 * gstride) {
+  for (int k = 0;; k += 2) {
+    const int g = nth(k);
+    if (g >= groups) break;
     run(bufA, g, preA);
-    if (g + 2 * gstride < groups) { issue(bufA, g + 2 * gstride); preA = epi_prefetch<MODE, R>(a, g + 2 * gstride, lane, token, pos); }
-    if (g + gstride < groups) {
-      run(bufB, g + gstride, preB);
-      if (g + 3 * gstride < groups) { issue(bufB, g + 3 * gstride); preB = epi_prefetch<MODE, R>(a, g + 3 * gstride, lane, token, pos); }
-    }
+    const int g2 = nth(k + 2);
+    if (g2 < groups) { issue(bufA, g2); preA = epi_prefetch<MODE, R>(a, g2, lane, token, pos); preA.tag = gtag(g2); }
+    const int g1 = nth(k + 1);
+    if (g1 >= groups) break;
+    run(bufB, g1, preB);
+    const int g3 = nth(k + 3);
+    if (g3 < groups) { issue(bufB, g3); preB = epi_prefetch<MODE, R>(a, g3, lane, token, pos); preB.tag = gtag(g3); }
   }
+}
+
+template <int MODE, int XV, int R>
+__global__ void __launch_bounds__(512) phase_small_kernel(const PhaseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  phase_small_body<MODE, XV, R>(a, smem, blockIdx.x, gridDim.x);
 }
 
 // Scalar path for shapes with n % 4 != 0 (rows are not 16-byte aligned): correctness only.
@@ -836,7 +871,7 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-    { const EpiPre nopre = {0.0f, 0.0f}; finish_group<MODE, R, false>(a, g, acc, lane, token, pos, nopre, best); }
+    { const EpiPre nopre = {0.0f, 0.0f, 0u}; finish_group<MODE, R, false>(a, g, acc, lane, token, pos, nopre, best); }
   }
   if (MODE == MODE_CLS && a.amax) {   // as in phase_body
     best = wave_max_u64(best);

@@ -169,6 +169,9 @@ static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
   a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter;
   a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
   a.kv_dim = c->kvd_loc; a.kv_mul = c->H / c->KVH;
+  a.cmax = (c->S + a.nsplit - 1) / a.nsplit;
+  a.ns_shift = -1;
+  for (int sft = 0; sft < 16; ++sft) if ((1 << sft) == a.nsplit) a.ns_shift = sft;
   a.exact = c->opt_exact;
   a.inv_sqrt_hs = 1.0 / sqrt((double)c->hs);
 #ifdef L2_STAMPS
@@ -208,6 +211,57 @@ static hipError_t launch_attn_tile(const l2_ctx* c, const AttnArgs& a, int ny, i
   return hipGetLastError();
 }
 
+// ---- the fused QKV + attention launch (attention.hip.h: qkv_attn_small_kernel) --------------------------------------------
+// Taken when the QKV phase is the latency form, heads are 33 .. 64 floats wide (16 lanes per cache row), the input vector is
+// 257 .. 1024 floats (stories15M, stories110M), one cache head per query head, one GPU, and the reference's own value accumulate
+// is not asked for.  L2_FUSE_QKV_ATTN=0 (development switch) keeps the two launches.
+static int fused_attn_blocks(const l2_ctx* c, int nsplit) { return c->H * nsplit; }
+static bool fused_shape_ok(const l2_ctx* c) {      // whatever the position
+  if (!c->opt_fuse || c->tp_path || c->KVH != c->H || !attn_vec(c) || !c->gran) return false;
+  if (!use_small(c, MODE_QKV, c->d + 2 * c->kvd, c->d) || attn_lr(c->hs) != 16) return false;
+  const int xv = (c->d / 4 + 63) / 64;
+  return xv >= 2 && xv <= 4;
+}
+// ... and for the step being enqueued: one workgroup per head only (with 8 splits per head the fused form loses to two launches:
+// 96 of the CUs are then attention workgroups that wait while the rest do the GEMV)
+static bool fused_qkv_attn_ok(const l2_ctx* c) {
+  if (!fused_shape_ok(c) || c->opt_exact) return false;
+  const int ns = c->cur_splits;
+  if (ns != 1 && !c->opt_fuse_splits) return false;
+  return fused_attn_blocks(c, ns) * 2 <= c->n_cus && (size_t)attn_tile_lds(c->S, ns, 8, 8) <= 160 * 1024;
+}
+
+template <int XV>
+static hipError_t launch_qkv_attn_xv(const l2_ctx* c, const PhaseArgs& qa, const AttnArgs& at, hipStream_t st) {
+  const int nattn = fused_attn_blocks(c, at.nsplit);
+  int nq = c->n_cus - nattn;
+  const int groups = (qa.rows + 1) / 2;
+  if (nq > groups) nq = groups;
+  const size_t lds_q = (size_t)XV * 64 * 16, lds_a = attn_tile_lds(c->S, at.nsplit, 8, 8);
+  const size_t lds = lds_q > lds_a ? lds_q : lds_a;
+  hipError_t e = lds_opt_in(&qkv_attn_small_kernel<XV, 16, 8>, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((qkv_attn_small_kernel<XV, 16, 8>), dim3(nq + nattn), dim3(512), lds, st, qa, at, nattn);
+  return hipGetLastError();
+}
+
+static hipError_t launch_qkv_attn(const l2_ctx* c, const PhaseArgs& qa_in, int l, hipStream_t st) {
+  PhaseArgs qa = qa_in;
+  qa.gran = c->gran; qa.gran_ep = c->gran_ep;
+  qa.gran_hmagic = (unsigned)(((1u << 20) + (unsigned)c->hs - 1u) / (unsigned)c->hs);
+#ifdef L2_STAMPS
+  qa.dbg = c->dbg + (size_t)(g_stamp_slot++ % 64) * 108;
+#endif
+  AttnArgs at;
+  fill_attn_args(c, l, at);
+  at.gran = c->gran; at.gran_ep = c->gran_ep; at.herr = c->h_herr_dev; at.wait_ticks = 200000000ull;      // 2 s
+  switch ((c->d / 4 + 63) / 64) {
+    case 2: return launch_qkv_attn_xv<2>(c, qa, at, st);
+    case 3: return launch_qkv_attn_xv<3>(c, qa, at, st);
+    default: return launch_qkv_attn_xv<4>(c, qa, at, st);
+  }
+}
+
 static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // attention (llama2.ts:244-267)
   AttnArgs a;
   fill_attn_args(c, l, a);
@@ -218,6 +272,6 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // att
     hipLaunchKernelGGL(attn_scalar_kernel, dim3(c->H_loc, 1), dim3(256), lds, st, a, 0);
     return hipGetLastError();
   }
-  if (c->opt_exact) a.nsplit = 1;
+  if (c->opt_exact) { a.nsplit = 1; a.cmax = c->S; a.ns_shift = 0; }
   return launch_attn_tile(c, a, a.nsplit, -1, st);
 }

@@ -63,9 +63,14 @@ static void destroy_graphs(l2_ctx* c) {
 // the split count, so intermediate counts never win (tools/ctx_curve.py, 7B and 110M: 2 / 4 splits are slower than
 // 8 at every position where they beat 1; the crossover is at 140-160 rows for 64- and 128-wide heads alike).
 static const int kSplitLevels[NLEV] = {1, 8};
+static bool fused_shape_ok(const l2_ctx* c);
+// Where the fused QKV + attention launch applies (launch.hip.h: fused_qkv_attn_ok) the unsplit level reaches to 256 rows: its
+// attention workgroups request their cache rows while the GEMV runs, so one workgroup per head keeps up for longer -- the fused
+// launch with one workgroup per head beats the two launches with 8 splits up to there (profiles/r04/fused_qkv_attention_ab.txt).
 static int split_level(const l2_ctx* c, int pos) {
   if (c->attn_splits_forced > 0 || c->opt_exact) return 0;
-  return pos + 1 > c->split_rows ? 1 : 0;
+  const int rows = (c->split_rows_set || !fused_shape_ok(c)) ? c->split_rows : 256;
+  return pos + 1 > rows ? 1 : 0;
 }
 static int splits_of(const l2_ctx* c, int level) { return c->attn_splits_forced > 0 ? c->attn_splits_forced : kSplitLevels[level]; }
 
@@ -91,6 +96,9 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->attn_part) hipFree(c->attn_part);
   if (c->attn_counter) hipFree(c->attn_counter);
   if (c->amax) hipFree(c->amax);
+  if (c->gran) hipFree(c->gran);
+  if (c->gran_ep) hipFree(c->gran_ep);
+  if (c->h_herr) hipHostFree(c->h_herr);
   for (hipEvent_t e : c->probe) hipEventDestroy(e);
   { float* pb[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_xb, c->pf_hb}; for (float* b : pb) if (b) hipFree(b); if (c->pf_tok) hipFree(c->pf_tok); }
   if (c->tokpos) hipFree(c->tokpos);
@@ -195,6 +203,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->attn_splits_forced = dev_int("L2_ATTN_SPLITS", 0);
   c->attn_nw = dev_int("L2_ATTN_NW", 0);
   c->split_rows = dev_int("L2_ATTN_SPLIT_ROWS", 144);
+  c->split_rows_set = dev_int("L2_ATTN_SPLIT_ROWS", -1) >= 0;
   c->small_max = dev_int("L2_SMALL_MAX", 8 << 20);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->pf_lds = dev_int("L2_PF_LDS", 1);
@@ -209,6 +218,15 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     CK(hipMemsetAsync(c->attn_counter, 0, (size_t)c->H_loc * CTR_STRIDE * 4, c->stream));
     CK(hipMalloc(&c->amax, 8 * 16 * 8));
     CK(hipMemsetAsync(c->amax, 0, 8 * 16 * 8, c->stream));
+    CK(hipMalloc(&c->gran, ((size_t)c->d_loc + 2 * (size_t)c->kvd_loc) * 8));
+    CK(hipMemsetAsync(c->gran, 0, ((size_t)c->d_loc + 2 * (size_t)c->kvd_loc) * 8, c->stream));
+    CK(hipMalloc(&c->gran_ep, (size_t)c->H_loc * 4 + 16));
+    CK(hipMemsetAsync(c->gran_ep, 0, (size_t)c->H_loc * 4 + 16, c->stream));
+    CK(hipHostMalloc(&c->h_herr, sizeof(int), hipHostMallocMapped));
+    *c->h_herr = 0;
+    CK(hipHostGetDevicePointer((void**)&c->h_herr_dev, c->h_herr, 0));
+    c->opt_fuse = dev_int("L2_FUSE_QKV_ATTN", 1);
+    c->opt_fuse_splits = dev_int("L2_FUSE_SPLITS", 0);
   }
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
@@ -487,8 +505,12 @@ static int ensure_packed(l2_ctx* c) {
 static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fold_argmax = false) {
   for (int l = 0; l < c->L; ++l) {
     PhaseArgs a = qkv_args(c, l);
-    LCHK(launch_phase<MODE_QKV>(c, a, st));
-    LCHK(launch_attn(c, l, st));
+    if (fused_qkv_attn_ok(c)) {
+      LCHK(launch_qkv_attn(c, a, l, st));        // the head-local edge inside one launch (attention.hip.h: qkv_attn_small_kernel)
+    } else {
+      LCHK(launch_phase<MODE_QKV>(c, a, st));
+      LCHK(launch_attn(c, l, st));
+    }
     a = wo_args(c, l);
     LCHK(launch_phase<MODE_WO>(c, a, st));
     if (c->p2p) {

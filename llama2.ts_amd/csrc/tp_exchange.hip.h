@@ -320,7 +320,13 @@ static int p2p_first_sync(l2_ctx* c) {
   return L2_OK;
 }
 
-static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer wait give up?
+static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer wait (or a hand-off wait of the fused QKV + attention launch) give up?
+  if (c->h_herr && *c->h_herr) {
+    *c->h_herr = 0;
+    hipMemsetAsync(c->gran, 0, ((size_t)c->d_loc + 2 * (size_t)c->kvd_loc) * 8, c->stream);      // tags of the broken launch: gone (the counters only ever grow)
+    hipStreamSynchronize(c->stream);
+    return fail(L2_E_HIP, "fused QKV + attention launch: a hand-off granule never arrived (bounded wait gave up); the step's results are invalid");
+  }
   if (c->p2p_err && *c->p2p_err) {
     *c->p2p_err = 0;
     c->broken = true;   // the device-side epoch / flag state is out of step with the peers for good: fail fast from now on
