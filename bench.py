@@ -373,7 +373,9 @@ def tp_prediction(hdr, seed, device, single_ms):
             c = runtime.Context(hdr, device=device, tp_rank=0, tp_size=G, nccl_id=runtime.TP_SOLO_ID)
             c.synth_fill(seed)
             n = min(64, hdr[6])
-            c.bench_decode(1, 0, n)
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < 2.5:      # untimed: pack, release, and the driver's scrub of what was released (see main)
+                c.bench_decode(1, 0, n)
             ms = c.bench_decode(1, 0, n) / n
             c.close()
             nx = 2 * hdr[2] + 1
@@ -609,6 +611,15 @@ def main():
         t_spin = time.perf_counter()
         while time.perf_counter() - t_spin < 0.3:
             ctx.bench_decode(1, 0, min(64, hdr[6]))
+    else:
+        # untimed: the first step repacks the matrices and gives their row-major tensors back to the driver (one copy of the weights);
+        # the driver then scrubs the freed memory in the background -- 25 GB at 7B, 2.5 - 3 s of extra HBM traffic that costs a decode
+        # running beside it ~2 % (profiles/r04/one_copy_release_transient.txt).  The steady state is what a serving process sees.
+        ctx.bench_decode(1, 0, min(8, hdr[6]))
+        if ctx.get_option(runtime.OPT_PACKED_MIB) > 0:
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < 3.5:
+                ctx.bench_decode(1, 0, min(64, hdr[6]))
     if W > 1:
         ctx.bench_decode(1, 0, W - 1)
     if W > 0:
@@ -640,8 +651,11 @@ def main():
                    "header": list(hdr), "parallelism": ("tp%d" % world) if shards else ("replicas%d" % world if world > 1 else "single"),
                    "loop": ("device-resident (forward + argmax on GPU); tensor-parallel step: %s" % ctx.tp_mode()
                             if shards else "device-resident (forward + argmax on GPU, one hipGraph replay per token)"),
-                   "weights": "fp32 row-major as the checkpoint stores them + %d MiB of repacked copies for the streaming kernels (DESIGN.md section 3)"
-                              % ctx.get_option(runtime.OPT_PACKED_MIB)},
+                   "weights": "fp32, ONE copy on the device (%d MiB): the matrices of the streaming phases repacked in the order the chip consumes them "
+                              "(%d MiB, DESIGN.md section 3), everything else row-major as the checkpoint stores it"
+                              % (ctx.get_option(runtime.OPT_WEIGHT_MIB), ctx.get_option(runtime.OPT_PACKED_MIB)),
+                   "weights_mib": {"on_device": ctx.get_option(runtime.OPT_WEIGHT_MIB), "repacked": ctx.get_option(runtime.OPT_PACKED_MIB),
+                                   "checkpoint": configs.checkpoint_bytes(hdr) >> 20}},
         "device_ms_per_step": round(dev_ms / K, 5),
         "algorithmic_bytes_per_token": int(bpt),
         "hbm_gbs_end_to_end": round(bpt * value / 1e9 / per_gpu_streams, 2),

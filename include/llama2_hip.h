@@ -68,8 +68,10 @@ enum {
                                  the xb of the FFN half, the final-normed x) are also written out for l2_read_state (parity
                                  tests); 0 (default): they stay on chip and reading them AFTER a forward returns L2_E_STATE -- q, hb, logits and
                                  the KV caches are always there */
-  L2_OPT_PACKED_MIB = 4       /* read-only (l2_get_option): MiB of device memory held by the repacked second copies of the matrices the
+  L2_OPT_PACKED_MIB = 4,      /* read-only (l2_get_option): MiB of device memory held by the repacked copies of the matrices the
                                  streaming kernels read; 0 before the first step and for models that need none */
+  L2_OPT_WEIGHT_MIB = 5       /* read-only: MiB of device memory held by ALL weights right now (row-major tensors + repacked copies).  After
+                                 the first step a repacked matrix exists once: its row-major tensor has been given back */
 };
 
 typedef struct l2_ctx l2_ctx;

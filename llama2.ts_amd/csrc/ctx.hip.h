@@ -206,6 +206,10 @@ struct l2_ctx {
   struct Packed { float* buf = nullptr; size_t layer_elems = 0; int U = 0, nwaves = 0, grid = 0; std::vector<uint8_t> dirty; bool noted = false; } packed[5];
   bool packed_valid = false;        // false after an upload of a matrix a packed phase reads: its (phase, layer) slices are rebuilt before the next step
   int opt_packed = 1;               // L2_PACKED=0: stream the row-major tensors (A/B)
+  // One copy of the weights: once a phase's matrices are repacked, their row-major tensors are given back (w[kind] = null); the prompt
+  // GEMMs read the repacked copy too, l2_read_tensor and a later l2_upload unpack it first (ensure_rowmajor).
+  bool released[L2_T_COUNT] = {};
+  int opt_one_copy = 1;             // L2_ONE_COPY=0: keep both copies (A/B, development switch)
 };
 
 static bool is_layered(int kind) { return kind >= L2_T_RMS_ATT && kind <= L2_T_W3; }

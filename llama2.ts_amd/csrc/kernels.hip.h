@@ -664,6 +664,30 @@ __global__ void __launch_bounds__(256) pack_kernel(const PhaseArgs a, f4* dst, i
   dst[(size_t)rnd * wstride * R * n4 + (size_t)nwr * (R * cpi) * ci + (size_t)place * (R * 64) * uc + (r * uc + u) * 64 + ln] = reinterpret_cast<const f4*>(src)[c4];
 }
 
+// The inverse: the row-major matrix (matrices) of one launch back out of the repacked copy -- what l2_read_tensor and a later
+// l2_upload into a packed phase work on once the row-major tensors have been given back (one copy of the weights).
+template <int MODE, int R>
+__global__ void __launch_bounds__(256) unpack_kernel(const PhaseArgs a, const f4* src, int U, int wstride) {
+  const int n4 = a.n >> 2, cpi = 64 * U, nchunks = (n4 + cpi - 1) / cpi, ulast = (n4 - (nchunks - 1) * cpi) >> 6;
+  const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
+  const int groups = (a.rows + rows_per_group - 1) / rows_per_group;
+  const int gi = blockIdx.x, e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= R * n4) return;
+  const int r = e / n4, c4 = e - r * n4;
+  // the rows of this group (a clamped duplicate row of a short last group is skipped: its source slot holds a copy of the last row)
+  if (MODE == MODE_W13) { if (gi * (R / 2) + (r % (R / 2)) >= a.rows) return; }
+  else if (MODE == MODE_QKV) { int m, i0; qkv_group(a, gi, R, m, i0); if (i0 + r >= (m == 0 ? a.dim : a.kv_dim)) return; }
+  else if (gi * R + r >= a.rows) return;
+  const float* rp[R];
+  row_ptrs<MODE, R>(a, gi, a.n, rp);
+  const float* dstp = rp[0];
+#pragma unroll
+  for (int k = 1; k < R; ++k) dstp = (r == k) ? rp[k] : dstp;
+  const int ci = c4 / cpi, u = (c4 - ci * cpi) >> 6, ln = c4 & 63;
+  const int rnd = gi / wstride, place = gi - rnd * wstride, nwr = min(wstride, groups - rnd * wstride), uc = (ci == nchunks - 1) ? ulast : U;
+  reinterpret_cast<f4*>(const_cast<float*>(dstp))[c4] = src[(size_t)rnd * wstride * R * n4 + (size_t)nwr * (R * cpi) * ci + (size_t)place * (R * 64) * uc + (r * uc + u) * 64 + ln];
+}
+
 // ------------------------------------------------------------------------------------------------
 // LATENCY form (small matrices: every phase of stories15M / stories110M moves 0.3 - 12.6 MB, i.e. 0.05 - 2 us of
 // HBM time, so the phase costs what its chain of dependent steps costs).  In-kernel anatomy of the streaming form

@@ -148,6 +148,7 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   const size_t lds = (size_t)nstage4 * (norm ? 2 : 1) * 16 + 64;
   // the repacked copy is only good for the geometry it was packed for (U = 2: the only batch width with more than one batch per row)
   if (a.wp && !(g.U == 2 && g.U == c->packed[MODE].U && g.nwaves == c->packed[MODE].nwaves && g.grid == c->packed[MODE].grid)) a.wp = nullptr;
+  if (!a.wp && !a.w0) return hipErrorInvalidValue;       // one copy of the weights: the row-major tensor is gone and this launch cannot read the repacked one
 #define L2_LAUNCH(UU, PP) do { if (UU == 2 && a.wp) { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, 2, PP, true>, lds); if (e_ != hipSuccess) return e_; \
                                                       launch_probed(c, phase_kernel<MODE, 2, 2, PP, true>, grid, block, lds, st, a, MODE == MODE_W13); } \
                                else { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \

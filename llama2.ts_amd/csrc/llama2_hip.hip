@@ -111,6 +111,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   delete c;
 }
 
+static int ensure_rowmajor(l2_ctx* c, bool unpack);
 static int p2p_alloc(l2_ctx* c);
 static int p2p_connect_ipc(l2_ctx* c);
 static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits);
@@ -158,6 +159,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->tune_gridcap = dev_int("L2_TUNE_GRIDCAP", 0);
   c->tune_rot = dev_int("L2_TUNE_ROT", 5);
   c->opt_packed = dev_int("L2_PACKED", 1);
+  c->opt_one_copy = dev_int("L2_ONE_COPY", 1);
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !hook_int("L2_TP_FORCE_COMM")) ? 1 : 0);
   c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
@@ -368,6 +370,7 @@ extern "C" int l2_upload(l2_ctx* c, int kind, int layer, const float* host, size
   if (n_floats != s.full_rows * s.full_cols)
     return fail(L2_E_ARG, "tensor kind %d expects %zu floats, got %zu", kind, s.full_rows * s.full_cols, n_floats);
   HIPCHK(hipSetDevice(c->device));
+  if (c->released[kind]) { rc = ensure_rowmajor(c, true); if (rc) return rc; }     // the row-major tensor was given back after packing: bring it back
   float* dst = c->w[kind] + c->layer_elems[kind] * (size_t)li;
   const float* src = host + s.row0 * s.full_cols + s.col0;
   if (s.cols == s.full_cols) {
@@ -489,8 +492,20 @@ static int pack_phase(l2_ctx* c, int layers, PhaseArgs (*args_of)(const l2_ctx*,
   return L2_OK;
 }
 static PhaseArgs cls_args_l(const l2_ctx* c, int) { return cls_args(c, false); }
+// tensor kinds whose only steady-state reader is phase `mode` (the shared classifier's matrix is the embedding table: it stays)
+static int phase_kinds(const l2_ctx* c, int mode, int (&kinds)[3]) {
+  switch (mode) {
+    case MODE_QKV: kinds[0] = L2_T_WQ; kinds[1] = L2_T_WK; kinds[2] = L2_T_WV; return 3;
+    case MODE_WO: kinds[0] = L2_T_WO; return 1;
+    case MODE_W13: kinds[0] = L2_T_W1; kinds[1] = L2_T_W3; return 2;
+    case MODE_W2: kinds[0] = L2_T_W2; return 1;
+    default: if (c->shared) return 0; kinds[0] = L2_T_WCLS; return 1;
+  }
+}
+
 static int ensure_packed(l2_ctx* c) {
   if (c->packed_valid) return L2_OK;
+  for (int k = 0; k < L2_T_COUNT; ++k) if (c->released[k]) return fail(L2_E_STATE, "internal: tensor kind %d is marked dirty while its row-major copy is gone", k);
   int rc;
   if ((rc = pack_phase<MODE_QKV>(c, c->L, qkv_args))) return rc;
   if ((rc = pack_phase<MODE_WO>(c, c->L, wo_args))) return rc;
@@ -499,6 +514,63 @@ static int ensure_packed(l2_ctx* c) {
   if ((rc = pack_phase<MODE_CLS>(c, 1, cls_args_l))) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   c->packed_valid = true;
+  // ONE copy of the weights: a packed phase reads nothing but its repacked copy (decode, prompt ingestion), so the row-major
+  // tensors it was built from go back to the allocator (Llama-2-7B: 25 GB).  Captured graphs keep working: their launches carry
+  // the repacked addresses, which do not move.
+  if (c->opt_one_copy) {
+    for (int m = 0; m < 5; ++m) {
+      if (!c->packed[m].buf) continue;
+      int kinds[3];
+      const int nk = phase_kinds(c, m, kinds);
+      for (int i = 0; i < nk; ++i) {
+        const int k = kinds[i];
+        if (c->w[k] && !c->released[k]) { HIPCHK(hipFree(c->w[k])); c->w[k] = nullptr; c->released[k] = true; }
+      }
+    }
+  }
+  return L2_OK;
+}
+
+template <int MODE>
+static int unpack_phase(l2_ctx* c, int layers, PhaseArgs (*args_of)(const l2_ctx*, int)) {
+  const l2_ctx::Packed& p = c->packed[MODE];
+  int kinds[3];
+  const int nk = phase_kinds(c, MODE, kinds);
+  bool any = false;
+  for (int i = 0; i < nk; ++i) any = any || c->released[kinds[i]];
+  if (!any) return L2_OK;
+  if (!p.buf) return fail(L2_E_STATE, "internal: phase %d has neither a row-major nor a repacked copy", MODE);
+  const PhaseArgs a0 = args_of(c, 0);
+  const int n4 = a0.n / 4, rpg = (MODE == MODE_W13) ? 1 : 2, groups = (a0.rows + rpg - 1) / rpg;
+  for (int l = 0; l < layers; ++l) {
+    const PhaseArgs a = args_of(c, l);
+    hipLaunchKernelGGL((unpack_kernel<MODE, 2>), dim3(groups, (2 * n4 + 255) / 256), dim3(256), 0, c->stream, a, reinterpret_cast<const f4*>(p.buf + p.layer_elems * (size_t)l), p.U, p.grid * p.nwaves);
+  }
+  LCHK(hipGetLastError());
+  return L2_OK;
+}
+
+// Bring back the row-major tensors that were given away after packing (`unpack`: with their contents, out of the repacked copies;
+// false: the caller overwrites all of them anyway).  They are given away again after the next repack.
+static int ensure_rowmajor(l2_ctx* c, bool unpack) {
+  bool any = false;
+  for (int k = 0; k < L2_T_COUNT; ++k) {
+    if (!c->released[k]) continue;
+    any = true;
+    HIPCHK(hipMalloc(&c->w[k], c->layer_elems[k] * c->layers_of[k] * sizeof(float)));
+  }
+  if (!any) return L2_OK;
+  int rc = L2_OK;
+  if (unpack) {
+    if (!c->packed_valid) return fail(L2_E_STATE, "internal: the repacked copies are stale and the row-major tensors are gone");
+    if ((rc = unpack_phase<MODE_QKV>(c, c->L, qkv_args))) return rc;
+    if ((rc = unpack_phase<MODE_WO>(c, c->L, wo_args))) return rc;
+    if ((rc = unpack_phase<MODE_W13>(c, c->L, w13_args))) return rc;
+    if ((rc = unpack_phase<MODE_W2>(c, c->L, w2_args))) return rc;
+    if ((rc = unpack_phase<MODE_CLS>(c, 1, cls_args_l))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  for (int k = 0; k < L2_T_COUNT; ++k) c->released[k] = false;
   return L2_OK;
 }
 
@@ -813,7 +885,7 @@ extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
       return L2_OK;
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
     case L2_OPT_KEEP_STATE: if (c->opt_keep_state != !!value) { c->opt_keep_state = !!value; destroy_graphs(c); } return L2_OK;
-    case L2_OPT_PACKED_MIB: return fail(L2_E_ARG, "option %d is read-only", key);
+    case L2_OPT_PACKED_MIB: case L2_OPT_WEIGHT_MIB: return fail(L2_E_ARG, "option %d is read-only", key);
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }
@@ -827,6 +899,13 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
     case L2_OPT_PACKED_MIB: {
       size_t floats = 0;
       if (c->packed_valid) for (int m = 0; m < 5; ++m) if (c->packed[m].buf) floats += c->packed[m].layer_elems * (size_t)(m == MODE_CLS ? 1 : c->L);
+      *value = (int)(floats * sizeof(float) >> 20);
+      return L2_OK;
+    }
+    case L2_OPT_WEIGHT_MIB: {      // every byte of weights on the device right now: row-major tensors still held + repacked copies
+      size_t floats = 0;
+      for (int k = 0; k < L2_T_COUNT; ++k) if (c->w[k] && !(k == L2_T_WCLS && c->shared)) floats += c->layer_elems[k] * (size_t)c->layers_of[k];
+      for (int m = 0; m < 5; ++m) if (c->packed[m].buf) floats += c->packed[m].layer_elems * (size_t)(m == MODE_CLS ? 1 : c->L);
       *value = (int)(floats * sizeof(float) >> 20);
       return L2_OK;
     }

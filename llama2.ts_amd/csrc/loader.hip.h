@@ -135,6 +135,7 @@ static uint64_t full_count(const l2_ctx* c, int kind) {
 extern "C" int l2_synth_fill(l2_ctx* c, uint32_t seed) {
   if (!c) return fail(L2_E_ARG, "null context");
   HIPCHK(hipSetDevice(c->device));
+  { const int rc_ = ensure_rowmajor(c, false); if (rc_) return rc_; }      // every tensor is overwritten: nothing to unpack
   uint64_t off = 0;
   for (int kind = 0; kind < L2_T_COUNT; ++kind) {
     const uint64_t n = full_count(c, kind);
@@ -194,6 +195,7 @@ extern "C" int l2_read_tensor(l2_ctx* c, int kind, int layer, size_t offset, flo
   const size_t n = c->layer_elems[kind] ? c->layer_elems[kind] : (size_t)c->V * c->d;
   if (offset + n_floats > n) return fail(L2_E_ARG, "read of %zu floats at %zu exceeds tensor (%zu)", n_floats, offset, n);
   HIPCHK(hipSetDevice(c->device));
+  if (c->released[kind]) { const int rc_ = ensure_rowmajor(c, true); if (rc_) return rc_; }      // out of the repacked copy (given back again after the next step)
   HIPCHK(hipMemcpy(out, c->w[kind] + n * (size_t)li + offset, n_floats * 4, hipMemcpyDeviceToHost));
   return L2_OK;
 }

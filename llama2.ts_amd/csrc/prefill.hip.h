@@ -35,7 +35,35 @@ struct PfArgs {
   const float* fr; const float* fi;
   int n, rows, dim, head_size;
   int pos0, nvalid;    // first position of the chunk, tokens in it (<= PF_T)
+  // One copy of the weights: when the decode step's repacked copy of this phase's matrices exists (kernels.hip.h, pack_kernel) the
+  // row-major tensors are gone (w0 = w1 = w2 = null) and the GEMMs read the repacked layout instead:
+  const float* wp;     // [round][column batch][place in the round][row of the group][u][lane] float4 of this layer, or null
+  int pk_wstride;      // row groups per round (waves of the decode launch's grid)
+  int pk_groups;       // row groups of the phase (2 rows each; w1 / w3: row g of both)
 };
+
+// Where float4 `c4` of row `r` of row group `g` lies in the repacked copy, split into the part that depends on the lane's row only
+// (two variants: ordinary column batches hold two 64-float4 sub-batches per row, a short last batch `ulast`) and the part that
+// depends on the column batch: offset = (last batch ? base_last : base) + nwr256 * ci + (u * 64 + ln), all in float4.
+struct PkLane { unsigned base, base_last, nwr256; };
+__device__ __forceinline__ PkLane pk_lane(const PfArgs& a, int g, int r) {
+  const int n4 = a.n >> 2, ws = a.pk_wstride;
+  const int rnd = g / ws, place = g - rnd * ws, nwr = min(ws, a.pk_groups - rnd * ws);
+  const int nchunks = (n4 + 127) >> 7, ulast = (n4 - (nchunks - 1) * 128) >> 6;
+  PkLane p;
+  const unsigned round0 = (unsigned)rnd * (unsigned)ws * 2u * (unsigned)n4;
+  p.base = round0 + (unsigned)place * 256u + (unsigned)r * 128u;
+  p.base_last = round0 + (unsigned)place * 128u * (unsigned)ulast + (unsigned)r * 64u * (unsigned)ulast;
+  p.nwr256 = (unsigned)nwr * 256u;
+  return p;
+}
+// row group and row-in-group of output row `row` (an index into the phase's rows: q | k | v stacked for QKV) of stream `second`
+// (w3 of the w1 / w3 phase)
+template <int MODE>
+__device__ __forceinline__ void pk_group_of(int row, bool second, int& g, int& r) {
+  if (MODE == MODE_W13) { g = row; r = second ? 1 : 0; }
+  else { g = row >> 1; r = row & 1; }
+}
 
 __global__ void __launch_bounds__(256) pf_embed_kernel(float* x, const float* emb, const int* tokens, int dim, int nvalid) {
   const int t = blockIdx.x;
@@ -186,8 +214,21 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
   const float* wbase = a.w0;
   if (MODE == MODE_QKV) { m = row0 / a.dim; i0 = row0 - m * a.dim; wbase = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2; }
   const int j = lane & 15, kq = lane >> 4;
-  const float* wrow = wbase + (size_t)(i0 + j) * n + 4 * kq;
-  const float* wrow3 = DUAL ? a.w1 + (size_t)(i0 + j) * n + 4 * kq : nullptr;
+  const bool pk = a.wp != nullptr;
+  const float* wrow = pk ? nullptr : wbase + (size_t)(i0 + j) * n + 4 * kq;
+  const float* wrow3 = (DUAL && !pk) ? a.w1 + (size_t)(i0 + j) * n + 4 * kq : nullptr;
+  PkLane pl = {0, 0, 0}, pl3 = {0, 0, 0};
+  if (pk) {
+    int g, r;
+    pk_group_of<MODE>(row0 + j, false, g, r); pl = pk_lane(a, g, r);
+    if (DUAL) { pk_group_of<MODE>(row0 + j, true, g, r); pl3 = pk_lane(a, g, r); }
+  }
+  const int pk_lastci = (((n >> 2) + 127) >> 7) - 1;
+  const f4* wp4 = reinterpret_cast<const f4*>(a.wp);
+  auto pk_at = [&](const PkLane& q, int sb) -> const f4* {      // 16-column block sb of the lane's row: float4 4 sb + kq
+    const int ci = sb >> 5;
+    return wp4 + ((ci == pk_lastci ? q.base_last : q.base) + q.nwr256 * (unsigned)ci + (unsigned)(((sb >> 4) & 1) * 64 + 4 * (sb & 15) + kq));
+  };
   const float* xrow = a.xin + (size_t)j * n + 4 * kq;       // token j (and 16 + j) as the A row
   PfAcc<TT, DUAL> acc;
   acc.clear();
@@ -199,8 +240,13 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int sb = min(p0 * UN + u, nblk - 1);     // clamped (never predicated) loads; masked in mma()
-      b.wv[u] = ldg_nt(wrow + 16 * sb);
-      if (DUAL) b.w3[u] = ldg_nt(wrow3 + 16 * sb);
+      if (pk) {
+        b.wv[u] = __builtin_nontemporal_load(pk_at(pl, sb));
+        if (DUAL) b.w3[u] = __builtin_nontemporal_load(pk_at(pl3, sb));
+      } else {
+        b.wv[u] = ldg_nt(wrow + 16 * sb);
+        if (DUAL) b.w3[u] = ldg_nt(wrow3 + 16 * sb);
+      }
 #pragma unroll
       for (int t = 0; t < TT; ++t) b.xv[u][t] = *reinterpret_cast<const f4*>(xrow + (size_t)16 * t * n + 16 * sb);
     }
@@ -387,7 +433,12 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   const int j = lane & 15, kq = lane >> 4;
   const unsigned voff = (unsigned)(((size_t)j * n + 4 * kq) * 4);     // this lane's element of a 16-row tile, bytes
   // one buffer descriptor per weight stream (a tile never straddles wq / wk / wv: dim % 16 == 0), one for the activations
+  // Repacked weights (a.wp: the decode step's copy, the only one once the row-major tensors have been given back): ONE descriptor
+  // over the layer's slice; a stream's lane offset is base + nwr256 * (column batch) -- one multiply-add per stream and batch of
+  // two blocks (32 MFMAs) -- and the block's place inside the batch stays in the scalar offset.
+  const bool pk = a.wp != nullptr;
   __amdgpu_buffer_rsrc_t wrs[NS];
+  PkLane pkl[NS];
   int tm[RT], ti0[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
@@ -397,13 +448,25 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
     if (MODE == MODE_QKV) { m = row0 / a.dim; i0 = row0 - m * a.dim; wb = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2; }
     tm[r] = m; ti0[r] = i0;
     const unsigned bytes = (unsigned)16 * (unsigned)n * 4u;
-    if (DUAL) {
+    if (pk) {
+      const unsigned slice = (unsigned)a.pk_groups * 2u * (unsigned)n * 4u;       // bytes of the layer's repacked slice (< 2 GiB)
+      int g, rr;
+      if (DUAL) {
+        wrs[2 * r] = wrs[2 * r + 1] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, slice, 0x00020000);
+        pk_group_of<MODE>(row0 + j, false, g, rr); pkl[2 * r] = pk_lane(a, g, rr);
+        pk_group_of<MODE>(row0 + j, true, g, rr); pkl[2 * r + 1] = pk_lane(a, g, rr);
+      } else {
+        wrs[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, slice, 0x00020000);
+        pk_group_of<MODE>(row0 + j, false, g, rr); pkl[r] = pk_lane(a, g, rr);
+      }
+    } else if (DUAL) {
       wrs[2 * r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w0 + (size_t)i0 * n), 0, bytes, 0x00020000);
       wrs[2 * r + 1] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1 + (size_t)i0 * n), 0, bytes, 0x00020000);
     } else {
       wrs[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wb + (size_t)i0 * n), 0, bytes, 0x00020000);
     }
   }
+  const int pk_lastci = (((n >> 2) + 127) >> 7) - 1;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xin), 0, (unsigned)(16 * TT) * (unsigned)n * 4u, 0x00020000);
   const unsigned tstride = 16u * (unsigned)n * 4u;                    // bytes between token tiles
   d4 acc[NS][TT];
@@ -423,11 +486,22 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   const unsigned oob = (unsigned)(16 * TT) * (unsigned)n * 4u;
   auto load = [&](Batch& b, int i) {
     const unsigned base = (i < nb) ? (unsigned)((wave + i * NW) * UN) * 64u : oob;     // scalar: 16 columns = 64 bytes per block
+    // repacked: blocks 2p, 2p + 1 of a batch share their column batch ci and sub-batch; a batch past the wave's last one is
+    // requested 2 GiB out (beyond any slice, no 32-bit wrap)
+    const int blk0 = (wave + i * NW) * UN, ci = blk0 >> 5;
+    const unsigned pbase = (i < nb) ? (unsigned)(((blk0 >> 4) & 1) * 64 + 4 * (blk0 & 15)) * 16u : 0x80000000u;
+    unsigned pvoff[NS];
+    if (pk) {
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) pvoff[s_] = ((ci == pk_lastci ? pkl[s_].base_last : pkl[s_].base) + pkl[s_].nwr256 * (unsigned)ci + (unsigned)kq) * 16u;
+    }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const unsigned soff = base + (unsigned)u * 64u;
 #pragma unroll
-      for (int s_ = 0; s_ < NS; ++s_) b.wv[u][s_] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs[s_], voff, soff, 2));   // nt: each weight byte is read once
+      for (int s_ = 0; s_ < NS; ++s_)
+        b.wv[u][s_] = pk ? __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs[s_], pvoff[s_], pbase + (unsigned)u * 64u, 2))
+                         : __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrs[s_], voff, soff, 2));   // nt: each weight byte is read once
 #pragma unroll
       for (int t = 0; t < TT; ++t) b.xv[u][t] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, soff + (unsigned)t * tstride, 0));
     }

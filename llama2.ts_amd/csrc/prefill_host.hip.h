@@ -37,8 +37,9 @@ static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int
     }
   }
   const dim3 grid(a.rows / 16);
+  // (the LDS form reads row-shaped pieces of the row-major tensor: a repacked-only phase takes the operand-layout kernel)
   // (four token tiles never take the LDS form: its 8-block register sets spilled -- 3200 vs 3490 tok/s -- and that instance is gone)
-  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && tt < 4) {
+  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && tt < 4 && !a.wp) {
     const size_t tiles = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
     const size_t parts = (size_t)4 * 2 * 3 * 4 * 64 * 8;
     const size_t lds = tiles > parts ? tiles : parts;
@@ -57,6 +58,23 @@ static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int
   if (tt == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE, 4, 4>), grid, dim3(256), 0, st, a);
   else if (tt == 2) hipLaunchKernelGGL((pf_gemm_kernel<MODE, 4, 2>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((pf_gemm_kernel<MODE, 4, 1>), grid, dim3(256), 0, st, a);
+}
+
+// The weights of one prompt GEMM: the row-major tensors of layer l, or -- once they have been given back (one copy of the weights:
+// ensure_packed) -- the decode step's repacked copy of this phase with the geometry it was packed for.
+template <int MODE>
+static void pf_weights(const l2_ctx* c, int l, PfArgs& a, int k0, int k1, int k2) {
+  a.w0 = a.w1 = a.w2 = nullptr; a.wp = nullptr; a.pk_wstride = 0; a.pk_groups = 0;
+  if (c->released[k0]) {
+    const l2_ctx::Packed& p = c->packed[MODE];
+    a.wp = p.buf + p.layer_elems * (size_t)l;
+    a.pk_wstride = p.grid * p.nwaves;
+    a.pk_groups = (int)(p.layer_elems / (2 * (size_t)(MODE == MODE_W2 ? c->h : c->d)));      // layer_elems = groups * 2 rows * n
+    return;
+  }
+  a.w0 = c->w[k0] + c->layer_elems[k0] * l;
+  if (k1 >= 0) a.w1 = c->w[k1] + c->layer_elems[k1] * l;
+  if (k2 >= 0) a.w2 = c->w[k2] + c->layer_elems[k2] * l;
 }
 
 // One launch sequence for up to PF_S chunks of PF_T prompt positions (n tokens at pos0 ...): every GEMM sees all of them.
@@ -86,8 +104,7 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
     a.x = c->pf_x;
     // rmsnorm + q,k,v + RoPE + cache rows (llama2.ts:216-240)
     hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_ATT] + d * l, c->d);
-    a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
-    a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
+    pf_weights<MODE_QKV>(c, l, a, L2_T_WQ, L2_T_WK, L2_T_WV);
     a.xin = c->pf_xn; a.out = c->pf_q; a.kc = c->kc + loff; a.vc = c->vc + loff; a.n = c->d; a.rows = 3 * c->d;
     launch_pf_gemm<MODE_QKV>(c, a, 4, tt, chunks, st);
     LCHK(hipGetLastError());
@@ -116,15 +133,15 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
       LCHK(launch_attn_tile(c, aa, n, pos0, st));
     }
     // wo + residual (llama2.ts:270-273)
-    a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l; a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
+    pf_weights<MODE_WO>(c, l, a, L2_T_WO, -1, -1); a.xin = c->pf_xb; a.n = c->d; a.rows = c->d;
     launch_pf_gemm<MODE_WO>(c, a, 4, tt, chunks, st);
     // rmsnorm + w1,w3 + SwiGLU (llama2.ts:276-289)
     hipLaunchKernelGGL(pf_norm_kernel, dim3(nt), dim3(256), 0, st, c->pf_xn, c->pf_x, c->w[L2_T_RMS_FFN] + d * l, c->d);
-    a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
+    pf_weights<MODE_W13>(c, l, a, L2_T_W1, L2_T_W3, -1);
     a.xin = c->pf_xn; a.out = c->pf_hb; a.n = c->d; a.rows = c->h;
     launch_pf_gemm<MODE_W13>(c, a, 4, tt, chunks, st);
     // w2 + residual (llama2.ts:292-295)
-    a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l; a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
+    pf_weights<MODE_W2>(c, l, a, L2_T_W2, -1, -1); a.xin = c->pf_hb; a.n = c->h; a.rows = c->d;
     launch_pf_gemm<MODE_W2>(c, a, 4, tt, chunks, st);
     LCHK(hipGetLastError());
   }

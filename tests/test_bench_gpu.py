@@ -23,7 +23,8 @@ def test_bench_json_contract():
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 32 and j["warmup"] == 4 and j["unit"] == "tokens/s" and j["vs_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
-    assert "+ 0 MiB of repacked copies" in j["config"]["weights"]          # stories15M: latency-form phases, a one-batch classifier
+    wm = j["config"]["weights_mib"]
+    assert wm["repacked"] == 0 and abs(wm["on_device"] - wm["checkpoint"]) <= 2          # stories15M: latency-form phases, a one-batch classifier
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = j["cpu_baseline"]
@@ -144,7 +145,7 @@ def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
         assert len(lines) == 1, lines
         j = json.loads(lines[0])
         assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "tp2" and j["scaling"] == "strong" and j["value"] > 0, j.get("note")
-        assert "MiB of repacked copies" in j["config"]["weights"] and "+ 0 MiB" not in j["config"]["weights"]     # 7B width: the streaming kernels' second copy
+        assert j["config"]["weights_mib"]["repacked"] > 0     # 7B width: the streaming kernels read their matrices in consumption order
         assert "note" in j and "no RCCL" in j["note"]
         assert j["tp"]["ranks"] == 2 and j["tp"]["sharded"] and j["tp"]["l2_tp_mode"] == [3] and j["tp"]["devices"] == [0, 0]
     _retry_once(attempt)
@@ -157,7 +158,7 @@ def test_bench_gpus_one_stays_in_process():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["config"]["parallelism"] == "single" and "tp" not in j
-    assert "+ 0 MiB of repacked copies" in j["config"]["weights"]
+    assert j["config"]["weights_mib"]["repacked"] == 0
 
 
 def test_bench_gpus_8_forms_an_eight_rank_group_by_itself(tmp_path):

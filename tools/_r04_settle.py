@@ -1,0 +1,12 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+from llama2_ts_amd import configs, runtime
+hdr = configs.header("llama2_7b")
+ctx = runtime.Context(hdr); ctx.synth_fill(1)
+t0 = time.perf_counter()
+ctx.bench_decode(1, 0, 8)
+print("first steps (pack + release) %.2f s, weights MiB %d" % (time.perf_counter() - t0, ctx.get_option(runtime.OPT_WEIGHT_MIB)))
+for i in range(14):
+    ms = ctx.bench_decode(1, 0, 128)
+    print("t=%5.2f s  %.2f tok/s" % (time.perf_counter() - t0, 128e3 / ms), flush=True)
+ctx.close()
