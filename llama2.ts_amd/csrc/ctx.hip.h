@@ -108,8 +108,8 @@ enum { P2P_MAXG = 8, P2P_FB = 64 };   // ranks; flag words per (parity, source):
 struct P2PPeers { unsigned long long* flags[P2P_MAXG]; double* inbox[P2P_MAXG]; float* logits[P2P_MAXG]; };
 struct P2PArgs {
   P2PPeers pr;
-  unsigned long long* epoch;   // this rank's exchange counter
-  unsigned* ticket;            // blocks finished in this launch
+  unsigned long long* epoch;   // this rank's exchange counters, one per block
+  unsigned* ticket;            // (unused)
   int* err;
   int G, rank, n;              // n: elements of this exchange (d, or V_loc)
   unsigned long long wait_ticks;   // bound of a flag wait, in 100 MHz ticks
@@ -139,7 +139,7 @@ struct l2_ctx {
   // one-shot peer-to-peer exchange (tp_p2p_*): this rank's inbox + flags, the peers' mappings
   bool p2p = false;
   void* p2p_base = nullptr;          // uncached: [2][8][64] flag words, then [2][8][d] doubles
-  unsigned long long* p2p_epoch = nullptr;   // + ticket (device)
+  unsigned long long* p2p_epoch = nullptr;   // [P2P_FB] exchange counters, one per block (device)
   int* p2p_err = nullptr;            // pinned + mapped
   int* p2p_err_dev = nullptr;
   P2PPeers p2p_peers = {};

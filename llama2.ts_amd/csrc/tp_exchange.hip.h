@@ -10,23 +10,37 @@
 // adds the same numbers in the same order, so x stays bit-identical across ranks and is rounded to fp32 once
 // (llama2.ts:201), exactly as the RCCL path and the oracle's orc_forward_tp do.  One kernel = exchange + residual;
 // nothing but kernels, so the whole tensor-parallel step is captured in one hipGraph.
-//   * epochs: a device counter per rank counts exchanges (all ranks run the same sequence); a flag holds the epoch
-//     of the exchange that last wrote its slot; slots alternate by epoch parity -- a rank cannot start exchange
-//     e + 2 before every peer has finished reading exchange e, because e + 1 needs their contribution first;
-//   * block b of every rank handles the same elements, so it only waits for block b of its peers;
-//   * release: stores, __threadfence_system(), barrier, then the flags (system-scope atomic stores); acquire:
-//     system-scope atomic polls (bounded: a rank that never arrives sets `err` instead of hanging the GPU), barrier,
-//     system fence, plain loads of the uncached inbox.
+//   * epochs: block b of every rank handles the same elements and only ever talks to block b of its peers, so every block
+//     counts ITS exchanges in a device word of its own (all ranks run the same sequence of launches); a flag holds the epoch of
+//     the exchange that last wrote its slot; slots alternate by epoch parity -- block b of a rank cannot start exchange e + 2
+//     before block b of every peer has finished reading exchange e, because e + 1 needs their contribution first, and they raise
+//     that only in the NEXT launch;
+//   * no fences (round 4; the first version bracketed the exchange with __threadfence_system(): ~8 us per exchange for a rank
+//     ALONE on its GPU, 30 % of the 8-rank step -- profiles/r04/tp_shard_step_kernels.txt): inbox, flags and the gathered
+//     logits are UNCACHED memory, every access to them is a system-scope relaxed atomic (sc0 sc1: past L1 and L2, straight to
+//     the memory that holds them, over xGMI for a peer's), so the release is "every storing wave has drained its stores
+//     (s_waitcnt vmcnt(0)), workgroup barrier, then the flag stores" -- writes to one peer arrive in order -- and the acquire is
+//     "poll the flag words, workgroup barrier, load" (MI355X guide, hand-off recipe R1 with every load L1-bypassing).  Polls are
+//     bounded: a rank that never arrives sets `err` instead of hanging the GPU.
 
-__device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) { return *a.epoch + 1; }
+__device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) { return a.epoch[blockIdx.x] + 1; }
 
-// flags of this block up on every peer ...
+__device__ __forceinline__ void p2p_store(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double p2p_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ void p2p_store(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// flags of this block up on every peer (solo: the G flags this rank would receive, raised by itself in its own inbox) ...
 __device__ __forceinline__ void p2p_raise(const P2PArgs& a, unsigned long long e, int tid) {
   const int par = (int)(e & 1), b = blockIdx.x;
-  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave: its payload stores have left
   __syncthreads();
-  // (solo: the G flags this rank would receive, raised by itself in its own inbox)
-  if (tid < a.G) __hip_atomic_store(a.pr.flags[a.solo ? a.rank : tid] + ((size_t)(par * P2P_MAXG + (a.solo ? tid : a.rank)) * P2P_FB + b), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid < a.G) __hip_atomic_store(a.pr.flags[a.solo ? a.rank : tid] + ((size_t)(par * P2P_MAXG + (a.solo ? tid : a.rank)) * P2P_FB + b), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ... then wait for every source's flag in the local inbox
 __device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e, int tid) {
@@ -35,8 +49,8 @@ __device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e,
     const unsigned long long* mine = a.pr.flags[a.rank] + ((size_t)(par * P2P_MAXG + tid) * P2P_FB + b);
     unsigned spins = 0;
     unsigned long long t0 = 0;
-    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-      __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+      __builtin_amdgcn_s_sleep(1);
       // bounded by WALL time on the constant 100 MHz clock (a.wait_ticks, default 30 s, L2_TP_WAIT_S): ordinary rank skew
       // -- a peer still capturing its graph, a slower checkpoint read -- must not trip it; a rank that died must.
       // The host then marks the context broken (check_p2p): epochs and flags no longer match the peers'.
@@ -48,15 +62,10 @@ __device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e,
     }
   }
   __syncthreads();
-  __threadfence_system();
 }
 
 __device__ __forceinline__ void p2p_end(const P2PArgs& a, unsigned long long e, int tid) {
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) { __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *a.epoch = e; }
-  }
+  if (tid == 0) a.epoch[blockIdx.x] = e;      // this block's count, read by the same block of the NEXT launch: a plain store nobody waits for
 }
 
 // PART 0: the whole exchange in one kernel (product path).  PART 1 / 2: its two halves -- contribute, then wait + combine
@@ -69,11 +78,11 @@ __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, con
                                                             float* mv_out, const int* tokpos) {
   const int tid = threadIdx.x, stride = gridDim.x * 256;
   const unsigned long long e = p2p_begin(a);
-  const size_t slot = (size_t)((int)(e & 1) * P2P_MAXG) * a.n;
+  const size_t slot = (size_t)((int)(e & 1) * P2P_MAXG) * a.n;      // (e: this block's epoch -- every block of a launch has the same one in a reduce)
   if (PART != 2) {
     for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
       const double v = partial[i];
-      for (int p = 0; p < a.G; ++p) a.pr.inbox[a.solo ? a.rank : p][slot + (size_t)(a.solo ? p : a.rank) * a.n + i] = v;
+      for (int p = 0; p < a.G; ++p) p2p_store(a.pr.inbox[a.solo ? a.rank : p] + slot + (size_t)(a.solo ? p : a.rank) * a.n + i, v);
     }
   }
   if (PART == 1) { p2p_raise(a, e, tid); return; }
@@ -81,8 +90,12 @@ __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, con
   p2p_wait(a, e, tid);
   for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
     const double* in = a.pr.inbox[a.rank] + slot + i;
-    double s = in[0];
-    for (int r = 1; r < a.G; ++r) s += in[(size_t)r * a.n];      // rank order on every rank
+    double part[P2P_MAXG];
+#pragma unroll
+    for (int r = 0; r < P2P_MAXG; ++r) part[r] = p2p_load(in + (size_t)(r < a.G ? r : 0) * a.n);      // all requested at once
+    double s = part[0];
+#pragma unroll
+    for (int r = 1; r < P2P_MAXG; ++r) if (r < a.G) s += part[r];      // rank order on every rank
     const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : x[i];
     const float mv = (float)s;
     x[i] = xr + mv;
@@ -99,7 +112,7 @@ __global__ void __launch_bounds__(256) tp_p2p_gather_kernel(const P2PArgs a, con
   if (PART != 2) {
     for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
       const float v = mine[i];
-      for (int p = 0; p < a.G; ++p) a.pr.logits[a.solo ? a.rank : p][(size_t)(a.solo ? p : a.rank) * a.n + i] = v;
+      for (int p = 0; p < a.G; ++p) p2p_store(a.pr.logits[a.solo ? a.rank : p] + (size_t)(a.solo ? p : a.rank) * a.n + i, v);
     }
   }
   if (PART == 1) { p2p_raise(a, e, tid); return; }
@@ -126,7 +139,7 @@ static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits) {
 }
 static P2PArgs p2p_args(const l2_ctx* c, int n) {
   P2PArgs a;
-  a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = (unsigned*)(c->p2p_epoch + 1); a.err = c->p2p_err_dev;
+  a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = nullptr; a.err = c->p2p_err_dev;
   a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks; a.solo = c->solo ? 1 : 0;
   return a;
 }
@@ -140,8 +153,8 @@ static int p2p_alloc(l2_ctx* c) {
   if (mode && !strcmp(mode, "rccl")) return L2_OK;
   if (hipExtMallocWithFlags(&c->p2p_base, p2p_bytes(c), hipDeviceMallocUncached) != hipSuccess) { c->p2p_base = nullptr; (void)hipGetLastError(); return L2_OK; }
   HIPCHK(hipMemset(c->p2p_base, 0, p2p_bytes(c)));
-  HIPCHK(hipMalloc(&c->p2p_epoch, 16));
-  HIPCHK(hipMemset(c->p2p_epoch, 0, 16));
+  HIPCHK(hipMalloc(&c->p2p_epoch, (size_t)P2P_FB * 8));
+  HIPCHK(hipMemset(c->p2p_epoch, 0, (size_t)P2P_FB * 8));
   HIPCHK(hipHostMalloc(&c->p2p_err, sizeof(int), hipHostMallocMapped));
   *c->p2p_err = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->p2p_err_dev, c->p2p_err, 0));
