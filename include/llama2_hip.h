@@ -62,7 +62,9 @@ enum {
 /* l2_set_option keys */
 enum {
   L2_OPT_EXACT_ATTENTION = 1, /* 1: value-accumulate rounds to fp32 at every timestep in t order, exactly as
-                                 llama2.ts:260-265 does (bit-faithful, slower); 0 (default): fp64 partial sums */
+                                 llama2.ts:260-265 does (the reference's own rounding points in that loop; slower; > 99.9 % of logits
+                                 come out bit-identical, the rest within 1 ulp: the tree-ordered fp64 sums elsewhere remain); 0 (default):
+                                 fp64 partial sums, one rounding */
   L2_OPT_USE_GRAPH = 2,       /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
   L2_OPT_KEEP_STATE = 3,      /* 1: the RunState fields that only transformer() itself reads (llama2.ts:131-146: att, k, v, hb2, xb2,
                                  the xb of the FFN half, the final-normed x) are also written out for l2_read_state (parity

@@ -251,7 +251,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
 
   // ---- weighted sum of values (llama2.ts:257-265)
   if (a.exact && NS == 1) {
-    // bit-faithful: the accumulator is a Float32Array element, rounded at every timestep, t ascending
+    // the reference's own rounding points: the accumulator is a Float32Array element, rounded at every timestep, t ascending
     for (int i = tid; i < hs; i += NTH) {
       const float* vp = a.vc + (size_t)hk * hs + i;
       float o = 0.0f;

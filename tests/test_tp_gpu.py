@@ -3,6 +3,7 @@ device or cut out of full host arrays by l2_upload, must equal llama2_ts_amd.tp.
 tensors.  RCCL with more than one rank needs >1 GPU (bench.py --gpus N on the driver's node); here the RCCL calls
 run with a 1-rank communicator, and the complete G-rank step runs through the library's loopback test hook
 (G contexts, G host threads, one device).  The collectives' arithmetic is also covered over gloo in test_tp_gloo.py."""
+import json
 import os
 
 import numpy as np
@@ -10,6 +11,8 @@ import pytest
 
 import oracle_lib as O
 from llama2_ts_amd import configs, runtime, tp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -296,3 +299,22 @@ dist.barrier()
         out = r.stdout.decode("utf8", "replace")
         assert r.returncode == 0, out[-3000:]
         assert ("peer-to-peer" in out) == (collective == "p2p"), out[-2000:]
+
+
+def test_context_on_a_device_other_than_the_threads_current_one():
+    """A context is bound to the device it was created on, whatever the calling thread has current: the first step allocates and
+    builds the repacked copies (ensure_ready), and that has to happen on the context's device -- one process holding two contexts
+    on two GPUs, or an N-API worker thread.  Needs two GPUs (skipped on the 1-GPU development boxes)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "llama2_7b_L2.json")))
+    ctx = runtime.Context(meta["header"], device=1)
+    ctx.synth_fill(meta["seed"])
+    torch.cuda.set_device(0)                      # the thread's current device is NOT the context's
+    free0 = torch.cuda.mem_get_info(0)[0]
+    toks = ctx.decode_greedy(1, 0, 8).tolist()    # packs (2 GB of repacked copies) and runs on device 1
+    assert toks == meta["argmax"][:8]
+    assert ctx.get_option(runtime.OPT_PACKED_MIB) > 1000
+    assert free0 - torch.cuda.mem_get_info(0)[0] < (256 << 20)       # nothing of it landed on device 0
+    ctx.close()
