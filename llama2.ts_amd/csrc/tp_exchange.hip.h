@@ -169,6 +169,20 @@ __global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n, in
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { partial[i] = (double)((rank + 1) * (k + 1)) + 0.5 * (double)i; x[i] = 0.0f; }
 }
+// ... and the check of what the exchange left in x, on the device: the soak below runs its exchanges back to back, like the
+// decode step does, not one per host round trip
+__global__ void p2p_selftest_check(const float* x, int G, int n, int k, int* bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && x[i] != (float)(0.5 * G * (G + 1) * (k + 1) + 0.5 * (double)i * G)) atomicAdd(bad, 1);
+}
+__global__ void p2p_selftest_fill_logits(float* mine, int rank, int n, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) mine[i] = (float)(rank * 4096 + k) + (float)i * 0.25f;
+}
+__global__ void p2p_selftest_check_logits(const float* all, int G, int n, int k, int* bad) {      // all: the gathered (uncached) vector of G slices
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < G * n) { const int r = i / n, j = i - r * n; if (all[i] != (float)(r * 4096 + k) + (float)j * 0.25f) atomicAdd(bad, 1); }
+}
 // Test hook (L2_TP_IPC_DIR=<directory>): the ranks are separate PROCESSES that meet through files instead of an RCCL
 // communicator, so the IPC mapping, the self-test and the peer-to-peer exchange run between processes on a box with one GPU
 // (RCCL refuses two ranks on one device).  No fallback in this mode: the exchange works or creation fails.
@@ -256,8 +270,34 @@ static int p2p_connect_ipc(l2_ctx* c) {
       if (*c->p2p_err) h_ok = 0;
       for (int i = 0; i < n && h_ok; ++i) if (got[i] != (float)(0.5 * G * (G + 1) * (k + 1) + 0.5 * (double)i * G)) h_ok = 0;
     }
+    // ... then a soak: 96 all-reduces and 32 logits gathers BACK TO BACK on the stream, every element of every result checked on
+    // the device.  The exchange has no fences (its ordering rests on drained write-through stores, see the top of this file), and
+    // no multi-GPU box has ever run it: a peer whose payload could become visible after its flag has 128 chances to show it here,
+    // in the timing the decode step has -- and sends the whole group to the RCCL collectives if it does.
+    if (h_ok) {
+      int* d_bad = nullptr;
+      HIPCHK(hipMalloc(&d_bad, sizeof(int)));
+      HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+      const int nl = c->V_loc;
+      for (int k = 4; k < 100; ++k) {
+        hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
+        hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
+        hipLaunchKernelGGL(p2p_selftest_check, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->xb2, G, n, k, d_bad);
+        if (k % 3 == 0) {
+          hipLaunchKernelGGL(p2p_selftest_fill_logits, dim3((nl + 255) / 256), dim3(256), 0, c->stream, c->logits_loc, c->rank, nl, k);
+          hipLaunchKernelGGL(tp_p2p_gather_kernel<0>, dim3(p2p_grid(nl)), dim3(256), 0, c->stream, p2p_args(c, nl), c->logits_loc);
+          hipLaunchKernelGGL(p2p_selftest_check_logits, dim3((G * nl + 255) / 256), dim3(256), 0, c->stream, c->logits, G, nl, k, d_bad);
+        }
+      }
+      int bad = 0;
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
+      hipFree(d_bad);
+      if (bad || *c->p2p_err) h_ok = 0;
+    }
     *c->p2p_err = 0;
     HIPCHK(hipMemset(c->xb2, 0, (size_t)n * 4));
+    HIPCHK(hipMemset(c->logits, 0, (size_t)c->V * 4));
     { const int rc_ = all_min(h_ok, &h_ok); if (rc_) return rc_; }
   }
   c->p2p = h_ok != 0;
