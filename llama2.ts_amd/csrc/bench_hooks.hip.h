@@ -79,18 +79,18 @@ extern "C" int l2_bench_gemv(l2_ctx* c, int kind, int layer, int iters, float* a
   switch (kind) {
     case L2_T_WQ: case L2_T_WK: case L2_T_WV:
       mode = MODE_QKV;
-      a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * layer; a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * layer;
-      a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * layer;
+      a.w0 = wptr(c, L2_T_WQ, layer); a.w1 = wptr(c, L2_T_WK, layer);
+      a.w2 = wptr(c, L2_T_WV, layer);
       a.in = c->xn; a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * layer; a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff;
       a.n = c->d; a.rows = c->d_loc + 2 * c->kvd_loc; a.dim = c->d_loc; a.kv_dim = c->kvd_loc; break;
     case L2_T_WO:
-      mode = MODE_WO; a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * layer; a.in = c->xb; a.res = c->xn; a.out = c->xb2;
+      mode = MODE_WO; a.w0 = wptr(c, L2_T_WO, layer); a.in = c->xb; a.res = c->xn; a.out = c->xb2;
       a.n = c->d_loc; a.rows = c->d; break;
     case L2_T_W1: case L2_T_W3:
-      mode = MODE_W13; a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * layer; a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * layer;
+      mode = MODE_W13; a.w0 = wptr(c, L2_T_W1, layer); a.w1 = wptr(c, L2_T_W3, layer);
       a.in = c->xn; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * layer; a.out = c->hb; a.n = c->d; a.rows = c->h_loc; break;
     case L2_T_W2:
-      mode = MODE_W2; a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * layer; a.in = c->hb; a.res = c->xn; a.out = c->xb2;
+      mode = MODE_W2; a.w0 = wptr(c, L2_T_W2, layer); a.in = c->hb; a.res = c->xn; a.out = c->xb2;
       a.n = c->h_loc; a.rows = c->d; break;
     case L2_T_WCLS: case L2_T_TOKEN_EMBEDDING:
       mode = MODE_CLS; a.w0 = c->w[L2_T_WCLS]; a.in = c->xn; a.rmsw = c->w[L2_T_RMS_FINAL]; a.out = c->logits_loc; a.aux = c->xb2;

@@ -394,6 +394,9 @@ static const float* packed_of(const l2_ctx* c, int mode, int l) {
   const l2_ctx::Packed& p = c->packed[mode];
   return (c->packed_valid && p.buf) ? p.buf + p.layer_elems * (size_t)l : nullptr;
 }
+// layer l of a per-layer tensor, or null once its row-major copy has been given back (one copy of the weights: the launch then
+// reads the repacked copy, and a null here makes a launch that cannot fail loudly instead of reading freed memory)
+static const float* wptr(const l2_ctx* c, int kind, int l) { return c->w[kind] ? c->w[kind] + c->layer_elems[kind] * (size_t)l : nullptr; }
 static PhaseArgs base_args(const l2_ctx* c) {
   PhaseArgs a;
   memset(&a, 0, sizeof(a));
@@ -404,9 +407,9 @@ static PhaseArgs base_args(const l2_ctx* c) {
 static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs + RoPE + KV-cache store (llama2.ts:216-240)
   PhaseArgs a = base_args(c);
   const size_t loff = (size_t)l * c->S * c->kvd_loc;
-  a.w0 = c->w[L2_T_WQ] + c->layer_elems[L2_T_WQ] * l;
-  a.w1 = c->w[L2_T_WK] + c->layer_elems[L2_T_WK] * l;
-  a.w2 = c->w[L2_T_WV] + c->layer_elems[L2_T_WV] * l;
+  a.w0 = wptr(c, L2_T_WQ, l);
+  a.w1 = wptr(c, L2_T_WK, l);
+  a.w2 = wptr(c, L2_T_WV, l);
   a.in = c->x; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr;
   a.rmsw = c->w[L2_T_RMS_ATT] + (size_t)c->d * l;
   a.out = c->q; a.out_k = c->kc + loff; a.out_v = c->vc + loff;
@@ -417,7 +420,7 @@ static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs +
 }
 static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (llama2.ts:270-273)
   PhaseArgs a = base_args(c);
-  a.w0 = c->w[L2_T_WO] + c->layer_elems[L2_T_WO] * l;
+  a.w0 = wptr(c, L2_T_WO, l);
   a.in = c->xb; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; a.res = c->x; a.out = c->x; a.aux = c->opt_keep_state ? c->xb2 : nullptr;
   a.n = c->d_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
@@ -426,8 +429,8 @@ static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (lla
 }
 static PhaseArgs w13_args(const l2_ctx* c, int l) {   // rmsnorm + w1,w3 GEMVs + SwiGLU (llama2.ts:276-289)
   PhaseArgs a = base_args(c);
-  a.w0 = c->w[L2_T_W1] + c->layer_elems[L2_T_W1] * l;
-  a.w1 = c->w[L2_T_W3] + c->layer_elems[L2_T_W3] * l;
+  a.w0 = wptr(c, L2_T_W1, l);
+  a.w1 = wptr(c, L2_T_W3, l);
   a.in = c->x; a.rmsw = c->w[L2_T_RMS_FFN] + (size_t)c->d * l;
   a.out = c->hb; a.aux = c->opt_keep_state ? c->hb2 : nullptr;
   a.n = c->d; a.rows = c->h_loc;
@@ -436,7 +439,7 @@ static PhaseArgs w13_args(const l2_ctx* c, int l) {   // rmsnorm + w1,w3 GEMVs +
 }
 static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (llama2.ts:292-295)
   PhaseArgs a = base_args(c);
-  a.w0 = c->w[L2_T_W2] + c->layer_elems[L2_T_W2] * l;
+  a.w0 = wptr(c, L2_T_W2, l);
   a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = (c->tp_path || !c->opt_keep_state) ? nullptr : c->xb;
   a.n = c->h_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
@@ -557,7 +560,12 @@ static int ensure_rowmajor(l2_ctx* c, bool unpack) {
   for (int k = 0; k < L2_T_COUNT; ++k) {
     if (!c->released[k]) continue;
     any = true;
-    HIPCHK(hipMalloc(&c->w[k], c->layer_elems[k] * c->layers_of[k] * sizeof(float)));
+    if (hipMalloc(&c->w[k], c->layer_elems[k] * c->layers_of[k] * sizeof(float)) != hipSuccess) {
+      (void)hipGetLastError();
+      c->w[k] = nullptr;
+      for (int j = 0; j < k; ++j) if (c->released[j] && c->w[j]) { hipFree(c->w[j]); c->w[j] = nullptr; }      // all or nothing: the repacked copies stay the only ones
+      return fail(L2_E_HIP, "no device memory to bring the row-major copy of tensor kind %d back (one copy of the weights is held; a re-upload or l2_read_tensor needs a second one for a moment)", k);
+    }
   }
   if (!any) return L2_OK;
   int rc = L2_OK;
