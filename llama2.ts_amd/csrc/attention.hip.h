@@ -34,7 +34,6 @@ struct AttnArgs {
   unsigned* counter;     // split form: [H] merge tickets (one per 128-byte line), zero between launches
   int dim, head_size, seq_len, n_heads, nsplit;
   int kv_dim, kv_mul;    // floats of a cache row; query heads per cache head (1 unless the context honours n_kv_heads < n_heads)
-  int cmax, ns_shift;    // (seq_len + nsplit - 1) / nsplit; log2(nsplit) when it is a power of two, else -1 (the kernels' prologue does not divide)
   double inv_sqrt_hs;    // 1 / sqrt(head_size)
   int exact;             // 1: fp32-rounded t-sequential value accumulate (llama2.ts:263); never with nsplit > 1
   int pos_plus1;         // scalar fallback kernel, prefill: non-zero = the queries are pos0 + blockIdx.y (else tokpos)
@@ -79,9 +78,10 @@ __device__ __forceinline__ void fused_head_done(const AttnArgs& a, int h, unsign
   if (tid == 0) a.gran_ep[h] = tag;
 }
 
-// rows of a split: ceil(T / nsplit) -- a shift for the split counts in use (1, 8)
+// rows of a split: ceil(T / nsplit).  (A shift for power-of-two split counts behind a run-time test was measured: hipcc then carries
+// both forms through all three tile-count bodies, 90 KB more code, and the kernel lost 0.4 us: profiles/r04/attention_prologue_ab.txt.)
 __device__ __forceinline__ int attn_chunk(const AttnArgs& a, int T) {
-  return a.ns_shift >= 0 ? (T + a.nsplit - 1) >> a.ns_shift : (T + a.nsplit - 1) / a.nsplit;
+  return (T + a.nsplit - 1) / a.nsplit;
 }
 
 constexpr int ATT_PS = 65;       // doubles per tile slot in the transpose buffer (odd: conflict-free reads)
@@ -106,8 +106,8 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   constexpr int RR = NW * RG;              // rows per workgroup per round
   constexpr int NTH = 64 * NW;
   const int S = a.seq_len, hs = a.head_size, dim = a.kv_dim, NS = a.nsplit;   // `dim`: the stride of the cache rows
-  const int hk = a.kv_mul == 1 ? h : h / a.kv_mul;                            // this head's columns of a cache row
-  const int cmax = a.cmax;
+  const int hk = h / a.kv_mul;                                                // this head's columns of a cache row
+  const int cmax = (S + NS - 1) / NS;
   float* sc = reinterpret_cast<float*>(smem);
   double* red = reinterpret_cast<double*>(smem + (size_t)((cmax + 3) & ~3) * 4);
   double* P = red + 32;
@@ -300,7 +300,8 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       }
       double own = 0.0;
       if (FUSED) { if (own_pos) own = (double)sc[n - 1] * (double)gv; }      // hs <= 64 <= NTH: i == tid
-      a.xb[(size_t)h * hs + i] = (float)(((c0 + c1) + (c2 + c3)) + own);   // ONE rounding of the fp64 sum
+      if (FUSED) a.xb[(size_t)h * hs + i] = (float)(((c0 + c1) + (c2 + c3)) + own);   // ONE rounding of the fp64 sum
+      else a.xb[(size_t)h * hs + i] = (float)((c0 + c1) + (c2 + c3));
     }
     STAMP(5);
     if (FUSED) fused_head_done(a, h, ftag, tid);
@@ -319,7 +320,8 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
     }
     double own = 0.0;
     if (FUSED) { if (own_pos) own = (double)sc[n - 1] * (double)gv; }
-    st_sc1(mypart + i, ((c0 + c1) + (c2 + c3)) + own);
+    if (FUSED) st_sc1(mypart + i, ((c0 + c1) + (c2 + c3)) + own);
+    else st_sc1(mypart + i, (c0 + c1) + (c2 + c3));
   }
   if (tid == 0) { st_sc1(mypart + hs, sum); st_sc1(mypart + hs + 1, (double)mx); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
@@ -407,7 +409,7 @@ __global__ void __launch_bounds__(512) qkv_attn_small_kernel(const PhaseArgs a, 
   L2_PIN4(a.w0, a.w1, a.w2, a.in); L2_PIN4(a.emb, a.rmsw, a.out, a.out_k); L2_PIN4(a.out_v, a.fr, a.fi, a.tokpos);
   L2_PIN4(a.n, a.rows, a.dim, a.kv_dim); L2_PIN4(a.head_size, a.gran, a.gran_ep, a.inv_n); asm volatile("" ::"s"(a.gran_hmagic)); asm volatile("" ::"s"(a.aux), "s"(a.aux2));
   L2_PIN4(at.kc, at.vc, at.att, at.xb); L2_PIN4(at.tokpos, at.part, at.counter, at.dim); L2_PIN4(at.head_size, at.seq_len, at.n_heads, at.nsplit);
-  L2_PIN4(at.kv_dim, at.kv_mul, at.cmax, at.ns_shift); L2_PIN4(at.inv_sqrt_hs, at.gran, at.gran_ep, at.herr); L2_PIN4(at.wait_ticks, at.exact, nattn, at.dbg);
+  asm volatile("" ::"s"(at.kv_dim), "s"(at.kv_mul)); L2_PIN4(at.inv_sqrt_hs, at.gran, at.gran_ep, at.herr); L2_PIN4(at.wait_ticks, at.exact, nattn, at.dbg);
 #undef L2_PIN4
   const int nq = (int)gridDim.x - nattn;
   if ((int)blockIdx.x < nq) { phase_small_body<MODE_QKV, XV, 2>(a, smem, blockIdx.x, nq); return; }
@@ -419,7 +421,12 @@ __global__ void __launch_bounds__(512) qkv_attn_small_kernel(const PhaseArgs a, 
 template <int LR, int NW, int NT>
 __global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_tile_dispatch<LR, NW, NT>(a, smem, blockIdx.x, blockIdx.y, a.tokpos[1]);
+  // every argument in ONE fetch round, and the position (device memory: one captured graph serves every position) requested right
+  // behind it -- left alone, hipcc fetches the arguments in two dependent rounds before it even asks for pos (see qkv_attn_small_kernel)
+  asm volatile("" ::"s"(a.q), "s"(a.kc), "s"(a.vc), "s"(a.att), "s"(a.xb), "s"(a.tokpos), "s"(a.part), "s"(a.counter));
+  const int pos = a.tokpos[1];
+  asm volatile("" ::"s"(a.dim), "s"(a.head_size), "s"(a.seq_len), "s"(a.n_heads), "s"(a.nsplit), "s"(a.kv_dim), "s"(a.kv_mul), "s"(a.inv_sqrt_hs));
+  attn_tile_dispatch<LR, NW, NT>(a, smem, blockIdx.x, blockIdx.y, pos);
 }
 
 // Prefill: grid (head, query).  Query p of the chunk sits at position pos0 + p and sees cache rows 0..pos0+p,
@@ -432,7 +439,7 @@ __global__ void __launch_bounds__(64 * NW) pf_attn_tile_kernel(const AttnArgs a,
   b.q = a.q + (size_t)p * a.dim;
   b.xb = a.xb + (size_t)p * a.dim;
   b.att = nullptr;
-  b.nsplit = 1; b.cmax = a.seq_len; b.ns_shift = 0;
+  b.nsplit = 1;
   attn_tile_dispatch<LR, NW, NT>(b, smem, blockIdx.x, 0, pos0 + p);
 }
 

@@ -170,9 +170,6 @@ static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
   a.tokpos = c->tokpos; a.part = c->attn_part; a.counter = c->attn_counter;
   a.dim = c->d_loc; a.head_size = c->hs; a.seq_len = c->S; a.n_heads = c->H_loc; a.nsplit = c->cur_splits;
   a.kv_dim = c->kvd_loc; a.kv_mul = c->H / c->KVH;
-  a.cmax = (c->S + a.nsplit - 1) / a.nsplit;
-  a.ns_shift = -1;
-  for (int sft = 0; sft < 16; ++sft) if ((1 << sft) == a.nsplit) a.ns_shift = sft;
   a.exact = c->opt_exact;
   a.inv_sqrt_hs = 1.0 / sqrt((double)c->hs);
 #ifdef L2_STAMPS
@@ -226,9 +223,8 @@ static bool fused_shape_ok(const l2_ctx* c) {      // whatever the position
 // ... and for the step being enqueued: one workgroup per head only (with 8 splits per head the fused form loses to two launches:
 // 96 of the CUs are then attention workgroups that wait while the rest do the GEMV)
 static bool fused_qkv_attn_ok(const l2_ctx* c) {
-  if (!fused_shape_ok(c) || c->opt_exact) return false;
+  if (!c->cur_fused || !fused_shape_ok(c) || c->opt_exact) return false;
   const int ns = c->cur_splits;
-  if (ns != 1 && !c->opt_fuse_splits) return false;
   return fused_attn_blocks(c, ns) * 2 <= c->n_cus && (size_t)attn_tile_lds(c->S, ns, 8, 8) <= 160 * 1024;
 }
 
@@ -273,6 +269,6 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // att
     hipLaunchKernelGGL(attn_scalar_kernel, dim3(c->H_loc, 1), dim3(256), lds, st, a, 0);
     return hipGetLastError();
   }
-  if (c->opt_exact) { a.nsplit = 1; a.cmax = c->S; a.ns_shift = 0; }
+  if (c->opt_exact) a.nsplit = 1;
   return launch_attn_tile(c, a, a.nsplit, -1, st);
 }

@@ -35,7 +35,7 @@
 
 using namespace l2k;
 
-enum { NLEV = 2 };   // attention split levels: 1 or 8 workgroups per head
+enum { NLEV = 3 };   // step levels by context length: two launches + one workgroup per head / the fused QKV + attention launch / two launches + 8 workgroups per head
 
 #include "ctx.hip.h"
 
@@ -62,17 +62,26 @@ static void destroy_graphs(l2_ctx* c) {
 // workgroups (flash-decode merge by the last arriver, attention.hip.h).  The merge costs ~2.5 us per layer whatever
 // the split count, so intermediate counts never win (tools/ctx_curve.py, 7B and 110M: 2 / 4 splits are slower than
 // 8 at every position where they beat 1; the crossover is at 140-160 rows for 64- and 128-wide heads alike).
-static const int kSplitLevels[NLEV] = {1, 8};
+static const int kSplitLevels[NLEV] = {1, 1, 8};
 static bool fused_shape_ok(const l2_ctx* c);
-// Where the fused QKV + attention launch applies (launch.hip.h: fused_qkv_attn_ok) the unsplit level reaches to 256 rows: its
-// attention workgroups request their cache rows while the GEMV runs, so one workgroup per head keeps up for longer -- the fused
-// launch with one workgroup per head beats the two launches with 8 splits up to there (profiles/r04/fused_qkv_attention_ab.txt).
+// Level of a step by its position.  Where the fused QKV + attention launch applies (launch.hip.h: fused_shape_ok) it takes the
+// middle of the range: its attention workgroups request their cache rows while the GEMV runs, so ONE workgroup per head keeps up
+// to 256 rows (two launches split a head over 8 workgroups from 144), but below `fuse_min_rows` the hand-off costs more than the
+// launch boundary it replaces (stories110M: two launches win by 2-3 % up to 128 rows, the fused launch by 4 % from there to 256;
+// stories15M: the fused launch wins from the first position -- profiles/r04/fused_qkv_attention_ab.txt, last block).
 static int split_level(const l2_ctx* c, int pos) {
   if (c->attn_splits_forced > 0 || c->opt_exact) return 0;
-  const int rows = (c->split_rows_set || !fused_shape_ok(c)) ? c->split_rows : 256;
-  return pos + 1 > rows ? 1 : 0;
+  const bool fusable = fused_shape_ok(c);
+  const int rows = pos + 1, unsplit_to = (c->split_rows_set || !fusable) ? c->split_rows : 256;
+  if (rows > unsplit_to) return 2;
+  return (fusable && rows > c->fuse_min_rows) ? 1 : 0;
 }
 static int splits_of(const l2_ctx* c, int level) { return c->attn_splits_forced > 0 ? c->attn_splits_forced : kSplitLevels[level]; }
+// what a step of this level is enqueued with
+static void set_level(l2_ctx* c, int level) {
+  c->cur_splits = splits_of(c, level);
+  c->cur_fused = level == 1 || (c->opt_fuse_splits && !c->opt_exact && fused_shape_ok(c));      // (the switch: fused wherever the shape allows -- tests)
+}
 
 extern "C" void l2_destroy(l2_ctx* c) {
   if (!c) return;
@@ -229,6 +238,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     CK(hipHostGetDevicePointer((void**)&c->h_herr_dev, c->h_herr, 0));
     c->opt_fuse = dev_int("L2_FUSE_QKV_ATTN", 1);
     c->opt_fuse_splits = dev_int("L2_FUSE_SPLITS", 0);
+    c->fuse_min_rows = dev_int("L2_FUSE_MIN_ROWS", c->d >= 512 ? 128 : 0);
   }
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
@@ -716,7 +726,7 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
   // (memcpy nodes inside a captured graph crash rocprofv3's kernel trace on ROCm 7.2)
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   const int lvl = split_level(c, pos);
-  c->cur_splits = splits_of(c, lvl);
+  set_level(c, lvl);
   if (c->opt_graph) {
     if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc && rc != L2_RUN_EAGER) return rc; }
   }
@@ -753,13 +763,13 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   if (c->opt_graph) {   // capture what this run needs before the timed region
     for (int s = 0; s < steps; ++s) {
       const int lvl = split_level(c, pos0 + s);
-      if (!c->g_greedy[lvl]) { c->cur_splits = splits_of(c, lvl); rc = capture(c, enqueue_greedy, &c->g_greedy[lvl]); if (rc == L2_RUN_EAGER) break; if (rc) return rc; }
+      if (!c->g_greedy[lvl]) { set_level(c, lvl); rc = capture(c, enqueue_greedy, &c->g_greedy[lvl]); if (rc == L2_RUN_EAGER) break; if (rc) return rc; }
     }
   }
   if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
   for (int s = 0; s < steps; ++s) {
     const int lvl = split_level(c, pos0 + s);
-    c->cur_splits = splits_of(c, lvl);
+    set_level(c, lvl);
     if (c->opt_graph) HIPCHK(hipGraphLaunch(c->g_greedy[lvl], c->stream));
     else { rc = enqueue_greedy(c, c->stream); if (rc) return rc; }
     // rocprofv3 (ROCm 7.2) segfaults with thousands of un-synchronised dispatches queued behind it:
@@ -804,7 +814,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   const bool graph = c->opt_graph && !c->loop;
   for (int s = 0; s < steps; ++s) {
     const int lvl = split_level(c, pos0 + s);
-    c->cur_splits = splits_of(c, lvl);
+    set_level(c, lvl);
     if (graph) {
       hipGraphExec_t& g = c->g_sample[lvl][c->samp_mode + (c->samp_amax ? 2 : 0)];
       if (!g) { rc = capture(c, enqueue_sample, &g); if (rc && rc != L2_RUN_EAGER) return rc; }

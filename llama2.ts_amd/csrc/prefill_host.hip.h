@@ -127,7 +127,7 @@ static int prefill_chunk(l2_ctx* c, const int32_t* tokens, int n, int pos0) {
       LCHK(hipGetLastError());
     } else {   // one workgroup per (head, query): the decode kernel (other head sizes, the exact accumulate, very long contexts)
       AttnArgs aa;
-      c->cur_splits = 1;
+      c->cur_splits = 1; c->cur_fused = false;
       fill_attn_args(c, l, aa);
       aa.q = c->pf_q; aa.xb = c->pf_xb; aa.att = nullptr; aa.pos_plus1 = 1;
       LCHK(launch_attn_tile(c, aa, n, pos0, st));
