@@ -41,6 +41,7 @@ struct AttnArgs {
   // of the same launch that compute them (kernels.hip.h: granule_store)
   const unsigned long long* gran;   // [dim + 2 kv_dim] words, tag = *gran_ep + 1
   unsigned* gran_ep;               // launch counter: read by every workgroup at its start, advanced once per launch by whoever finishes head 0
+  int fused_four_waves;            // fused launch: contexts of up to 128 rows on four waves (else eight)
   int* herr;                       // host-mapped: set when a granule wait gave up
   unsigned long long wait_ticks;   // bound of that wait on the 100 MHz clock
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
@@ -415,7 +416,15 @@ __global__ void __launch_bounds__(512) qkv_attn_small_kernel(const PhaseArgs a, 
   if ((int)blockIdx.x < nq) { phase_small_body<MODE_QKV, XV, 2>(a, smem, blockIdx.x, nq); return; }
   int sp = 0, h = (int)blockIdx.x - nq;
   while (h >= at.n_heads) { h -= at.n_heads; ++sp; }               // (split, head) without a division: at most nsplit steps
-  attn_tile_dispatch<LR, 8, NT, true>(at, smem, h, sp, at.tokpos[1]);
+  const int pos = at.tokpos[1];
+  // up to 128 rows: FOUR waves (one per SIMD: a dependent fp64 instruction then issues as soon as its operands are there, and a
+  // barrier has four waves to collect, not eight), the other four leave at once; beyond: eight waves, one round of 256 rows
+  if (at.nsplit == 1 && pos + 1 <= 4 * NT * (64 / LR) && at.fused_four_waves) {
+    if (threadIdx.x >= 256) return;
+    attn_tile_dispatch<LR, 4, NT, true>(at, smem, h, sp, pos);
+    return;
+  }
+  attn_tile_dispatch<LR, 8, NT, true>(at, smem, h, sp, pos);
 }
 
 template <int LR, int NW, int NT>

@@ -166,6 +166,7 @@ struct l2_ctx {
   int* h_herr = nullptr;                // pinned + mapped: a granule wait gave up
   int* h_herr_dev = nullptr;
   int opt_fuse = 1;                     // L2_FUSE_QKV_ATTN=0: two launches (A/B, development switch)
+  int opt_fuse_four_waves = 1;          // L2_FUSE_FOUR_WAVES=0: the fused launch's attention workgroups always on eight waves (A/B)
   int opt_fuse_splits = 0;              // L2_FUSE_SPLITS=1: the fused launch also at the split level (A/B, tests: it is slower there)
   unsigned long long* amax = nullptr;   // greedy loop: 8 argmax keys, one per 128-byte line, zero between tokens
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position

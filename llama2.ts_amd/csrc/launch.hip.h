@@ -234,7 +234,7 @@ static hipError_t launch_qkv_attn_xv(const l2_ctx* c, const PhaseArgs& qa, const
   int nq = c->n_cus - nattn;
   const int groups = (qa.rows + 1) / 2;
   if (nq > groups) nq = groups;
-  const size_t lds_q = (size_t)XV * 64 * 16, lds_a = attn_tile_lds(c->S, at.nsplit, 8, 8);
+  const size_t lds_q = (size_t)XV * 64 * 16, lds_a = attn_tile_lds(c->S, at.nsplit, 8, 8);      // (the four-wave form needs less)
   const size_t lds = lds_q > lds_a ? lds_q : lds_a;
   hipError_t e = lds_opt_in(&qkv_attn_small_kernel<XV, 16, 8>, lds);
   if (e != hipSuccess) return e;
@@ -252,6 +252,7 @@ static hipError_t launch_qkv_attn(const l2_ctx* c, const PhaseArgs& qa_in, int l
   AttnArgs at;
   fill_attn_args(c, l, at);
   at.gran = c->gran; at.gran_ep = c->gran_ep; at.herr = c->h_herr_dev; at.wait_ticks = 200000000ull;      // 2 s
+  at.fused_four_waves = c->opt_fuse_four_waves;
   switch ((c->d / 4 + 63) / 64) {
     case 2: return launch_qkv_attn_xv<2>(c, qa, at, st);
     case 3: return launch_qkv_attn_xv<3>(c, qa, at, st);

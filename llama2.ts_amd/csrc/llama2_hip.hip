@@ -238,6 +238,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     CK(hipHostGetDevicePointer((void**)&c->h_herr_dev, c->h_herr, 0));
     c->opt_fuse = dev_int("L2_FUSE_QKV_ATTN", 1);
     c->opt_fuse_splits = dev_int("L2_FUSE_SPLITS", 0);
+    c->opt_fuse_four_waves = dev_int("L2_FUSE_FOUR_WAVES", 1);
     c->fuse_min_rows = dev_int("L2_FUSE_MIN_ROWS", c->d >= 512 ? 128 : 0);
   }
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));

@@ -735,15 +735,17 @@ FUSED_SHAPES = [(288, 768, 2, 6, 6, 331, 300), (768, 2048, 2, 12, 12, -259, 290)
 
 
 @pytest.mark.parametrize("hdr", FUSED_SHAPES)
-@pytest.mark.parametrize("env", [{}, {"L2_FUSE_SPLITS": "1", "L2_ATTN_SPLIT_ROWS": "20"}, {"L2_FUSE_SPLITS": "1", "L2_ATTN_SPLITS": "3"}])
+@pytest.mark.parametrize("env", [{}, {"L2_FUSE_MIN_ROWS": "0"}, {"L2_FUSE_MIN_ROWS": "0", "L2_FUSE_FOUR_WAVES": "0"},
+                                 {"L2_FUSE_SPLITS": "1", "L2_ATTN_SPLIT_ROWS": "20"}, {"L2_FUSE_SPLITS": "1", "L2_ATTN_SPLITS": "3"}])
 def test_fused_qkv_attention_launch_equals_the_two_launches(built, hdr, env, monkeypatch):
     """The head-local edge inside ONE launch (attention.hip.h: qkv_attn_small_kernel; llama2.ts:216-240 -> 244-267): q, k, v of the
     position handed to the attention workgroups of the same launch as tagged granules, row pos scored from them.  Shapes that take
     it (input vectors of 257 .. 1024 floats, heads of 33 .. 64) against a context that runs the two launches (L2_FUSE_QKV_ATTN=0) and
     against the oracle: every RunState field the two phases write (q, k, v, att, the attention output xb through the wo result, the
     cache rows), logits, argmax, the device loop (one hipGraph per token: the launch counters the tags come from live on the
-    device), a second run from position 0 over the same context (tags must not repeat), the unsplit level up to its 256 rows, and
-    -- behind its switch -- the fused form with a head split over several workgroups."""
+    device), a second run from position 0 over the same context (tags must not repeat), the unsplit level up to its 256 rows
+    (four attention waves up to 128 rows, eight beyond; the fused launch from the first row on where the default starts it at 129)
+    and -- behind its switch -- the fused form with a head split over several workgroups."""
     orc = O.Oracle(hdr, 5)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
