@@ -1,3 +1,6 @@
+"""Decode rate over the seconds after the first step of a repacked model (Llama-2-7B): the first step gives the row-major tensors back
+(one copy of the weights) and the driver scrubs the released memory in the background -- L2_ONE_COPY=0 (behind L2_TEST_HOOKS=1) keeps
+both copies for comparison.  profiles/r04/one_copy_release_transient.txt."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 from llama2_ts_amd import configs, runtime
