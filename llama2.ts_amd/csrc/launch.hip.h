@@ -24,7 +24,9 @@ static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
   if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4 || (c->tune_U == 3 && mode == MODE_CLS)) U = c->tune_U;
   g.U = U;
   const int groups = (rows * pair + g.R - 1) / g.R;
-  g.nwaves = groups >= 1024 ? 4 : (groups >= 512 ? 2 : 1);
+  // 4 waves per workgroup from 512 row groups on (2 up to round 3: the q / k / v shard of an 8-rank group -- 768 groups -- runs
+  // 9.0 -> 7.1 us with 4: fewer, fuller workgroups share the staged x; tools/tp_shard_sweep.py)
+  g.nwaves = groups >= 512 ? 4 : (groups >= 256 ? 2 : 1);
   if (c->tune_nwaves == 1 || c->tune_nwaves == 2 || c->tune_nwaves == 4) g.nwaves = c->tune_nwaves;
   // staging: PRE float4 per thread per round, one round if it can cover the (padded) vector
   const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 64 * g.nwaves;
