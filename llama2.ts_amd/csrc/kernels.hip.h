@@ -343,23 +343,23 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         const int i = i0 + 2 * p;
         const float s0 = (float)acc[2 * p], s1 = (float)acc[(2 * p + 1) % R];  // matmul store, llama2.ts:201
         if (m == 2) {  // v: straight into the cache row (llama2.ts:240)
+          if (a.gran) { unsigned long long* gp = a.gran + a.dim + a.kv_dim + i; granule_store(gp, s0, pre.tag); granule_store(gp + 1, s1, pre.tag); }      // first: a workgroup of this launch waits for them
           float* vc = a.out_v + (size_t)pos * a.kv_dim;
           vc[i] = s0; vc[i + 1] = s1;
           if (a.aux2) { a.aux2[i] = s0; a.aux2[i + 1] = s1; }
-          if (a.gran) { unsigned long long* gp = a.gran + a.dim + a.kv_dim + i; granule_store(gp, s0, pre.tag); granule_store(gp + 1, s1, pre.tag); }
         } else {       // RoPE on the adjacent pair (llama2.ts:224-235)
           double fcr, fci;
           if (PREF) { fcr = pre.e0; fci = pre.e1; }
           else { const int idx = pos * (a.head_size / 2) + (i % a.head_size) / 2; fcr = a.fr[idx]; fci = a.fi[idx]; }
           const float o0 = (float)((double)s0 * fcr - (double)s1 * fci);
           const float o1 = (float)((double)s0 * fci + (double)s1 * fcr);
+          if (a.gran) { unsigned long long* gp = a.gran + (m == 0 ? 0 : a.dim) + i; granule_store(gp, o0, pre.tag); granule_store(gp + 1, o1, pre.tag); }      // first: a workgroup of this launch waits for them
           if (m == 0) { a.out[i] = o0; a.out[i + 1] = o1; }
           else {        // k: cache row (llama2.ts:239)
             float* kc = a.out_k + (size_t)pos * a.kv_dim;
             kc[i] = o0; kc[i + 1] = o1;
             if (a.aux) { a.aux[i] = o0; a.aux[i + 1] = o1; }
           }
-          if (a.gran) { unsigned long long* gp = a.gran + (m == 0 ? 0 : a.dim) + i; granule_store(gp, o0, pre.tag); granule_store(gp + 1, o1, pre.tag); }
         }
       }
     }
