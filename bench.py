@@ -247,11 +247,48 @@ def cpu_baseline(name, hdr, seed):
     out = {"value": round(1.0 / sec, 4), "unit": "tokens/s", "cores": 1, "kind": "port", "sample": sample, "extrapolated": extrapolated,
            "host_cpu": host_cpu_model()}
     out.update(reference_js_figure(name))
+    out["js_port"] = js_port_baseline(name, hdr, seed)
     if out.get("reference_js_tok_s"):
         out["port_vs_reference_js"] = round(out["value"] / out["reference_js_tok_s"], 2)
         out["note"] = ("the C port on this box's host core runs %.1fx the reference's own runtime (Node, build container): GPU / reference-runtime "
                        "ratios are that much larger than GPU / port ratios" % out["port_vs_reference_js"])
     return out
+
+
+def js_port_baseline(name, hdr, seed):
+    """The reference's arithmetic in the reference's RUNTIME on this box: oracle/llama2_oracle.mjs (a JavaScript restatement of
+    llama2.ts:168-303, bit-identical to the real reference on every golden fixture: tests/test_oracle_golden.py) under this box's
+    Node, one thread like the reference, on the same synthetic checkpoint (written to /tmp by the C generator), tok/s as the
+    reference counts them (llama2.ts:507, 511: the clock starts after the first token).  Bounded to ~10 s of JS time; checkpoints
+    beyond 2 GB are skipped (a 27 GB file would have to be written and read back: minutes)."""
+    node = shutil.which("node")
+    if not node:
+        return {"value": None, "why": "no node on this box"}
+    if configs.checkpoint_bytes(hdr) > (2 << 30):
+        return {"value": None, "why": "checkpoint of %.0f GB: writing and reading it back would take minutes (reference_js_tok_s quotes the build container's run)"
+                % (configs.checkpoint_bytes(hdr) / 2.0 ** 30)}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    ref = reference_js_figure(name).get("reference_js_tok_s") or 5.0
+    steps = int(max(8, min(hdr[6], 10.0 * ref)))
+    path = os.path.join(tempfile.gettempdir(), "l2_js_%s_%d_%d.bin" % (name, seed, os.getpid()))
+    try:
+        O.synth_write(hdr, seed, path)
+        r = subprocess.run([node, os.path.join(ROOT, "oracle", "llama2_oracle.mjs"), path, str(steps)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if r.returncode != 0:
+            return {"value": None, "why": "node failed: %s" % r.stderr.decode("utf8", "replace")[-200:]}
+        j = json.loads(r.stdout.decode())
+        gold = golden_argmax(name, seed)
+        return {"value": round(j["tok_s"], 4), "unit": "tokens/s", "cores": 1, "kind": "port", "runtime": "node %s on this box" % j.get("node"),
+                "sample": "oracle/llama2_oracle.mjs, %d greedy tokens from BOS on the full %s shape" % (steps, name),
+                "tokens_equal_reference_golden": (None if gold is None else j["tokens"] == gold[:steps])}
+    except Exception as e:   # noqa: BLE001 -- a baseline that cannot be taken must not fail the benchmark
+        return {"value": None, "why": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
 
 
 def host_cpu_model():

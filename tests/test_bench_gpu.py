@@ -29,6 +29,10 @@ def test_bench_json_contract():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    import shutil
+    if shutil.which("node"):      # the reference's arithmetic in the reference's runtime, on this box (oracle/llama2_oracle.mjs)
+        jp = cb["js_port"]
+        assert jp["value"] > 0 and jp["cores"] == 1 and jp["tokens_equal_reference_golden"] is True and "node" in jp["runtime"]
     assert abs(j["value"] - 1e3 / j["ms_per_step"]) / j["value"] < 0.01
     # the run that was TIMED is checked against the real reference's tokens (tests/golden/stories15M.json), and so is the drop-in loop
     pr = j["parity"]

@@ -14,6 +14,7 @@ import pytest
 import oracle_lib as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
@@ -134,3 +135,22 @@ def test_rng_known_answers():
     r2, r3 = O.Rng(7), O.Rng(7)
     u = r2.u32()
     assert r3.f32() == np.float32((u / 256) / 16777216.0)
+
+
+@pytest.mark.parametrize("name,steps", [("tiny", 64), ("ragged", 33), ("stories15M", 24)])
+def test_js_restatement_is_bit_identical_to_the_reference(name, steps, tmp_path):
+    """oracle/llama2_oracle.mjs -- the forward pass restated for a JavaScript engine, timed by bench.py's cpu_baseline leg on the GPU
+    box's host (the reference's own source is not there) -- under this box's Node on the fixture's synthetic checkpoint: the sha256 of
+    the logits of EVERY step and every greedy token must be what the REAL reference produced (tests/golden/*.json)."""
+    import shutil
+    import subprocess
+    if shutil.which("node") is None:
+        pytest.skip("no node")
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    ck = str(tmp_path / "m.bin")
+    O.synth_write(meta["header"], meta["seed"], ck)
+    r = subprocess.run(["node", os.path.join(ROOT, "oracle", "llama2_oracle.mjs"), ck, str(steps), "--sha"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    j = json.loads(r.stdout.decode())
+    assert j["steps"] == steps and j["sha256"] == meta["logits_sha256"][:steps]
+    assert j["tokens"] == meta["argmax"][:steps]
