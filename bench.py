@@ -248,10 +248,13 @@ def cpu_baseline(name, hdr, seed):
            "host_cpu": host_cpu_model()}
     out.update(reference_js_figure(name))
     out["js_port"] = js_port_baseline(name, hdr, seed)
-    if out.get("reference_js_tok_s"):
+    if (out["js_port"] or {}).get("value"):
+        out["note"] = ("same box, one core each: the C port %.2f tok/s, the reference's arithmetic under this box's own Node (js_port) %.2f tok/s; "
+                       "reference_js_tok_s is the reference ITSELF, but on the build container's slower CPU" % (out["value"], out["js_port"]["value"]))
+    elif out.get("reference_js_tok_s"):
         out["port_vs_reference_js"] = round(out["value"] / out["reference_js_tok_s"], 2)
-        out["note"] = ("the C port on this box's host core runs %.1fx the reference's own runtime (Node, build container): GPU / reference-runtime "
-                       "ratios are that much larger than GPU / port ratios" % out["port_vs_reference_js"])
+        out["note"] = ("the C port on this box's host core runs %.1fx what the reference itself did under Node in the build container (a slower CPU): "
+                       "no JS figure from this box for this shape (js_port.why)" % out["port_vs_reference_js"])
     return out
 
 
