@@ -491,6 +491,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if under_profiler():
+        # rocprofv3 (ROCm 7.2) segfaults once a process has replayed a hipGraph more than ~128 times with kernel tracing on
+        # (profiles/README.md): under a profiler the library launches the same kernels eagerly -- per-kernel durations carry over,
+        # the tokens/s of such a run is host-bound and says nothing
+        os.environ.setdefault("L2_USE_GRAPH", "0")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -714,6 +719,8 @@ def main():
                      "devices": [r["device"] for r in ranks], "step": ctx.tp_mode(), "proved_before_timing": tp_proof}
     if shards:
         out["tp_predicted"] = committed_prediction(args.config, world)
+    if under_profiler() and os.environ.get("L2_USE_GRAPH") == "0":
+        out["profiled"] = "this run was started under a profiler: eager launches instead of one hipGraph replay per token (host-bound; read the kernel durations, not `value`)"
     if tp_note:
         out["note"] = tp_note
     if extras:
