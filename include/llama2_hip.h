@@ -72,8 +72,12 @@ enum {
                                  the KV caches are always there */
   L2_OPT_PACKED_MIB = 4,      /* read-only (l2_get_option): MiB of device memory held by the repacked copies of the matrices the
                                  streaming kernels read; 0 before the first step and for models that need none */
-  L2_OPT_WEIGHT_MIB = 5       /* read-only: MiB of device memory held by ALL weights right now (row-major tensors + repacked copies).  After
+  L2_OPT_WEIGHT_MIB = 5,      /* read-only: MiB of device memory held by ALL weights right now (row-major tensors + repacked copies).  After
                                  the first step a repacked matrix exists once: its row-major tensor has been given back */
+  L2_OPT_SAMPLED_TOKENS = 6,  /* read-only: tokens l2_decode_sample has picked on this context with temperature != 0 (saturates at INT_MAX) */
+  L2_OPT_SAMPLED_SERIAL = 7   /* read-only: of those, the tokens whose running sums came within the proven margin of the threshold and were
+                                 therefore picked by the reference's loop run as written (csrc/sampler_margin.hip.h); the others by the
+                                 margin rule */
 };
 
 typedef struct l2_ctx l2_ctx;

@@ -904,7 +904,8 @@ extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
       return L2_OK;
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
     case L2_OPT_KEEP_STATE: if (c->opt_keep_state != !!value) { c->opt_keep_state = !!value; destroy_graphs(c); } return L2_OK;
-    case L2_OPT_PACKED_MIB: case L2_OPT_WEIGHT_MIB: return fail(L2_E_ARG, "option %d is read-only", key);
+    case L2_OPT_PACKED_MIB: case L2_OPT_WEIGHT_MIB: case L2_OPT_SAMPLED_TOKENS: case L2_OPT_SAMPLED_SERIAL:
+      return fail(L2_E_ARG, "option %d is read-only", key);
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
 }
@@ -926,6 +927,13 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
       for (int k = 0; k < L2_T_COUNT; ++k) if (c->w[k] && !(k == L2_T_WCLS && c->shared)) floats += c->layer_elems[k] * (size_t)c->layers_of[k];
       for (int m = 0; m < 5; ++m) if (c->packed[m].buf) floats += c->packed[m].layer_elems * (size_t)(m == MODE_CLS ? 1 : c->L);
       *value = (int)(floats * sizeof(float) >> 20);
+      return L2_OK;
+    }
+    case L2_OPT_SAMPLED_TOKENS: case L2_OPT_SAMPLED_SERIAL: {
+      unsigned long long st[2] = {0, 0};
+      if (c->samp.V) { HIPCHK(hipSetDevice(c->device)); HIPCHK(l2s::read_stats(c->samp, st, c->stream)); }
+      const unsigned long long v = st[key == L2_OPT_SAMPLED_SERIAL ? 1 : 0];
+      *value = v > 0x7fffffffull ? 0x7fffffff : (int)v;
       return L2_OK;
     }
     default: return fail(L2_E_ARG, "unknown option %d", key);

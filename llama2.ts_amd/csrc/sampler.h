@@ -33,6 +33,13 @@ struct Sampler {
   unsigned long long* cq = nullptr;   // (G * 1024) per element: grid composite since the start of its run
   int* cm = nullptr;
   unsigned* mxkey = nullptr;     // max of the scaled logits (order-preserving key), zero between tokens
+  // margin form (sampler_margin.hip.h): tile sums of the probabilities, float spacings of the ambiguous quotients, arrivals, counters
+  double* part2 = nullptr;       // (G)
+  double* amb = nullptr;         // (G)
+  unsigned* ticket = nullptr;    // zero between tokens
+  unsigned long long* stats = nullptr;   // {tokens picked, of those by the serial loop}
+  bool chain = false;            // L2_SAMPLER_CHAIN=1: every running sum exact on the whole chip (round 2-3 default), kept for A/B
+  bool force_serial = false;     // L2_SAMPLER_FORCE_SERIAL=1: the margin form treats every token as undecided
   int rank_tg = 0;               // sorted tiles the rank merge holds in LDS at a time
   bool serial = false;           // L2_SAMPLER_SERIAL=1: one lane accumulates (the straightforward form, kept for A/B)
 };
@@ -48,6 +55,9 @@ void destroy(Sampler* s);
 // argmax keys the classifier folded max(logits) into (one per 128-byte line); usable only for temperature > 0, saves
 // the sampler's own maximum pass; the sampler zeroes them for the next token.
 hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, unsigned long long* amax, hipStream_t st);
+
+// {tokens the margin form picked, of those by its serial loop} since create(); synchronous.
+hipError_t read_stats(const Sampler& s, unsigned long long out[2], hipStream_t st);
 
 // Diagnostic: running sums S_i = fl(S_{i-1} + x_i) of n <= MAX_VOCAB non-negative fp32 values, by the exact parallel
 // algorithm (synchronous).

@@ -53,6 +53,7 @@ __device__ __forceinline__ void advance(int* tokpos, int* tokens_out, int next) 
 #include "sampler_serial.hip.h"
 #include "sampler_chain.hip.h"
 #include "sampler_sort.hip.h"
+#include "sampler_margin.hip.h"
 
 // Stage 1 = the exps (recs / cnt), stage 2 = the probabilities, in index or in sorted order (recs2 / cnt2, cq / cm): two
 // sets of run records because the fused kernels write stage 2 while other workgroups still read stage 1.
@@ -88,6 +89,12 @@ hipError_t running_sums(const float* x_dev, int n, double* prefix_dev, hipStream
   return e;
 }
 
+hipError_t read_stats(const Sampler& s, unsigned long long out[2], hipStream_t st) {
+  if (!s.stats) return hipErrorInvalidValue;
+  hipError_t e = hipMemcpyAsync(out, s.stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+  return e == hipSuccess ? hipStreamSynchronize(st) : e;
+}
+
 hipError_t create(Sampler* s, int V) {
   if (V <= 0 || V > MAX_VOCAB) return hipErrorInvalidValue;
   s->V = V;
@@ -118,7 +125,17 @@ hipError_t create(Sampler* s, int V) {
   L2S(hipMalloc(&s->cm, padded * sizeof(int)));
   L2S(hipMalloc(&s->mxkey, sizeof(unsigned)));
   L2S(hipMemset(s->mxkey, 0, sizeof(unsigned)));
-  { const char* g_ = getenv("L2_TEST_HOOKS"); const char* e_ = getenv("L2_SAMPLER_SERIAL"); s->serial = g_ && atoi(g_) != 0 && e_ && atoi(e_) != 0; }   // A/B form, development gate
+  L2S(hipMalloc(&s->part2, (size_t)s->G * sizeof(double)));
+  L2S(hipMalloc(&s->amb, (size_t)s->G * sizeof(double)));
+  L2S(hipMalloc(&s->ticket, sizeof(unsigned)));
+  L2S(hipMemset(s->ticket, 0, sizeof(unsigned)));
+  L2S(hipMalloc(&s->stats, 2 * sizeof(unsigned long long)));
+  L2S(hipMemset(s->stats, 0, 2 * sizeof(unsigned long long)));
+  {                                                            // A/B forms, development gate
+    const char* g_ = getenv("L2_TEST_HOOKS");
+    auto hook = [&](const char* name) { const char* e_ = getenv(name); return g_ && atoi(g_) != 0 && e_ && atoi(e_) != 0; };
+    s->serial = hook("L2_SAMPLER_SERIAL"); s->chain = hook("L2_SAMPLER_CHAIN"); s->force_serial = hook("L2_SAMPLER_FORCE_SERIAL");
+  }
   // the rank merge holds up to RANK_TG sorted tiles in LDS at a time
   s->rank_tg = (int)((padded / STILE) < (size_t)RANK_TG ? (padded / STILE) : (size_t)RANK_TG);
   L2S(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RANK_TG * STILE * 4 + (MAX_VOCAB / TILE) * 8));
@@ -128,7 +145,8 @@ hipError_t create(Sampler* s, int V) {
 
 void destroy(Sampler* s) {
   void* bufs[] = {s->probs, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->part, s->part_sorted,
-                  s->recs, s->recs2, s->cnt, s->cnt2, s->off, s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->mxkey};
+                  s->recs, s->recs2, s->cnt, s->cnt2, s->off, s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->mxkey,
+                  s->part2, s->amb, s->ticket, s->stats};
   for (void* b : bufs) if (b) (void)hipFree(b);
   *s = Sampler();
 }
@@ -160,6 +178,21 @@ hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* t
   // temperature + exp (:481-483, :183-188), runs of the exps' running sum
   if (!amax) hipLaunchKernelGGL(scaled_max_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey);
   hipLaunchKernelGGL(exp_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey, amax, s.probs, s.part);
+  if (!s.chain) {
+    MarginArgs m = {};
+    m.exps = s.probs; m.part = s.part; m.V = s.V; m.G = s.G; m.part2 = s.part2; m.amb = s.amb; m.ticket = s.ticket;
+    m.sorted = s.probs_sorted; m.ids = s.idx_sorted; m.part_sorted = s.part_sorted; m.params = s.params; m.rng = s.rng;
+    m.tokpos = tokpos; m.tokens_out = tokens_out; m.mxkey = s.mxkey; m.amax = amax; m.stats = s.stats; m.force_serial = s.force_serial ? 1 : 0;
+    if (!topp_mode) {
+      hipLaunchKernelGGL(sample_margin_kernel, dim3(s.G), dim3(TN), 0, st, m);
+      return hipGetLastError();
+    }
+    // the descending order needs the exact probabilities: runs of the exps, [exact total -> probabilities -> sorted tiles], rank merge
+    hipLaunchKernelGGL(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
+    if ((e = sort_descending(s, s.probs, chain_args(s, s.probs, s.part, false), true, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(topp_margin_kernel, dim3(1), dim3(TN), 0, st, m);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
   const ChainArgs exps = chain_args(s, s.probs, s.part, false);
   ChainArgs pick;

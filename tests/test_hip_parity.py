@@ -643,16 +643,45 @@ def test_exact_parallel_running_sums_equal_the_serial_loop():
         assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (n, int(np.argmax(got != want)))
 
 
-def test_sampler_serial_and_parallel_forms_agree(monkeypatch):
+def test_sampler_forms_agree(monkeypatch):
+    """The device sampler's forms give the same tokens and RNG state: the default (tree sums + the proven margin, csrc/sampler_margin.hip.h),
+    the same with every token declared undecided (the reference's loop run as written by one lane: the branch a token takes when a running sum
+    comes within the margin of its threshold), every running sum exact on the whole chip (the round-2/3 default) and the one-workgroup serial
+    form.  The counters say which branch picked: none by the serial loop in the default form here, all of them when forced."""
     hdr = configs.header("stories15M")
+    settings = ((0.9, 1.0), (1.3, 0.8), (1e6, 0.5), (0.2, 0.999), (-0.8, 1.0))
     runs = {}
-    for serial in ("0", "1"):
-        monkeypatch.setenv("L2_SAMPLER_SERIAL", serial)
+    for form, env in (("margin", {}), ("forced", {"L2_SAMPLER_FORCE_SERIAL": "1"}), ("chain", {"L2_SAMPLER_CHAIN": "1"}), ("serial", {"L2_SAMPLER_SERIAL": "1"})):
+        for k in ("L2_SAMPLER_FORCE_SERIAL", "L2_SAMPLER_CHAIN", "L2_SAMPLER_SERIAL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         ctx = runtime.Context(hdr)
         ctx.synth_fill(1)
-        runs[serial] = [ctx.decode_sample(1, 0, 24, t, p, 9)[0].tolist() for t, p in ((0.9, 1.0), (1.3, 0.8))]
+        runs[form] = [tuple(x.tolist() if hasattr(x, "tolist") else x for x in ctx.decode_sample(1, 0, 24, t, p, 9)) for t, p in settings]
+        picked, by_loop = ctx.get_option(runtime.OPT_SAMPLED_TOKENS), ctx.get_option(runtime.OPT_SAMPLED_SERIAL)
+        if form == "margin":
+            assert picked == 24 * len(settings) and by_loop == 0
+        if form == "forced":
+            assert picked == 24 * len(settings) and by_loop == picked
         ctx.close()
-    assert runs["0"] == runs["1"]
+    assert runs["margin"] == runs["forced"] == runs["chain"] == runs["serial"]
+
+
+@pytest.mark.parametrize("form", ["L2_SAMPLER_FORCE_SERIAL", "L2_SAMPLER_CHAIN"])
+def test_device_sampler_other_forms_reproduce_the_reference_run(monkeypatch, form):
+    """The reference's own -t / -p runs (fixtures cli_temp, cli_topp) through the margin form's serial branch and through the exact chain."""
+    monkeypatch.setenv(form, "1")
+    for name, n_prompt in (("cli_temp", 0), ("cli_topp", 4)):
+        meta, temperature, topp, seed = _sampled_run(name)
+        fed = meta["tokens_fed"]
+        ctx = runtime.Context(meta["header"])
+        ctx.synth_fill(meta["seed"])
+        for pos in range(n_prompt):
+            ctx.forward(fed[pos], pos)
+        toks, _ = ctx.decode_sample(fed[n_prompt], n_prompt, len(fed) - 1 - n_prompt, temperature, topp, seed)
+        assert toks.tolist() == fed[n_prompt + 1:], (form, name)
+        ctx.close()
 
 
 @pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_ATTN_NW": "4"}), ("stories110M", {"L2_ATTN_NW": "8"}), ("stories15M", {"L2_ATTN_NW": "8"}),
