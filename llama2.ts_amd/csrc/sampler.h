@@ -40,7 +40,7 @@ struct Sampler {
   unsigned long long* stats = nullptr;   // {tokens picked, of those by the serial loop}
   bool chain = false;            // L2_SAMPLER_CHAIN=1: every running sum exact on the whole chip (round 2-3 default), kept for A/B
   bool force_serial = false;     // L2_SAMPLER_FORCE_SERIAL=1: the margin form treats every token as undecided
-  int rank_tg = 0;               // sorted tiles the rank merge holds in LDS at a time
+  unsigned* rank_acc = nullptr;  // (G * 1024) the rank merge's per-element accumulators {groups reported : 8, elements in front : 24}, zero between tokens
   bool serial = false;           // L2_SAMPLER_SERIAL=1: one lane accumulates (the straightforward form, kept for A/B)
 };
 

@@ -136,9 +136,8 @@ hipError_t create(Sampler* s, int V) {
     auto hook = [&](const char* name) { const char* e_ = getenv(name); return g_ && atoi(g_) != 0 && e_ && atoi(e_) != 0; };
     s->serial = hook("L2_SAMPLER_SERIAL"); s->chain = hook("L2_SAMPLER_CHAIN"); s->force_serial = hook("L2_SAMPLER_FORCE_SERIAL");
   }
-  // the rank merge holds up to RANK_TG sorted tiles in LDS at a time
-  s->rank_tg = (int)((padded / STILE) < (size_t)RANK_TG ? (padded / STILE) : (size_t)RANK_TG);
-  L2S(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RANK_TG * STILE * 4 + (MAX_VOCAB / TILE) * 8));
+  L2S(hipMalloc(&s->rank_acc, padded * sizeof(unsigned)));       // the rank merge's per-element accumulators: zero between tokens
+  L2S(hipMemset(s->rank_acc, 0, padded * sizeof(unsigned)));
 #undef L2S
   return hipSuccess;
 }
@@ -146,7 +145,7 @@ hipError_t create(Sampler* s, int V) {
 void destroy(Sampler* s) {
   void* bufs[] = {s->probs, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->part, s->part_sorted,
                   s->recs, s->recs2, s->cnt, s->cnt2, s->off, s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->mxkey,
-                  s->part2, s->amb, s->ticket, s->stats};
+                  s->part2, s->amb, s->ticket, s->stats, s->rank_acc};
   for (void* b : bufs) if (b) (void)hipFree(b);
   *s = Sampler();
 }
@@ -157,7 +156,7 @@ static hipError_t sort_descending(const Sampler& s, const float* values, const C
   const int gs = (s.V + STILE - 1) / STILE, n = gs * STILE;
   if (fused) hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
   else hipLaunchKernelGGL(sort_tile_kernel<false>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
-  hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT), dim3(RT), (size_t)s.rank_tg * STILE * 4 + s.G * sizeof(double), st, s.run_p, s.idx, gs, s.G, s.rank_tg,
+  hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT, (gs + RANK_TQ - 1) / RANK_TQ), dim3(RT), 0, st, s.run_p, s.idx, gs, s.G, s.rank_acc,
                      s.probs_sorted, s.idx_sorted, s.part_sorted);
   return hipGetLastError();
 }

@@ -69,60 +69,60 @@ __global__ void __launch_bounds__(TN) sort_tile_kernel(ChainArgs a, const float*
   }
 }
 
-// Every element's place in the merged order: its place in its own tile + the number of elements of every other tile
-// in front of it (ties: the tile with the smaller ids first), by binary search in the G sorted tiles held in LDS.
-constexpr int RT = 512;                                           // threads = elements per workgroup of the rank merge (256 and 1024: the same time)
-constexpr int RANK_TG = 38;                                       // sorted tiles a workgroup holds in LDS at a time (152 KB of the 160)
+// Every element's place in the merged order: its place in its own tile + the number of elements of every other tile in front of it
+// (ties: the tile with the smaller ids first), by binary search in sorted tiles held in LDS.  The searches are what the kernel costs
+// (measured at 32 tiles on 64 workgroups: 4 us filling LDS, 8 us searching), so they are spread over the chip: workgroup (x, y) ranks
+// RT consecutive elements against the RANK_TQ tiles of group y only and adds its count to acc[element]; the top byte of acc counts the
+// groups that have reported, and the thread whose add completes an element knows its rank, stores it and puts acc back to zero.
+constexpr int RT = 512;                                           // threads = elements per workgroup of the rank merge
+constexpr int RANK_TQ = 8;                                        // sorted tiles a workgroup searches (32 KB of LDS)
 // Also adds every element to the sum of the tile of the merged order it lands in (part[], zero on entry): the approximate
-// prefix of the next stage.  fp64 atomics in no fixed order -- the prefix only has to be approximate (exact_sum.h).
-// Vocabularies of more than TG tiles (38 912 entries) go through LDS in groups of TG tiles, the ranks adding up over the groups.
-__global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const int* run_id, int GS, int G, int TG, float* sorted, int* ids, double* part) {
-  extern __shared__ int lds_p[];                                // TG * STILE probability bit patterns (pads: negative), then G tile sums
+// prefix of the next stage.  fp64 atomics in no fixed order -- the prefix only has to be approximate.
+__global__ void __launch_bounds__(RT) sort_rank_kernel(const float* run_p, const int* run_id, int GS, int G, unsigned* acc, float* sorted, int* ids, double* part) {
+  __shared__ int lds_p[RANK_TQ * STILE];                        // probability bit patterns of the group's tiles (pads: negative)
+  __shared__ double lpart[MAX_VOCAB / TILE];
   const int tid = threadIdx.x, n = GS * STILE;
-  double* lpart = reinterpret_cast<double*>(lds_p + TG * STILE);
   for (int j = tid; j < G; j += RT) lpart[j] = 0.0;
   const int e = blockIdx.x * RT + tid;
-  const int my_id = e < n ? run_id[e] : -1;
   const int mine = e < n ? reinterpret_cast<const int*>(run_p)[e] : -1;
   const int own = e / STILE;
-  int rank = e - own * STILE;
-  for (int g0 = 0; g0 < GS; g0 += TG) {
-    const int gt = min(TG, GS - g0), gn = gt * STILE;           // tiles g0 .. g0 + gt - 1 in LDS
-    if (g0) __syncthreads();
-    // every workgroup pulls all the tiles; measured: one 16-byte load in flight per thread (8 KB per workgroup) beats 4, 8 and 16
-    // (+5 / +5 / +8 us) -- the same lines are wanted by every CU at once and deeper queues only lengthen the wait behind them;
-    // an LDS-DMA fill (global_load_lds_dwordx4, every 1 KB chunk in flight at once) takes the same time as this loop
-    for (int j = tid * 4; j < gn; j += RT * 4) *reinterpret_cast<int4*>(lds_p + j) = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(run_p) + (size_t)g0 * STILE + j);
-    __syncthreads();
-    if (mine >= 0) {                                            // not a pad
-      constexpr int U = 8;                                      // searches in flight per thread
-      for (int b0 = 0; b0 < gt; b0 += U) {
-        int lo[U], thr[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int b = min(b0 + u, gt - 1);
-          lo[u] = b * STILE;
-          thr[u] = mine - (g0 + b < own ? 1 : 0);               // earlier tile: elements >= mine come first; later tile: only > mine
-        }
-#pragma unroll
-        for (int s = STILE / 2; s > 0; s >>= 1) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) if (lds_p[lo[u] + s - 1] > thr[u]) lo[u] += s;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int b = min(b0 + u, gt - 1);
-          int cnt = lo[u] - b * STILE;
-          if (cnt == STILE - 1 && lds_p[lo[u]] > thr[u]) cnt = STILE;
-          if (b0 + u < gt && g0 + b != own) rank += cnt;
-        }
-      }
-    }
+  const int g0 = blockIdx.y * RANK_TQ, gt = min(RANK_TQ, GS - g0), gn = gt * STILE, groups = gridDim.y;
+  {
+    // one 16-byte load in flight per thread (deeper queues measured slower), every workgroup starting at another tile
+    const int* src = reinterpret_cast<const int*>(run_p) + (size_t)g0 * STILE;
+    const int rot = (int)(blockIdx.x % (unsigned)gt) * STILE;
+    for (int j = tid * 4; j < gn; j += RT * 4) { int jj = j + rot; if (jj >= gn) jj -= gn; *reinterpret_cast<int4*>(lds_p + jj) = *reinterpret_cast<const int4*>(src + jj); }
   }
-  if (mine >= 0) {
-    sorted[rank] = __int_as_float(mine);
-    ids[rank] = my_id;
-    atomicAdd(lpart + rank / TILE, (double)__int_as_float(mine));
+  __syncthreads();
+  if (mine >= 0) {                                              // not a pad
+    int lo[RANK_TQ], thr[RANK_TQ];
+#pragma unroll
+    for (int u = 0; u < RANK_TQ; ++u) {
+      const int b = min(u, gt - 1);
+      lo[u] = b * STILE;
+      thr[u] = mine - (g0 + b < own ? 1 : 0);                   // earlier tile: elements >= mine come first; later tile: only > mine
+    }
+#pragma unroll
+    for (int s = STILE / 2; s > 0; s >>= 1) {
+#pragma unroll
+      for (int u = 0; u < RANK_TQ; ++u) if (lds_p[lo[u] + s - 1] > thr[u]) lo[u] += s;
+    }
+    unsigned count = (own >= g0 && own < g0 + gt) ? (unsigned)(e - own * STILE) : 0u;   // its place in its own tile, counted once
+#pragma unroll
+    for (int u = 0; u < RANK_TQ; ++u) {
+      const int b = min(u, gt - 1);
+      int cnt = lo[u] - b * STILE;
+      if (cnt == STILE - 1 && lds_p[lo[u]] > thr[u]) cnt = STILE;
+      if (u < gt && g0 + b != own) count += (unsigned)cnt;
+    }
+    const unsigned before = groups > 1 ? atomicAdd(acc + e, count + (1u << 24)) : 0u;
+    if ((int)(before >> 24) == groups - 1) {                     // every other group has reported: the rank is complete
+      const int rank = (int)((before & 0xffffffu) + count);
+      if (groups > 1) __hip_atomic_store(acc + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past the L2, like the adds
+      sorted[rank] = __int_as_float(mine);
+      ids[rank] = run_id[e];
+      atomicAdd(lpart + rank / TILE, (double)__int_as_float(mine));
+    }
   }
   __syncthreads();
   for (int j = tid; j < G; j += RT) if (lpart[j] != 0.0) atomicAdd(part + j, lpart[j]);

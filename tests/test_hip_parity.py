@@ -569,9 +569,9 @@ def test_device_sampler_matches_oracle_on_other_settings():
         ctx.close(); ref.close()
 
 
-@pytest.mark.parametrize("hdr,why", [((64, 176, 1, 4, 4, 50257, 16), "more sorted tiles than the rank merge holds in LDS at once: two groups"),
-                                     ((64, 176, 1, 4, 4, 128256, 16), "four groups of sorted tiles (a Llama-3 vocabulary)"),
-                                     ((64, 176, 1, 4, 4, 38912, 16), "exactly one full group"),
+@pytest.mark.parametrize("hdr,why", [((64, 176, 1, 4, 4, 50257, 16), "50 sorted tiles: seven groups of the rank merge, the last one ragged"),
+                                     ((64, 176, 1, 4, 4, 128256, 16), "126 sorted tiles in 16 groups (a Llama-3 vocabulary)"),
+                                     ((64, 176, 1, 4, 4, 38912, 16), "38 sorted tiles"),
                                      ((64, 176, 1, 4, 4, 1000, 16), "one ragged tile"),
                                      ((64, 176, 1, 4, 4, 5121, 16), "last tile holds one element")])
 def test_device_sampler_other_vocabularies(hdr, why):
