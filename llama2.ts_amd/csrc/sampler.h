@@ -37,6 +37,7 @@ struct Sampler {
   double* part2 = nullptr;       // (G)
   double* amb = nullptr;         // (G)
   unsigned* ticket = nullptr;    // zero between tokens
+  double* total = nullptr;       // top-p: the exact total of the exps (runs_total_kernel -> the tile sort)
   unsigned long long* stats = nullptr;   // {tokens picked, of those by the serial loop}
   bool chain = false;            // L2_SAMPLER_CHAIN=1: every running sum exact on the whole chip (round 2-3 default), kept for A/B
   bool force_serial = false;     // L2_SAMPLER_FORCE_SERIAL=1: the margin form treats every token as undecided

@@ -129,6 +129,7 @@ hipError_t create(Sampler* s, int V) {
   L2S(hipMalloc(&s->amb, (size_t)s->G * sizeof(double)));
   L2S(hipMalloc(&s->ticket, sizeof(unsigned)));
   L2S(hipMemset(s->ticket, 0, sizeof(unsigned)));
+  L2S(hipMalloc(&s->total, sizeof(double)));
   L2S(hipMalloc(&s->stats, 2 * sizeof(unsigned long long)));
   L2S(hipMemset(s->stats, 0, 2 * sizeof(unsigned long long)));
   {                                                            // A/B forms, development gate
@@ -145,20 +146,25 @@ hipError_t create(Sampler* s, int V) {
 void destroy(Sampler* s) {
   void* bufs[] = {s->probs, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->part, s->part_sorted,
                   s->recs, s->recs2, s->cnt, s->cnt2, s->off, s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->mxkey,
-                  s->part2, s->amb, s->ticket, s->stats, s->rank_acc};
+                  s->part2, s->amb, s->ticket, s->stats, s->rank_acc, s->total};
   for (void* b : bufs) if (b) (void)hipFree(b);
   *s = Sampler();
 }
 
 // Descending stable order of V values (probabilities, or exps still to be divided by their exact total when `fused`): sorted tiles, then the
 // rank merge writes probs_sorted / idx_sorted and adds every value to the sum of the 1024-element tile it lands in (part_sorted).
-static hipError_t sort_descending(const Sampler& s, const float* values, const ChainArgs& exps, bool fused, hipStream_t st) {
-  const int gs = (s.V + STILE - 1) / STILE, n = gs * STILE;
-  if (fused) hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
-  else hipLaunchKernelGGL(sort_tile_kernel<false>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
+static hipError_t rank_merge(const Sampler& s, int gs, hipStream_t st) {
+  const int n = gs * STILE;
   hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT, (gs + RANK_TQ - 1) / RANK_TQ), dim3(RT), 0, st, s.run_p, s.idx, gs, s.G, s.rank_acc,
                      s.probs_sorted, s.idx_sorted, s.part_sorted);
   return hipGetLastError();
+}
+
+static hipError_t sort_descending(const Sampler& s, const float* values, const ChainArgs& exps, bool fused, hipStream_t st) {
+  const int gs = (s.V + STILE - 1) / STILE;
+  if (fused) hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
+  else hipLaunchKernelGGL(sort_tile_kernel<false>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
+  return rank_merge(s, gs, st);
 }
 
 hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* tokpos, int* tokens_out, unsigned long long* amax, hipStream_t st) {
@@ -187,8 +193,10 @@ hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* t
       return hipGetLastError();
     }
     // the descending order needs the exact probabilities: runs of the exps, [exact total -> probabilities -> sorted tiles], rank merge
-    hipLaunchKernelGGL(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
-    if ((e = sort_descending(s, s.probs, chain_args(s, s.probs, s.part, false), true, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(runs_total_kernel, dim3(s.G), dim3(TN), 0, st, chain_args(s, s.probs, s.part, false), (Run*)s.recs, s.cnt, s.ticket, s.total);
+    const int gs = (s.V + STILE - 1) / STILE;
+    hipLaunchKernelGGL(sort_tile_wide_kernel, dim3(gs), dim3(WT), 0, st, s.probs, s.total, s.V, s.run_p, s.idx);
+    if ((e = rank_merge(s, gs, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(topp_margin_kernel, dim3(1), dim3(TN), 0, st, m);
     return hipGetLastError();
   }

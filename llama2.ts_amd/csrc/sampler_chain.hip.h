@@ -217,7 +217,29 @@ __global__ void __launch_bounds__(TN) tile_sums_kernel(const float* x, int V, do
 // exact sum in front of a run into the exact running sum at any element of it.
 __device__ __forceinline__ int pack_meta(const Seg& s, bool serial) { return (s.meta & 3) | (serial ? 4 : 0) | (s.meta & (int)0xffff0000); }
 
-template <bool COMP>
+// A run record / a count as three / one write-through store(s) and L1-bypassing loads: what a workgroup of the SAME launch may read once the
+// writers have drained their stores and taken a ticket (MI355X_MICROARCH.md, hand-off forms; Run is three 8-byte words).
+static_assert(sizeof(Run) == 24, "a run record is three 8-byte words");
+__device__ __forceinline__ void run_store_through(Run* dst, const Run& r) {
+  unsigned long long w[3];
+  memcpy(w, &r, 24);
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) __hip_atomic_store(d + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool THROUGH>
+__device__ __forceinline__ Run run_load(const Run* src) {
+  if (!THROUGH) return *src;
+  unsigned long long w[3];
+  const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) w[k] = __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  Run r;
+  memcpy(&r, w, 24);
+  return r;
+}
+
+template <bool COMP, bool THROUGH = false>
 __device__ __forceinline__ void emit_runs(const Elems& el, const float (&v)[IT], int V, int tile, Run* recs, int* cnt, unsigned long long* cq, int* cm) {
   Run* out = recs + (size_t)tile * (TILE + 1);
   const int i0 = tile * TILE + threadIdx.x * IT;
@@ -228,8 +250,10 @@ __device__ __forceinline__ void emit_runs(const Elems& el, const float (&v)[IT],
     const bool tile_end = threadIdx.x == TN - 1 && k == IT - 1;
     if (el.serial[k] || tile_end) {
       Run r; r.q0 = s.q0; r.d = seg_d(s); r.E = seg_E(s); r.x = el.serial[k] ? v[k] : 0.0f; r.end = min(i0 + k, V - 1);
-      out[el.serial[k] ? seg_cnt(s) - 1 : seg_cnt(s)] = r;
-      if (tile_end) cnt[tile] = seg_cnt(s) + (el.serial[k] ? 0 : 1);
+      Run* at = out + (el.serial[k] ? seg_cnt(s) - 1 : seg_cnt(s));
+      const int total_runs = seg_cnt(s) + (el.serial[k] ? 0 : 1);
+      if (THROUGH) { run_store_through(at, r); if (tile_end) __hip_atomic_store(cnt + tile, total_runs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else { *at = r; if (tile_end) cnt[tile] = total_runs; }
     }
   }
 }
@@ -341,7 +365,7 @@ __device__ __forceinline__ int find_first(const ChainArgs& a, ChainShared& sh, c
 enum { CHAIN_SAMPLE = 1, CHAIN_TOPP = 2, CHAIN_DEBUG = 3 };
 
 // Walk the runs in order with the exact fp64 state; leaves the total in sh.val (read it after a barrier).
-template <bool IN_LDS>
+template <bool IN_LDS, bool THROUGH = false>
 __device__ __forceinline__ void chain_walk(const ChainArgs& a, ChainShared& sh, int T) {
   const int tid = threadIdx.x;
   const RunState<IN_LDS> rs{sh, a};
@@ -415,7 +439,7 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, ChainShared& sh, 
     } else {
       int k = 0;
       for (int t = 0; t < a.G; ++t)
-        for (int r = 0, n = sh.off[t + 1] - sh.off[t]; r < n; ++r, ++k) step(k, a.recs[(size_t)t * (TILE + 1) + r]);
+        for (int r = 0, n = sh.off[t + 1] - sh.off[t]; r < n; ++r, ++k) step(k, run_load<THROUGH>(a.recs + (size_t)t * (TILE + 1) + r));
     }
     sh.val = S;
   }
@@ -423,11 +447,12 @@ __device__ __forceinline__ void chain_walk(const ChainArgs& a, ChainShared& sh, 
 
 // Order the tiles' runs (first run of every tile in sh.off, records staged in LDS when they fit) and walk them.
 // Returns the number of runs; *in_lds says where the per-run state went.  Every thread of the workgroup calls it.
+template <bool THROUGH = false>
 __device__ __forceinline__ int chain_total(const ChainArgs& a, ChainShared& sh, bool* in_lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = tid < a.G ? a.cnt[tid] : 0;
+  const int c = tid < a.G ? (THROUGH ? __hip_atomic_load(a.cnt + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.cnt[tid]) : 0;
   Run r0, r1;                                              // nearly every tile has one or two runs: fetched together with the count
-  if (tid < a.G) { r0 = a.recs[(size_t)tid * (TILE + 1)]; r1 = a.recs[(size_t)tid * (TILE + 1) + 1]; }
+  if (tid < a.G) { r0 = run_load<THROUGH>(a.recs + (size_t)tid * (TILE + 1)); r1 = run_load<THROUGH>(a.recs + (size_t)tid * (TILE + 1) + 1); }
   int incl = c;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
@@ -445,12 +470,12 @@ __device__ __forceinline__ int chain_total(const ChainArgs& a, ChainShared& sh, 
     if (tid < a.G) {
       if (c > 0) sh.rec[first] = r0;
       if (c > 1) sh.rec[first + 1] = r1;
-      for (int r = 2; r < c; ++r) sh.rec[first + r] = a.recs[(size_t)tid * (TILE + 1) + r];
+      for (int r = 2; r < c; ++r) sh.rec[first + r] = run_load<THROUGH>(a.recs + (size_t)tid * (TILE + 1) + r);
     }
     __syncthreads();
     chain_walk<true>(a, sh, T);
   } else {
-    chain_walk<false>(a, sh, T);
+    chain_walk<false, THROUGH>(a, sh, T);
   }
   __syncthreads();
   return T;
@@ -501,6 +526,26 @@ __global__ void __launch_bounds__(TN) chain_kernel(ChainArgs a) {
     return;
   }
   if (in_lds) chain_pick<MODE, true>(a, sh, T); else chain_pick<MODE, false>(a, sh, T);
+}
+
+// Runs of the exps and, by the last workgroup to finish, their exact total (the softmax denominator, :189): the records go out as
+// write-through stores, every wave drains them, one lane takes a ticket; the workgroup that gets the last one walks the chain.
+__global__ void __launch_bounds__(TN) runs_total_kernel(ChainArgs a, Run* recs, int* cnt, unsigned* ticket, double* total) {
+  __shared__ ChainShared sh;
+  float v[IT];
+  load_tile(a.x, a.V, blockIdx.x, v);
+  Elems el;
+  tile_scan(v, tile_base(a.part, blockIdx.x), sh.tile, el);
+  emit_runs<false, true>(el, v, a.V, blockIdx.x, recs, cnt, nullptr, nullptr);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sh.slot = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (sh.slot != a.G - 1) return;
+  __syncthreads();
+  bool in_lds;
+  chain_total<true>(a, sh, &in_lds);
+  if (threadIdx.x == 0) { *total = sh.val; *ticket = 0u; }
 }
 
 // The exact softmax denominator, recomputed by every workgroup of the kernel that needs it next (a walk over ~50 runs is

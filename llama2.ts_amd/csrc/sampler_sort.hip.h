@@ -69,6 +69,38 @@ __global__ void __launch_bounds__(TN) sort_tile_kernel(ChainArgs a, const float*
   }
 }
 
+// The same tile sort by 1024 threads with one key each and the exact total handed in (runs_total_kernel): four waves per SIMD hide the
+// lane exchanges one wave per SIMD waits for, and no thread carries four 64-bit keys through 55 stages.
+constexpr int WT = 1024;
+static_assert(WT == STILE, "one key per thread");
+__global__ void __launch_bounds__(WT) sort_tile_wide_kernel(const float* exps, const double* total, int V, float* run_p, int* run_id) {
+  __shared__ u64 xch[STILE];
+  const int tid = threadIdx.x, i = blockIdx.x * STILE + tid;
+  const double s = *total;
+  const float p = (i < V) ? (float)((double)exps[i] / s) : 0.0f;                  // :192
+  u64 v = (i < V) ? (((u64)(0xffffffffu - __float_as_uint(p)) << 32) | (unsigned)i) : ~0ull;
+#pragma unroll
+  for (int k2 = 2; k2 <= STILE; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      const bool keep_min = ((tid & j) == 0) == ((tid & k2) == 0);
+      u64 o;
+      if (j < 64) {
+        o = __shfl_xor(v, j, 64);
+      } else {
+        __syncthreads();
+        xch[tid] = v;
+        __syncthreads();
+        o = xch[tid ^ j];
+      }
+      v = keep_min ? (v < o ? v : o) : (v > o ? v : o);
+    }
+  }
+  const bool pad = v == ~0ull;
+  run_p[i] = pad ? -1.0f : __uint_as_float(0xffffffffu - (unsigned)(v >> 32));
+  run_id[i] = pad ? -1 : (int)(unsigned)v;
+}
+
 // Every element's place in the merged order: its place in its own tile + the number of elements of every other tile in front of it
 // (ties: the tile with the smaller ids first), by binary search in sorted tiles held in LDS.  The searches are what the kernel costs
 // (measured at 32 tiles on 64 workgroups: 4 us filling LDS, 8 us searching), so they are spread over the chip: workgroup (x, y) ranks
