@@ -5,7 +5,14 @@
 // (softmax :189, sample :369/:373, sample_topp :385/:391) and the chosen index depends on comparing a random
 // threshold against those running sums, so a tree sum (different in the last bits) can flip a token.
 //
-// Default form (whole chip; 4 launches per token for sample, 6 for top-p; +31 / +59 us per token at stories110M):
+// Default form (sampler_margin.hip.h; +11 us per token for sample, +39 us for top-p at stories110M): the function returns an INDEX, so the
+// running sums only have to be known well enough to decide every comparison the loop makes.  Tree sums over the whole chip plus a proven
+// margin (margin_rule.h: n 2^-53 per summation order, the float spacing of every probability a tree total could round differently) decide
+// it; a token whose running sum comes within the margin of its threshold (a few in a million) is picked by the reference's loop run as
+// written by one lane of the same workgroup.  Launches: sample 2 (exps + tile sums -> probabilities' tile sums, the last workgroup picks);
+// top-p 5 (exps; runs of the exps + their exact total by the last workgroup; probabilities + tile sort; rank merge; pick) -- the descending
+// order of sample_topp needs the exact probabilities, hence the exact total there.
+// Exact-chain form (L2_SAMPLER_CHAIN=1 behind L2_TEST_HOOKS; the default of rounds 2-3; 4 launches for sample, 6 for top-p; +31 / +59 us):
 //   exp + tile sums (the maximum comes from the classifier's argmax keys) -> runs of the exps
 //   sample:  [exact total -> probabilities -> their runs] -> chain: exact running sums, threshold, search, advance
 //   top-p:   [exact total -> probabilities -> sorted tiles] -> rank merge (+ tile sums) -> runs -> chain
@@ -14,14 +21,15 @@
 // runs on one grid composed by a scan first), every prediction is checked, and the searched index is evaluated inside
 // the one run that contains it.  The bracketed steps share a launch: each of their workgroups repeats the walk for the
 // total instead of waiting for a launch that would hand it over.  Bit-identical to the serial loop by construction
-// (tests/test_exact_sum_cpu.py on the host, l2_debug_running_sums on the GPU).
+// (tests/test_exact_sum_cpu.py on the host, l2_debug_running_sums on the GPU).  The default form keeps its first half for top-p.
 // The descending stable sort of sample_topp (Array.prototype.sort is stable in V8 >= 7.0) is a bitonic sort of
-// (probability, id) keys per tile followed by one rank-by-binary-search merge of the 32 sorted tiles out of LDS.
+// (probability, id) keys per 1024-element tile followed by one rank-by-binary-search merge of the sorted tiles out of LDS.
 //
 // L2_SAMPLER_SERIAL=1 keeps the straightforward form for A/B: ONE lane adds in index order (~10 cycles per element,
 // ~130 us per pass over 32 000 values) inside a single 1024-thread workgroup (top-p: behind the same tile sort + rank merge).
 #include "sampler.h"
 #include "exact_sum.h"
+#include "margin_rule.h"
 
 #include <stdlib.h>
 

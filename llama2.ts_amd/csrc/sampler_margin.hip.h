@@ -22,8 +22,6 @@
 // top-p 5 (exps, runs of the exps, [exact total -> probabilities -> sorted tiles], rank merge, pick) -- the descending order
 // needs the exact probabilities, so its first half stays the exact chain of sampler_chain.hip.h.
 
-constexpr double TWO_M53 = 1.1102230246251565e-16;     // 2^-53
-
 struct MarginArgs {
   const float* exps;             // (V) fp32 exps of the scaled logits (exp_kernel)
   const double* part;            // (G) their tile sums
@@ -51,18 +49,6 @@ struct MarginShared {
   __attribute__((aligned(16))) double buf[CH];      // the serial loop's staging (values widened to fp64 by all threads)
   double bound[MAX_VOCAB / SEG];                    //   and its recorded running sums
 };
-
-// fl32(fl64(e / T)), and into *amb the spacing of floats around it when another total within `win` fp64 steps could round the other way
-__device__ __forceinline__ float quotient_checked(float e, double T, int win, double* amb) {
-  const double q = (double)e / T;
-  if (e != 0.0f) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(q);
-    const int ex = (int)(b >> 52) & 0x7ff, low = (int)(b & 0x1fffffffu);       // the 29 bits a float drops; their midpoint is 2^28
-    if (ex < 1023 - 100) *amb += 0x1p-99;                                       // float subnormals and their neighbourhood: spacing <= 2^-123
-    else if (abs(low - 0x10000000) <= win) *amb += __longlong_as_double((long long)(ex - 22) << 52);   // 2 ^ (binade - 22): the spacing above it
-  }
-  return (float)q;
-}
 
 // inclusive scan of one value per thread over the workgroup; *total = the sum of all of them (the same bits in every thread)
 __device__ __forceinline__ double block_scan(double x, double* wsum, double* total) {
@@ -126,18 +112,19 @@ __device__ __forceinline__ int decide_first(F value, int V, int G, double thr, d
   int mine = 0x7fffffff;
   double q_mine = 0.0, q_before = 0.0;
 #pragma unroll
-  for (int k = IT - 1; k >= 0; --k) if (Q[k] > thr + M) { mine = i0 + k; q_mine = Q[k]; q_before = k ? Q[k - 1] : front; }
+  for (int k = IT - 1; k >= 0; --k) if (mr::known_true(Q[k], thr, M)) { mine = i0 + k; q_mine = Q[k]; q_before = k ? Q[k - 1] : front; }
   const int j = block_first(mine != 0x7fffffff, mine, &sh.slot[1]);       // the first element of the tile known TRUE
   if (tid == 0) sh.slot[2] = -2;
   __syncthreads();
   // j is the loop's first TRUE element when the element in front of it is known FALSE (cum is monotone: so is everything before that)
-  if (mine == j && j < V && (j == 0 || q_before < thr - M)) { sh.slot[2] = j < limit ? j : -1; sh.val[3] = q_mine; }
+  if (mine == j && j < V && (j == 0 || mr::known_false(q_before, thr, M))) { sh.slot[2] = j < limit ? j : -1; sh.val[3] = q_mine; }
   __syncthreads();
   if (sh.slot[2] == -2) {
     // or the loop ends in front of anything TRUE: its last element, limit - 1, is known FALSE
     const int l = limit - 1;
-    if (l >= i0 && l < i0 + IT && Q[l - i0] < thr - M) sh.slot[2] = -1;
-    if (tid == 0 && limit == tt * TILE && base < thr - M) sh.slot[2] = -1;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) if (i0 + k == l && mr::known_false(Q[k], thr, M)) sh.slot[2] = -1;
+    if (tid == 0 && limit == tt * TILE && mr::known_false(base, thr, M)) sh.slot[2] = -1;
   }
   __syncthreads();
   *qhit = sh.val[3];
@@ -214,12 +201,12 @@ __global__ void __launch_bounds__(TN) sample_margin_kernel(const MarginArgs a) {
   __shared__ MarginShared sh;
   const int tid = threadIdx.x, tile = blockIdx.x, n = a.V;
   const double T = tile_base(a.part, a.G);                     // tree total of the exps: the same bits in every lane of every workgroup
-  const int win = 4 * (n + 64) + 8;
+  const int win = mr::window(n);
   float v[IT];
   load_tile(a.exps, n, tile, v);
   double amb = 0.0;
 #pragma unroll
-  for (int k = 0; k < IT; ++k) v[k] = quotient_checked(v[k], T, win, &amb);      // padding: e = 0 -> p = 0
+  for (int k = 0; k < IT; ++k) v[k] = mr::quotient_checked(v[k], T, win, &amb);      // padding: e = 0 -> p = 0
   const double t = tile_total(v, sh.wsum);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) amb += __shfl_xor(amb, off, 64);
@@ -243,7 +230,7 @@ __global__ void __launch_bounds__(TN) sample_margin_kernel(const MarginArgs a) {
   if (tid == 0) { sh.val[1] = (double)random_f32(a.rng); *a.ticket = 0u; }
   __syncthreads();
   const double u = sh.val[1];
-  const double M = 8.0 * (double)(n + 64) * TWO_M53 * Qn + 4.0 * A;
+  const double M = mr::margin(n, Qn, A);
   auto prob = [&](int i) { return (float)((double)a.exps[i] / T); };
   int hit = -2;
   double qhit;
@@ -271,7 +258,7 @@ __global__ void __launch_bounds__(TN) topp_margin_kernel(const MarginArgs a) {
   __syncthreads();
   if (tid < a.G) a.part_sorted[tid] = 0.0;
   const double u = sh.val[1];
-  const double M = 8.0 * (double)(n + 64) * TWO_M53 * Qn;
+  const double M = mr::margin(n, Qn, 0.0);
   auto sorted = [&](int i) { return a.sorted[i]; };
   int token = 0;
   bool serial = a.force_serial || !(Qn > 0.0 && Qn <= 1.7976931348623157e308);

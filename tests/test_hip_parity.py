@@ -616,6 +616,9 @@ def test_device_sampler_long_runs_against_oracle():
             want.append(tok)
         assert toks.tolist() == want, (temperature, topp, seed, int(np.argmax(np.array(toks.tolist()) != np.array(want))))
         assert rng_after == rng.state.value
+        # picked by the margin rule, not by its serial loop (a few tokens in a million would be; equal probabilities by the thousand -- the
+        # two huge temperatures -- put many running sums near a threshold at once and are allowed more)
+        assert ctx.get_option(runtime.OPT_SAMPLED_TOKENS) == n and ctx.get_option(runtime.OPT_SAMPLED_SERIAL) <= (n // 4 if temperature >= 1e6 else 1)
         ctx.close(); ref.close()
 
 
