@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(TN) runs_total_kernel(ChainArgs a, Run* recs, 
   __syncthreads();
   bool in_lds;
   chain_total<true>(a, sh, &in_lds);
-  if (threadIdx.x == 0) { *total = sh.val; *ticket = 0u; }
+  if (threadIdx.x == 0) { *total = sh.val; __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // The exact softmax denominator, recomputed by every workgroup of the kernel that needs it next (a walk over ~50 runs is

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(TN) sample_margin_kernel(const MarginArgs a) {
   double Qn, A;
   const double incl = block_scan(own, sh.wsum, &Qn);
   block_scan(own_amb, sh.wamb, &A);
-  if (tid == 0) { sh.val[1] = (double)random_f32(a.rng); *a.ticket = 0u; }
+  if (tid == 0) { sh.val[1] = (double)random_f32(a.rng); __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // past the L2, where the adds are made
   __syncthreads();
   const double u = sh.val[1];
   const double M = mr::margin(n, Qn, A);

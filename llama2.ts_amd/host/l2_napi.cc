@@ -35,6 +35,7 @@ struct Api {
   decltype(&l2_decode_sample) decode_sample;
   decltype(&l2_read_state) read_state;
   decltype(&l2_set_option) set_option;
+  decltype(&l2_get_option) get_option;
   decltype(&l2_load_checkpoint) load_checkpoint;
   decltype(&l2_get_header) get_header;
   decltype(&l2_prefill) prefill;
@@ -58,7 +59,8 @@ bool load_library(const char* hint) {
   api.name = (decltype(api.name))dlsym(api.so, "l2_" #name);               \
   if (!api.name) { g_load_error = "missing symbol l2_" #name; dlclose(api.so); api.so = nullptr; return false; }
   BIND(abi_version) BIND(device_count) BIND(last_error) BIND(create) BIND(destroy) BIND(upload) BIND(synth_fill)
-  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(decode_sample) BIND(read_state) BIND(set_option) BIND(load_checkpoint) BIND(get_header) BIND(prefill) BIND(read_tensor)
+  BIND(forward) BIND(logits_host) BIND(decode_greedy) BIND(decode_sample) BIND(read_state) BIND(set_option)
+  BIND(get_option) BIND(load_checkpoint) BIND(get_header) BIND(prefill) BIND(read_tensor)
 #undef BIND
   if (api.abi_version() != L2_ABI_VERSION) { g_load_error = "ABI version mismatch"; dlclose(api.so); api.so = nullptr; return false; }
   return true;
@@ -387,6 +389,19 @@ napi_value SetOption(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+napi_value GetOption(napi_env env, napi_callback_info info) {
+  ARGS(2)
+  l2_ctx* c;
+  int32_t key;
+  if (!get_ctx(env, argv[0], &c) || !get_i32(env, argv[1], &key)) return nullptr;
+  int value = 0;
+  int rc = api.get_option(c, key, &value);
+  if (rc) return throw_l2(env, rc);
+  napi_value r;
+  napi_create_int32(env, value, &r);
+  return r;
+}
+
 napi_value DeviceCount(napi_env env, napi_callback_info) {
   if (!api.so) return throw_err(env, "call open() first");
   napi_value r;
@@ -398,7 +413,7 @@ napi_value Init(napi_env env, napi_value exports) {
   struct { const char* name; napi_callback fn; } fns[] = {
       {"open", Open}, {"create", Create}, {"destroy", Destroy}, {"upload", Upload}, {"synthFill", SynthFill},
       {"forward", Forward}, {"logitsBuffer", LogitsBuffer}, {"decodeGreedy", DecodeGreedy}, {"decodeSample", DecodeSample}, {"readState", ReadState},
-      {"setOption", SetOption}, {"deviceCount", DeviceCount}, {"loadCheckpoint", LoadCheckpoint}, {"prefill", Prefill}, {"readTensor", ReadTensor}};
+      {"setOption", SetOption}, {"getOption", GetOption}, {"deviceCount", DeviceCount}, {"loadCheckpoint", LoadCheckpoint}, {"prefill", Prefill}, {"readTensor", ReadTensor}};
   for (auto& f : fns) {
     napi_value v;
     napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);

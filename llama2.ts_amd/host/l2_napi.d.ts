@@ -33,4 +33,7 @@ export function readState(ctx: L2Handle, which: number, layer: number, out: Floa
 export function readTensor(ctx: L2Handle, kind: number, layer: number, offset: number, out: Float32Array): void;
 /** L2_OPT_* of include/llama2_hip.h: 1 exact attention, 2 use hipGraph, 3 keep state. */
 export function setOption(ctx: L2Handle, key: number, value: number): void;
+/** Read an option or a read-only counter: 4 MiB of repacked weight copies, 5 MiB of all weights on the device, 6 tokens decodeSample has picked,
+ *  7 of those the ones picked by the reference's loop run as written (a running sum within the proven margin of its threshold). */
+export function getOption(ctx: L2Handle, key: number): number;
 export function deviceCount(): number;

@@ -85,7 +85,8 @@ function run() {
     const n = pos - pos_t0, sec = ms / 1000;
     process.stderr.write(JSON.stringify({ metrics: { tokens_timed: n, tok_s: sec > 0 ? n / sec : null, algorithmic_bytes_per_token: n ? Math.round(bytes / n) : null,
       hbm_gb_s: sec > 0 ? bytes / sec / 1e9 : null, hbm_peak_gb_s: 8000, hbm_frac: sec > 0 ? bytes / sec / 1e9 / 8000 : null,
-      loop: o.loop, timer: "Date.now(), first timed position " + pos_t0 } }) + "\n");
+      loop: o.loop, timer: "Date.now(), first timed position " + pos_t0,
+      sampler: o.loop == "device" && o.temperature != 0 ? { tokens: be.getOption(weights.ctx, 6), by_serial_loop: be.getOption(weights.ctx, 7) } : undefined } }) + "\n");
   }
   be.destroy(weights.ctx);
   process.stdout.write(JSON.stringify({ tokens: out, tok_s: ms > 0 ? (out.length - 1) / ms * 1000 : null }) + "\n");

@@ -123,6 +123,7 @@ int l2_read_state(l2_ctx* c, int which, int layer, float* out, size_t n) {
   return L2_OK;
 }
 
+int l2_get_option(l2_ctx* c, int key, int* value) { if (!c || !value || key < 1 || key > 7) return fail(L2_E_ARG, "unknown option"); *value = 100 + key; return L2_OK; }
 int l2_set_option(l2_ctx* c, int key, int value) { (void)value; return (c && key >= 1 && key <= 3) ? L2_OK : fail(L2_E_ARG, "unknown option"); }
 
 int l2_get_header(l2_ctx* c, int32_t cfg_out[7]) {

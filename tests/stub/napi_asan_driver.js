@@ -93,6 +93,8 @@ a.forward(ctx, 1, 0, undefined);
   throws(() => a.readTensor(ctx, 2, 0, -1, tv), "non-negative", "readTensor negative offset");
   a.setOption(ctx, 1, 1);
   throws(() => a.setOption(ctx, 77, 1), "unknown option", "option key");
+  if (a.getOption(ctx, 6) !== 106) throw new Error("getOption: wrong value");
+  throws(() => a.getOption(ctx, 77), "unknown option", "read of an unknown option");
 }
 { // native loader entry
   const r = a.loadCheckpoint(ckpt, 0);

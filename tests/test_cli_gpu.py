@@ -127,6 +127,18 @@ def test_metrics_line_on_stderr(workdir):
         assert abs(m["hbm_frac"] - m["hbm_gb_s"] / 8000) < 1e-9
 
 
+def test_metrics_line_counts_the_sampler(workdir):
+    """A sampled device loop with --metrics also says how its tokens were picked (getOption 6 / 7 through the addon): every sampled token by
+    the margin rule here, none by the serial loop -- and the text is still the reference's."""
+    for name in ("cli_temp", "cli_topp"):
+        flags, prompt_ids, want = reference_run(name)
+        rc, res, err = run_ids(workdir, argv_for(flags, prompt_ids, "device", ("--metrics",)))
+        assert rc == 0, err
+        assert text_of(res["tokens"]) == want
+        m = json.loads([l for l in err.splitlines() if l.startswith("{")][-1])["metrics"]
+        assert m["sampler"]["tokens"] == int(flags["-n"]) - len(prompt_ids) and m["sampler"]["by_serial_loop"] == 0, m
+
+
 def test_offset_views_through_the_real_addon(workdir, tmp_path):
     """llama2.ts:56 makes its Float32Arrays as views (buffer.buffer, buffer.byteOffset, n): the addon must hand the VIEW's bytes to
     l2_upload.  Arrays with byteOffset != 0 (a plain ArrayBuffer view, and a pooled Buffer the way the reference builds it) go up

@@ -47,7 +47,7 @@ def test_addon_exports_and_fails_without_gpu(built, tmp_path):
         os.path.join(ROOT, "llama2.ts_amd", "lib", "libllama2hip.so"))
     r = subprocess.run(["node", "-e", js], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     out = r.stdout.decode().splitlines()
-    assert out[0] == "create,decodeGreedy,decodeSample,destroy,deviceCount,forward,loadCheckpoint,logitsBuffer,open,prefill,readState,readTensor,setOption,synthFill,upload"
+    assert out[0] == "create,decodeGreedy,decodeSample,destroy,deviceCount,forward,getOption,loadCheckpoint,logitsBuffer,open,prefill,readState,readTensor,setOption,synthFill,upload"
     import torch
     if not torch.cuda.is_available():
         assert out[1].startswith("ERR libllama2hip: no HIP device visible")
