@@ -671,6 +671,22 @@ def test_sampler_forms_agree(monkeypatch):
     assert runs["margin"] == runs["forced"] == runs["chain"] == runs["serial"]
 
 
+@pytest.mark.parametrize("vocab", [1000, 5121, 50257])
+def test_margin_sampler_serial_branch_on_ragged_vocabularies(monkeypatch, vocab):
+    """The margin form's serial loop (the branch an undecided token takes) on vocabularies that end inside a tile, inside one of its 4096-value
+    staging chunks and inside a 512-value segment of recorded sums: same tokens and RNG state as the default branch, plain and top-p."""
+    hdr = (64, 176, 1, 4, 4, vocab, 16)
+    runs = {}
+    for forced in ("0", "1"):
+        monkeypatch.setenv("L2_SAMPLER_FORCE_SERIAL", forced)
+        ctx = runtime.Context(hdr)
+        ctx.synth_fill(3)
+        runs[forced] = [tuple(x.tolist() if hasattr(x, "tolist") else x for x in ctx.decode_sample(1, 0, 12, t, p, 21)) for t, p in ((0.9, 1.0), (1.1, 0.9), (0.6, 0.3))]
+        assert ctx.get_option(runtime.OPT_SAMPLED_SERIAL) == (36 if forced == "1" else 0)
+        ctx.close()
+    assert runs["0"] == runs["1"]
+
+
 @pytest.mark.parametrize("form", ["L2_SAMPLER_FORCE_SERIAL", "L2_SAMPLER_CHAIN"])
 def test_device_sampler_other_forms_reproduce_the_reference_run(monkeypatch, form):
     """The reference's own -t / -p runs (fixtures cli_temp, cli_topp) through the margin form's serial branch and through the exact chain."""
