@@ -21,7 +21,9 @@
 extern "C" {
 #endif
 
-#define L2_ABI_VERSION 2
+/* 3 (round 5): l2_bench_tokens, option keys 5-7, L2_TP_SOLO_ID / l2_tp_mode 5 and the L2_TP_FENCED switch joined the surface after 2 -- a
+ * binding built against 3 refuses an older library at open() (l2_abi_version), not at the first call that is missing */
+#define L2_ABI_VERSION 3
 
 enum {
   L2_OK = 0,
@@ -163,9 +165,11 @@ int l2_decode_greedy(l2_ctx* ctx, int first_token, int pos0, int steps, int32_t*
  * (:378-394: stable descending sort, the element that crosses topp is never returned, fall-through returns id 0),
  * driven by the reference's xorshift* generator (:348-360).  `*rng_state` is the 64-bit state the reference keeps in
  * the BigInt `rng_seed` (what `-s` parsed, non-zero); it is advanced by one draw per sampled token and written back.
- * Every running sum is accumulated sequentially in index order on the device, as the reference does, so the SAME
- * token ids come out for the same seed.  temperature == 0 is l2_decode_greedy (no draw).  Like l2_decode_greedy it
- * does not stop at BOS. */
+ * The SAME token ids come out for the same seed: what the reference's loops return is an INDEX -- the first element whose
+ * sequentially accumulated running sum passes the threshold -- and the device decides every comparison those loops make from
+ * tree sums plus a proven margin (csrc/margin_rule.h); a token whose running sum comes within that margin of its threshold
+ * (about 4 in 100 000) is picked by the reference's loop run as written, element by element (L2_OPT_SAMPLED_SERIAL counts
+ * them).  temperature == 0 is l2_decode_greedy (no draw).  Like l2_decode_greedy it does not stop at BOS. */
 int l2_decode_sample(l2_ctx* ctx, int first_token, int pos0, int steps, double temperature, double topp,
                      uint64_t* rng_state, int32_t* tokens_out);
 

@@ -113,6 +113,7 @@ struct P2PArgs {
   int* err;
   int G, rank, n;              // n: elements of this exchange (d, or V_loc)
   unsigned long long wait_ticks;   // bound of a flag wait, in 100 MHz ticks
+  int fenced;                  // L2_TP_FENCED=1: system-scope fences around the flags (tp_exchange.hip.h)
   int solo;                    // shard-timing context (l2_create_tp with the L2_TP_SOLO_ID id): every "peer" is this rank itself
 };
 
@@ -147,6 +148,7 @@ struct l2_ctx {
   bool p2p_peers_ready = false;
   bool rccl_graph = false;           // the RCCL collectives of the step are captured into the per-token hipGraph (cleared if capture is refused)
   unsigned long long p2p_wait_ticks = 3000000000ull;   // L2_TP_WAIT_S (default 30 s) on the 100 MHz clock
+  int p2p_fenced = 0;                // L2_TP_FENCED=1: the peer-to-peer exchange with system-scope fences around its flags
   bool solo = false;                 // shard-timing context: one rank of G alone, the exchange kernels run against its own inbox (timing only, sums are G x the partial)
   bool p2p_synced = false;           // the ranks have met once (host side) right before the first exchange of a step
   bool broken = false;               // a peer-to-peer wait gave up: this rank's epochs no longer match its peers'
@@ -212,6 +214,7 @@ struct l2_ctx {
   // One copy of the weights: once a phase's matrices are repacked, their row-major tensors are given back (w[kind] = null); the prompt
   // GEMMs read the repacked copy too, l2_read_tensor and a later l2_upload unpack it first (ensure_rowmajor).
   bool released[L2_T_COUNT] = {};
+  bool rerelease = false;           // l2_read_tensor brought the row-major tensors back for a parity read: the next step gives them away again (no repack)
   int opt_one_copy = 1;             // L2_ONE_COPY=0: keep both copies (A/B, development switch)
 };
 

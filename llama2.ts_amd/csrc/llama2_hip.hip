@@ -171,6 +171,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->opt_one_copy = dev_int("L2_ONE_COPY", 1);
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !hook_int("L2_TP_FORCE_COMM")) ? 1 : 0);
   c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
+  c->p2p_fenced = env_int("L2_TP_FENCED", 0) ? 1 : 0;
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
@@ -517,9 +518,39 @@ static int phase_kinds(const l2_ctx* c, int mode, int (&kinds)[3]) {
   }
 }
 
+static bool phase_has_dirty(const l2_ctx* c, int m) { for (uint8_t b : c->packed[m].dirty) if (b) return true; return false; }
+
+// ONE copy of the weights: a packed phase reads nothing but its repacked copy (decode, prompt ingestion), so the row-major tensors it
+// was built from go back to the allocator (Llama-2-7B: 25 GB).  Captured graphs keep working: their launches carry the repacked
+// addresses, which do not move.
+static int release_packed_sources(l2_ctx* c) {
+  c->rerelease = false;
+  if (!c->opt_one_copy) return L2_OK;
+  for (int m = 0; m < 5; ++m) {
+    if (!c->packed[m].buf) continue;
+    int kinds[3];
+    const int nk = phase_kinds(c, m, kinds);
+    for (int i = 0; i < nk; ++i) {
+      const int k = kinds[i];
+      if (c->w[k] && !c->released[k]) { HIPCHK(hipFree(c->w[k])); c->w[k] = nullptr; c->released[k] = true; }
+    }
+  }
+  return L2_OK;
+}
+
 static int ensure_packed(l2_ctx* c) {
-  if (c->packed_valid) return L2_OK;
-  for (int k = 0; k < L2_T_COUNT; ++k) if (c->released[k]) return fail(L2_E_STATE, "internal: tensor kind %d is marked dirty while its row-major copy is gone", k);
+  // nothing to repack; row-major tensors that l2_read_tensor brought back for a parity read are given away again
+  if (c->packed_valid) return c->rerelease ? release_packed_sources(c) : L2_OK;
+  // A dirty slice is rebuilt from the row-major tensors of ITS phase: those must be there (an upload brings them back before it marks
+  // anything).  Other phases may have given theirs away -- a shared classifier's matrix is the embedding table, which never goes:
+  // re-uploading it after a step dirties the classifier phase only.
+  for (int m = 0; m < 5; ++m) {
+    if (!phase_has_dirty(c, m)) continue;
+    int kinds[3];
+    const int nk = phase_kinds(c, m, kinds);
+    for (int i = 0; i < nk; ++i)
+      if (c->released[kinds[i]]) return fail(L2_E_STATE, "internal: tensor kind %d is marked dirty while its row-major copy is gone", kinds[i]);
+  }
   int rc;
   if ((rc = pack_phase<MODE_QKV>(c, c->L, qkv_args))) return rc;
   if ((rc = pack_phase<MODE_WO>(c, c->L, wo_args))) return rc;
@@ -528,21 +559,7 @@ static int ensure_packed(l2_ctx* c) {
   if ((rc = pack_phase<MODE_CLS>(c, 1, cls_args_l))) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   c->packed_valid = true;
-  // ONE copy of the weights: a packed phase reads nothing but its repacked copy (decode, prompt ingestion), so the row-major
-  // tensors it was built from go back to the allocator (Llama-2-7B: 25 GB).  Captured graphs keep working: their launches carry
-  // the repacked addresses, which do not move.
-  if (c->opt_one_copy) {
-    for (int m = 0; m < 5; ++m) {
-      if (!c->packed[m].buf) continue;
-      int kinds[3];
-      const int nk = phase_kinds(c, m, kinds);
-      for (int i = 0; i < nk; ++i) {
-        const int k = kinds[i];
-        if (c->w[k] && !c->released[k]) { HIPCHK(hipFree(c->w[k])); c->w[k] = nullptr; c->released[k] = true; }
-      }
-    }
-  }
-  return L2_OK;
+  return release_packed_sources(c);
 }
 
 template <int MODE>
@@ -554,6 +571,7 @@ static int unpack_phase(l2_ctx* c, int layers, PhaseArgs (*args_of)(const l2_ctx
   for (int i = 0; i < nk; ++i) any = any || c->released[kinds[i]];
   if (!any) return L2_OK;
   if (!p.buf) return fail(L2_E_STATE, "internal: phase %d has neither a row-major nor a repacked copy", MODE);
+  if (phase_has_dirty(c, MODE)) return fail(L2_E_STATE, "internal: the repacked copy of phase %d is stale and its row-major tensors are gone", MODE);
   const PhaseArgs a0 = args_of(c, 0);
   const int n4 = a0.n / 4, rpg = (MODE == MODE_W13) ? 1 : 2, groups = (a0.rows + rpg - 1) / rpg;
   for (int l = 0; l < layers; ++l) {
@@ -581,7 +599,8 @@ static int ensure_rowmajor(l2_ctx* c, bool unpack) {
   if (!any) return L2_OK;
   int rc = L2_OK;
   if (unpack) {
-    if (!c->packed_valid) return fail(L2_E_STATE, "internal: the repacked copies are stale and the row-major tensors are gone");
+    // (a phase whose tensors are gone is never stale: unpack_phase checks; another phase may be -- a shared classifier after the
+    //  embedding table was uploaded again -- and that one still has its source)
     if ((rc = unpack_phase<MODE_QKV>(c, c->L, qkv_args))) return rc;
     if ((rc = unpack_phase<MODE_WO>(c, c->L, wo_args))) return rc;
     if ((rc = unpack_phase<MODE_W13>(c, c->L, w13_args))) return rc;

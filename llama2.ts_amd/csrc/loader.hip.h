@@ -195,7 +195,9 @@ extern "C" int l2_read_tensor(l2_ctx* c, int kind, int layer, size_t offset, flo
   const size_t n = c->layer_elems[kind] ? c->layer_elems[kind] : (size_t)c->V * c->d;
   if (offset + n_floats > n) return fail(L2_E_ARG, "read of %zu floats at %zu exceeds tensor (%zu)", n_floats, offset, n);
   HIPCHK(hipSetDevice(c->device));
-  if (c->released[kind]) { const int rc_ = ensure_rowmajor(c, true); if (rc_) return rc_; }      // out of the repacked copy (given back again after the next step)
+  // out of the repacked copy; the next step (or the next l2_upload's repack) gives the tensors away again -- several reads in a row
+  // (a parity check walks every layer) unpack once
+  if (c->released[kind]) { const int rc_ = ensure_rowmajor(c, true); if (rc_) return rc_; c->rerelease = true; }
   HIPCHK(hipMemcpy(out, c->w[kind] + n * (size_t)li + offset, n_floats * 4, hipMemcpyDeviceToHost));
   return L2_OK;
 }

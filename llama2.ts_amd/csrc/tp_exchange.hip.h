@@ -22,6 +22,10 @@
 //     (s_waitcnt vmcnt(0)), workgroup barrier, then the flag stores" -- writes to one peer arrive in order -- and the acquire is
 //     "poll the flag words, workgroup barrier, load" (MI355X guide, hand-off recipe R1 with every load L1-bypassing).  Polls are
 //     bounded: a rank that never arrives sets `err` instead of hanging the GPU.
+//   * L2_TP_FENCED=1 (an ordinary environment switch, read at creation, not behind the development gate) puts the fences back:
+//     __threadfence_system() between the barrier and the flag stores and behind the poll.  No multi-GPU box has run either form;
+//     the fence-free one is guarded by the soak at creation (below) and by bench.py's golden check before it times anything -- a
+//     deployment that sees ranks diverge has this switch before it has a new build.
 
 __device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) { return a.epoch[blockIdx.x] + 1; }
 
@@ -40,6 +44,7 @@ __device__ __forceinline__ void p2p_raise(const P2PArgs& a, unsigned long long e
   const int par = (int)(e & 1), b = blockIdx.x;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave: its payload stores have left
   __syncthreads();
+  if (a.fenced && tid < a.G) __threadfence_system();   // L2_TP_FENCED=1: a system-scope release in front of the flags (the round-3 form: ~8 us per exchange)
   if (tid < a.G) __hip_atomic_store(a.pr.flags[a.solo ? a.rank : tid] + ((size_t)(par * P2P_MAXG + (a.solo ? tid : a.rank)) * P2P_FB + b), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ... then wait for every source's flag in the local inbox
@@ -60,6 +65,7 @@ __device__ __forceinline__ void p2p_wait(const P2PArgs& a, unsigned long long e,
         else if (now - t0 > a.wait_ticks) { *a.err = 1; break; }
       }
     }
+    if (a.fenced) __threadfence_system();              // ... and a system-scope acquire behind the poll
   }
   __syncthreads();
 }
@@ -140,7 +146,7 @@ static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits) {
 static P2PArgs p2p_args(const l2_ctx* c, int n) {
   P2PArgs a;
   a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = nullptr; a.err = c->p2p_err_dev;
-  a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks; a.solo = c->solo ? 1 : 0;
+  a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks; a.solo = c->solo ? 1 : 0; a.fenced = c->p2p_fenced;
   return a;
 }
 static int p2p_grid(int n) { const int b = (n + 255) / 256; return b > P2P_FB ? P2P_FB : (b < 1 ? 1 : b); }
@@ -273,7 +279,9 @@ static int p2p_connect_ipc(l2_ctx* c) {
     // ... then a soak: 96 all-reduces and 32 logits gathers BACK TO BACK on the stream, every element of every result checked on
     // the device.  The exchange has no fences (its ordering rests on drained write-through stores, see the top of this file), and
     // no multi-GPU box has ever run it: a peer whose payload could become visible after its flag has 128 chances to show it here,
-    // in the timing the decode step has -- and sends the whole group to the RCCL collectives if it does.
+    // in the timing the decode step has -- and sends the whole group to the RCCL collectives if it does (a group that met through
+    // files, L2_TP_FILE_RENDEZVOUS / L2_TP_IPC_DIR, has no communicator to fall back to: there creation FAILS, below, and bench.py
+    // moves on to independent replicas).
     if (h_ok) {
       int* d_bad = nullptr;
       HIPCHK(hipMalloc(&d_bad, sizeof(int)));
@@ -378,7 +386,7 @@ static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer w
     *c->h_herr = 0;
     hipMemsetAsync(c->gran, 0, ((size_t)c->d_loc + 2 * (size_t)c->kvd_loc) * 8, c->stream);      // tags of the broken launch: gone (the counters only ever grow)
     hipStreamSynchronize(c->stream);
-    return fail(L2_E_HIP, "fused QKV + attention launch: a hand-off granule never arrived (bounded wait gave up); the step's results are invalid");
+    return fail(L2_E_HIP, "a hand-off granule inside a fused launch never arrived (bounded wait gave up); the step's results are invalid");
   }
   if (c->p2p_err && *c->p2p_err) {
     *c->p2p_err = 0;

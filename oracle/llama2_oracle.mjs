@@ -12,8 +12,13 @@
 // Only tests/ and bench.py's cpu_baseline leg run this.  The product (llama2.ts_amd/) never does.
 //
 //   node llama2_oracle.mjs <checkpoint.bin> <steps> [--sha] [--prompt id,id,...]
+//   node llama2_oracle.mjs --synth d,hidden,L,H,KV,V,S,seed <steps> [--sha] [--tensor-sha]
 // prints ONE JSON line: {"tokens": [...], "tok_s": ..., "steps": n, "sha256": [...] (with --sha)}.
 // Timing as the reference does it (llama2.ts:507, 511): the clock starts after the first token.
+// --synth: no file -- the typed arrays are filled IN PROCESS by the repo's deterministic generator restated here (the integer hash
+// of oracle/llama2_oracle.c: orc_synth_fill / orc_synth_freq; same header ints, same seed => the same bytes `oracle_cli synth`
+// writes, pinned by tests/test_oracle_golden.py through --tensor-sha: sha256 of every tensor).  That is how bench.py times this
+// restatement on the 27 GB Llama-2-7B shape, which cannot go through a file in a benchmark's time.
 import * as fs from "fs";
 import * as crypto from "crypto";
 
@@ -51,6 +56,78 @@ function openModel(file) {
   w.cls = cfg.shared ? w.emb : take(V * d);                                // :127
   if (at != nFloats) throw new Error("checkpoint size does not match its header");
   const st = {                                                             // newRunState, :147-163
+    x: new Float32Array(d), xb: new Float32Array(d), xb2: new Float32Array(d), hb: new Float32Array(hd), hb2: new Float32Array(hd),
+    q: new Float32Array(d), k: new Float32Array(d), v: new Float32Array(d), att: new Float32Array(cfg.heads * S),
+    logits: new Float32Array(V), kc: new Float32Array(L * S * d), vc: new Float32Array(L * S * d),
+  };
+  return { cfg, w, st };
+}
+
+// ---- the synthetic generator (oracle/llama2_oracle.c:73-150): 32-bit integer hashing, one fp32 multiply and one fp32 add per element
+function hash32(a) {
+  a ^= a >>> 16; a = Math.imul(a, 0x7feb352d); a ^= a >>> 15; a = Math.imul(a, 0x846ca68b); a ^= a >>> 16;
+  return a >>> 0;
+}
+/** out[i] = bias + fl(c(g0 + i) * scale), c = a centred sum of four 16-bit uniforms hashed from the element's index in the float stream. */
+function synthFill(out, g0, seed, scale, bias) {
+  const sk = Math.imul(seed, 0x9E3779B9) ^ 0x85ebca6b;
+  const n = out.length;
+  let lo = g0 % 4294967296, hi = Math.floor(g0 / 4294967296), k = hash32(hi ^ sk);
+  for (let i = 0; i < n; ++i) {
+    const h1 = hash32((lo ^ k) >>> 0), h2 = hash32((h1 + 0x9E3779B9) >>> 0);
+    const c = (h1 & 0xffff) + (h1 >>> 16) + (h2 & 0xffff) + (h2 >>> 16) - 131070;
+    out[i] = bias + Math.fround(c * scale);             // the product rounded to fp32, the sum rounded by the store
+    if (++lo == 4294967296) { lo = 0; ++hi; k = hash32(hi ^ sk); }
+  }
+}
+function detExp(x) {                                    // x in [-10, 0], IEEE basic operations only
+  const y = x / 1024.0;
+  let t = 1.0, s = 1.0;
+  for (let k = 1; k <= 14; ++k) { t = (t * y) / k; s = s + t; }
+  for (let i = 0; i < 10; ++i) s = s * s;
+  return s;
+}
+function detSinCos(x) {                                 // |x| <= 1
+  const x2 = x * x;
+  let ts = x, tc = 1.0, ss = x, cc = 1.0;
+  for (let k = 1; k <= 12; ++k) {
+    tc = ((-tc) * x2) / ((2 * k - 1) * (2 * k)); cc = cc + tc;
+    ts = ((-ts) * x2) / ((2 * k) * (2 * k + 1)); ss = ss + ts;
+  }
+  return [ss, cc];
+}
+/** The model of openModel(), every tensor its own Float32Array filled by the generator (checkpoint order = index in the float stream). */
+function synthModel(hdr, seed) {
+  const cfg = { dim: hdr[0], hidden: hdr[1], layers: hdr[2], heads: hdr[3], kvHeads: hdr[4], vocab: Math.abs(hdr[5]), seqLen: hdr[6], shared: hdr[5] > 0 };
+  cfg.headSize = cfg.dim / cfg.heads;
+  const { dim: d, hidden: hd, layers: L, vocab: V, seqLen: S, headSize: hs } = cfg;
+  const STD = 37837.22723720648;                        // sqrt(4 * (65536^2 - 1) / 12)
+  let at = 0;
+  const gen = (n, sigma, bias) => { const a = new Float32Array(n); synthFill(a, at, seed, Math.fround(sigma / STD), bias); at += n; return a; };
+  const perLayer = (n, sigma, bias) => { const out = []; for (let l = 0; l < L; ++l) out.push(gen(n, sigma, bias)); return out; };
+  const sd = 1.0 / Math.sqrt(d), sh = 1.0 / Math.sqrt(hd);
+  const w = {};
+  w.emb = gen(V * d, 0.02, 0);
+  w.rmsAtt = perLayer(d, 0.1, 1);
+  w.wq = perLayer(d * d, sd, 0); w.wk = perLayer(d * d, sd, 0); w.wv = perLayer(d * d, sd, 0); w.wo = perLayer(d * d, sd, 0);
+  w.rmsFfn = perLayer(d, 0.1, 1);
+  w.w1 = perLayer(hd * d, sd, 0); w.w2 = perLayer(d * hd, sh, 0); w.w3 = perLayer(hd * d, sd, 0);
+  w.rmsFinal = gen(d, 0.1, 1);
+  const hs2 = hs / 2;
+  w.fcr = new Float32Array(S * hs2); w.fci = new Float32Array(S * hs2);
+  for (let j = 0; j < hs2; ++j) {                       // angle t * theta by complex rotation (orc_synth_freq)
+    const theta = detExp(-(((2.0 * j) / hs) * 9.210340371976184));
+    const [st, ct] = detSinCos(theta);
+    let cr = 1.0, ci = 0.0;
+    for (let t = 0; t < S; ++t) {
+      w.fcr[t * hs2 + j] = cr; w.fci[t * hs2 + j] = ci;
+      const nr = cr * ct - ci * st, ni = cr * st + ci * ct;
+      cr = nr; ci = ni;
+    }
+  }
+  at += 2 * S * hs2;
+  w.cls = cfg.shared ? w.emb : gen(V * d, 0.02, 0);
+  const st = {
     x: new Float32Array(d), xb: new Float32Array(d), xb2: new Float32Array(d), hb: new Float32Array(hd), hb2: new Float32Array(hd),
     q: new Float32Array(d), k: new Float32Array(d), v: new Float32Array(d), att: new Float32Array(cfg.heads * S),
     logits: new Float32Array(V), kc: new Float32Array(L * S * d), vc: new Float32Array(L * S * d),
@@ -139,12 +216,19 @@ function firstMax(a) {                                                     // :3
   return at;
 }
 
-const [, , file, stepsArg, ...flags] = process.argv;
-if (!file || !stepsArg) { console.error("usage: node llama2_oracle.mjs <checkpoint.bin> <steps> [--sha] [--prompt id,id,...]"); process.exit(1); }
+let [, , file, stepsArg, ...flags] = process.argv;
+let synth = null;
+if (file == "--synth") { synth = (stepsArg || "").split(",").map((t) => parseInt(t)); [stepsArg, ...flags] = flags; }
+if (!file || !stepsArg || (synth && synth.length != 8)) {
+  console.error("usage: node llama2_oracle.mjs <checkpoint.bin> <steps> [--sha] [--prompt id,id,...]\n       node llama2_oracle.mjs --synth d,hidden,L,H,KV,V,S,seed <steps> [--sha] [--tensor-sha]");
+  process.exit(1);
+}
 const wantSha = flags.includes("--sha");
 const pi = flags.indexOf("--prompt");
 const prompt = pi >= 0 ? flags[pi + 1].split(",").filter((t) => t.length).map((t) => parseInt(t)) : [];
-const model = openModel(file);
+const tGen = Date.now();
+const model = synth ? synthModel(synth.slice(0, 7), synth[7] >>> 0) : openModel(file);
+const genSeconds = (Date.now() - tGen) / 1000;
 const steps = Math.min(parseInt(stepsArg), model.cfg.seqLen);
 const tokens = [], shas = [];
 let token = 1, t0 = 0;
@@ -156,6 +240,12 @@ for (let pos = 0; pos < steps; ++pos) {
   if (!t0) t0 = Date.now();
 }
 const ms = Date.now() - t0;
-const out = { tokens, steps, tok_s: steps > 1 && ms > 0 ? (steps - 1) / ms * 1000 : null, node: process.version };
+const out = { tokens, steps, tok_s: steps > 1 && ms > 0 ? (steps - 1) / ms * 1000 : null, node: process.version, load_s: genSeconds };
 if (wantSha) out.sha256 = shas;
+if (flags.includes("--tensor-sha")) {                   // sha256 of every tensor in checkpoint order (per-layer tensors: layers back to back)
+  const sha = (arrays) => { const h = crypto.createHash("sha256"); for (const a of arrays) h.update(Buffer.from(a.buffer, a.byteOffset, a.byteLength)); return h.digest("hex"); };
+  const w = model.w, one = (a) => sha([a]);
+  out.tensor_sha256 = [one(w.emb), sha(w.rmsAtt), sha(w.wq), sha(w.wk), sha(w.wv), sha(w.wo), sha(w.rmsFfn), sha(w.w1), sha(w.w2), sha(w.w3),
+    one(w.rmsFinal), one(w.fcr), one(w.fci)].concat(model.cfg.shared ? [] : [one(w.cls)]);
+}
 process.stdout.write(JSON.stringify(out) + "\n");

@@ -26,7 +26,7 @@ def test_header_symbols_exported(built):
     raw = C.CDLL(runtime.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert built.l2_abi_version() == 2
+    assert built.l2_abi_version() == 3
 
 
 def test_header_cites_reference_lines():
@@ -84,7 +84,9 @@ def test_bun_ffi_snippet_matches_the_header():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     snippet = doc[doc.index("## 2. bun:ffi"):doc.index("## 3.")]
     bound = re.findall(r"(l2_[a-z_]+):\s*\{\s*args:\s*\[([^\]]*)\],\s*returns:\s*FFIType\.(\w+)", snippet)
-    assert {b[0] for b in bound} >= {"l2_create", "l2_upload", "l2_forward", "l2_last_error", "l2_destroy"}
+    assert {b[0] for b in bound} >= {"l2_abi_version", "l2_create", "l2_upload", "l2_forward", "l2_last_error", "l2_destroy"}
+    ver = int(re.search(r"#define L2_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "llama2_hip.h")).read()).group(1))
+    assert "l2_abi_version() !== %d" % ver in snippet, "the snippet checks another ABI version than the header defines"
 
     def kind(ctype):
         t = ctype.strip()

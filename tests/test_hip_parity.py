@@ -762,6 +762,8 @@ def test_one_copy_of_the_weights(built, monkeypatch):
     assert np.array_equal(ctx.read_tensor(runtime.T_W2, 1, 4096 * 11008 - 5000, 5000), w2_before)
     assert np.array_equal(ctx.read_tensor(runtime.T_WQ, 0, 12345, 4096), wq_before)
     assert ctx.get_option(runtime.OPT_WEIGHT_MIB) > ckpt_mib + packed - emb_mib - 8           # both copies for the moment
+    ctx.forward(1, 0)                                                                         # ... the next step gives them away again, upload or not
+    assert abs(ctx.get_option(runtime.OPT_WEIGHT_MIB) - ckpt_mib) <= 4
     # ... a matrix uploaded now replaces its slice of the repacked copy at the next step, which gives the row-major tensors away again
     wo1 = ctx.read_tensor(runtime.T_WO, 1, 0, 4096 * 4096)
     ctx.upload(runtime.T_WO, 1, np.zeros(4096 * 4096, dtype=np.float32))
@@ -881,4 +883,17 @@ def test_repacked_matrices_equal_the_row_major_ones_and_follow_uploads(built, hd
         a.upload(kind, layer, w); b.upload(kind, layer, w)
     after = run(0, 6, False)
     assert not np.array_equal(bits(before), bits(after))
+    if hdr[5] > 0:
+        # a shared classifier's matrix is the embedding table, which is never given away: uploading it again AFTER a step dirties the
+        # classifier phase only, while the layer matrices exist as repacked copies alone (round 4 refused the next step) ...
+        emb = orc.weights(runtime.T_TOKEN_EMBEDDING, -1).copy() * np.float32(0.5)
+        a.upload(runtime.T_TOKEN_EMBEDDING, -1, emb); b.upload(runtime.T_TOKEN_EMBEDDING, -1, emb)
+        halved = run(0, 3, False)
+        assert not np.array_equal(bits(halved), bits(after))
+        # ... and a released matrix uploaded while the classifier phase is still stale comes back out of its own (valid) repacked copy
+        emb = orc.weights(runtime.T_TOKEN_EMBEDDING, -1).copy() * np.float32(0.75)
+        a.upload(runtime.T_TOKEN_EMBEDDING, -1, emb); b.upload(runtime.T_TOKEN_EMBEDDING, -1, emb)
+        wq = orc.weights(runtime.T_WQ, 0).copy() * np.float32(1.25)
+        a.upload(runtime.T_WQ, 0, wq); b.upload(runtime.T_WQ, 0, wq)
+        run(0, 3, False)
     a.close(); b.close(); orc.close()
