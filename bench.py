@@ -160,6 +160,96 @@ def trace_child(name, seed):
     ctx.close()
 
 
+def dropin_loop(ctx, K):
+    """K steps through the blocking drop-in call (llama2.ts:468 -> 478: logits land on the host every token, argmax there)."""
+    tok = 1
+    ctx.forward(1, 0)
+    t0 = time.perf_counter()
+    toks = []
+    for pos in range(K):
+        tok = int(np.argmax(ctx.forward(tok, pos, view=True)))
+        toks.append(tok)
+    return K / (time.perf_counter() - t0), toks
+
+
+def dropin_child(name, seed):
+    """`--dropin-child`: the drop-in loop alone, as a process of its own, so that it can be timed under another runtime setting
+    (AMD_DIRECT_DISPATCH=0: the HIP runtime submits from a thread of its own) than the parent was started with.  Prints one JSON line."""
+    hdr = configs.header(name)
+    ctx = runtime.Context(hdr)
+    ctx.synth_fill(seed)
+    K = min(256, hdr[6])
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.3:
+        ctx.bench_decode(1, 0, 64)
+    dropin_loop(ctx, K)
+    rate, toks = dropin_loop(ctx, K)
+    ctx.close()
+    print(json.dumps({"dropin_tok_s": round(rate, 2), "tokens": toks}))
+
+
+def dropin_direct_dispatch_off(name, seed):
+    """dropin_tok_s with the one runtime knob that moves the replayed-graph floor (profiles/r04/direct_dispatch_ab.txt): measured in a
+    child, reported beside the default -- a deployment may set it, the library does not change the host's runtime configuration."""
+    try:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dropin-child", "--config", name, "--seed", str(seed)]
+        r = subprocess.run(cmd, env=clean_child_env(AMD_DIRECT_DISPATCH="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        gold = golden_argmax(name, seed)
+        return {"value": j["dropin_tok_s"], "env": "AMD_DIRECT_DISPATCH=0", "equal_to_reference_golden": (None if gold is None else j["tokens"] == gold[:len(j["tokens"])])}
+    except Exception as e:   # noqa: BLE001 -- a side measurement must not fail the benchmark
+        return {"value": None, "why": "%s: %s" % (type(e).__name__, e)}
+
+
+def write_checkpoint(ctx, path):
+    """The context's weights as a llama2.c-v0 file (header + tensors in checkpoint order, llama2.ts:80-93, 112-129), read back from
+    the DEVICE through l2_read_tensor: what the Node host loads below is what the decode above ran on."""
+    cfg = ctx.cfg
+    with open(path, "wb") as f:
+        f.write(np.asarray(cfg.header, dtype="<i4").tobytes())
+        for kind, layers, count in runtime.tensor_shapes(cfg):
+            for layer in range(max(layers, 1)):
+                ctx.read_tensor(kind, layer if layers else -1, 0, count).tofile(f)
+
+
+def napi_dropin(ctx, name, seed, K):
+    """The boundary the contract names: the SAME K steps through the real N-API addon under Node -- host/l2_run.mjs --loop host is the
+    reference's loop (one transformer() per position, llama2.ts:468; first maximum on the host, :478) over l2_backend's readWeights /
+    transformer, clock started after the first iteration like llama2.ts:507 -- on a checkpoint file written from this context's weights."""
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "llama2.ts_amd", "host", "l2_napi.node")
+    if not node or not os.path.exists(addon):
+        return {"value": None, "why": "no node / no built addon on this box"}
+    if configs.checkpoint_bytes(ctx.cfg.header) > (2 << 30):
+        return {"value": None, "why": "checkpoint of %.0f GB: not written to a file inside a benchmark run (ctypes dropin_tok_s is the figure for this shape)"
+                % (configs.checkpoint_bytes(ctx.cfg.header) / 2.0 ** 30)}
+    path = os.path.join(tempfile.gettempdir(), "l2_napi_%s_%d_%d.bin" % (name, seed, os.getpid()))
+    try:
+        write_checkpoint(ctx, path)
+        cmd = [node, os.path.join(ROOT, "llama2.ts_amd", "host", "l2_run.mjs"), path, "--steps", str(K), "--loop", "host", "--metrics"]
+        best = None
+        for _ in range(2):      # the first run also pays the page cache and the addon's first dlopen
+            r = subprocess.run(cmd, env=clean_child_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if r.returncode != 0:
+                return {"value": None, "why": "node failed: %s" % r.stderr.decode("utf8", "replace")[-200:]}
+            m = [json.loads(ln)["metrics"] for ln in r.stderr.decode().splitlines() if ln.startswith("{") and '"metrics"' in ln][-1]
+            toks = json.loads(r.stdout.decode().strip().splitlines()[-1])["tokens"]
+            if best is None or m["tok_s"] > best[0]["tok_s"]:
+                best = (m, toks)
+        m, toks = best
+        gold = golden_argmax(name, seed)
+        return {"value": round(m["tok_s"], 2), "unit": "tokens/s", "tokens_timed": m["tokens_timed"], "timer": m["timer"], "hbm_frac": round(m["hbm_frac"], 4),
+                "how": "node host/l2_run.mjs --loop host --metrics (N-API addon -> C ABI), best of 2 runs",
+                "equal_to_reference_golden": (None if gold is None else toks == gold[:len(toks)])}
+    except Exception as e:   # noqa: BLE001
+        return {"value": None, "why": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
 # ---- parity of the run that was timed ---------------------------------------------------------------------------
 def golden_argmax(name, seed):
     """The tokens the REAL reference chose on this synthetic checkpoint (tests/golden/<config>.json, written by
@@ -268,8 +358,7 @@ def js_port_baseline(name, hdr, seed):
     if not node:
         return {"value": None, "why": "no node on this box"}
     if configs.checkpoint_bytes(hdr) > (2 << 30):
-        return {"value": None, "why": "checkpoint of %.0f GB: writing and reading it back would take minutes (reference_js_tok_s quotes the build container's run)"
-                % (configs.checkpoint_bytes(hdr) / 2.0 ** 30)}
+        return js_port_in_process(name, hdr, seed, node)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     ref = reference_js_figure(name).get("reference_js_tok_s") or 5.0
@@ -292,6 +381,32 @@ def js_port_baseline(name, hdr, seed):
             os.remove(path)
         except OSError:
             pass
+
+
+def js_port_in_process(name, hdr, seed, node):
+    """The same for a checkpoint too large to go through a file (Llama-2-7B: 27 GB): llama2_oracle.mjs --synth fills its typed arrays
+    IN PROCESS with the repo's generator restated in JavaScript (pinned per tensor against oracle_cli's bytes by
+    tests/test_oracle_golden.py), then times 3 tokens after the first like llama2.ts:507, 511.  Needs the model + KV caches in host
+    memory; generating 6.7e9 values in one JS thread takes a couple of minutes, outside the timed region."""
+    need_gb = configs.checkpoint_bytes(hdr) / 2.0 ** 30 + 2.0 * hdr[2] * hdr[6] * hdr[0] * 4 / 2.0 ** 30 + 4.0
+    if mem_available_gb() < need_gb:
+        return {"value": None, "why": "MemAvailable %.0f GB < the %.0f GB the full model needs in this process" % (mem_available_gb(), need_gb)}
+    if os.environ.get("L2_BENCH_SKIP_JS_7B"):
+        return {"value": None, "why": "skipped (L2_BENCH_SKIP_JS_7B)"}
+    steps = 4
+    try:
+        r = subprocess.run([node, "--max-old-space-size=4096", os.path.join(ROOT, "oracle", "llama2_oracle.mjs"), "--synth", ",".join(str(v) for v in list(hdr) + [seed]), str(steps)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+        if r.returncode != 0:
+            return {"value": None, "why": "node failed: %s" % r.stderr.decode("utf8", "replace")[-200:]}
+        j = json.loads(r.stdout.decode())
+        gold = golden_argmax(name, seed)
+        return {"value": round(j["tok_s"], 4), "unit": "tokens/s", "cores": 1, "kind": "port", "runtime": "node %s on this box" % j.get("node"),
+                "sample": "oracle/llama2_oracle.mjs --synth (weights generated in process, %.0f s), %d greedy tokens from BOS on the full %s shape, clock started after the first"
+                          % (j.get("load_s") or 0.0, steps, name),
+                "tokens_equal_reference_golden": (None if gold is None else j["tokens"] == gold[:steps])}
+    except Exception as e:   # noqa: BLE001
+        return {"value": None, "why": "%s: %s" % (type(e).__name__, e)}
 
 
 def host_cpu_model():
@@ -373,15 +488,11 @@ def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None):
            "hbm_frac_end_to_end": round(bpt * K / wall / 1e9 / HBM_PEAK_GBS, 4),
            "parity": parity}
     # the same K steps through the blocking drop-in boundary (llama2.ts:468 -> 478: logits to the host every token, argmax there)
-    tok = 1
-    ctx.forward(1, 0)
-    t0 = time.perf_counter()
-    dropin_tokens = []
-    for pos in range(K):
-        tok = int(np.argmax(ctx.forward(tok, pos, view=True)))
-        dropin_tokens.append(tok)
-    out["dropin_tok_s"] = round(K / (time.perf_counter() - t0), 2)
+    rate, dropin_tokens = dropin_loop(ctx, K)
+    out["dropin_tok_s"] = round(rate, 2)
     out["parity"]["dropin_equal_to_reference_golden"] = parity_block(name, seed, dropin_tokens)["equal_to_reference_golden"]
+    out["napi_dropin_tok_s"] = napi_dropin(ctx, name, seed, K)               # ... and through the N-API addon under Node (the contract's binding)
+    out["dropin_tok_s_direct_dispatch_off"] = dropin_direct_dispatch_off(name, seed)
     out["roofline"] = roofline_block(ctx, cfg, K, traffic[0], traffic[1], trace_us)
     out["per_kernel"] = per_kernel_block(ctx, cfg)      # back-to-back launches of each GEMV phase: us and GB/s of its matrix bytes
     S = hdr[6]
@@ -478,6 +589,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dropin-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     # the host driver of this pool only supports dmabuf IPC: without this, RCCL and hipIpcGetMemHandle fail in ranks a launcher
     # other than spawn_ranks() started (set before the first HIP call of the process)
@@ -487,6 +599,9 @@ def main():
         return
     if args.trace_child:
         trace_child(args.config, args.seed)
+        return
+    if args.dropin_child:
+        dropin_child(args.config, args.seed)
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -725,15 +840,12 @@ def main():
         out["note"] = tp_note
     if extras:
         if not args.no_dropin:   # the same K steps through the blocking drop-in boundary (logits to the host every token)
-            tok = 1
-            ctx.forward(1, 0)
-            t0 = time.perf_counter()
-            dropin_tokens = []
-            for pos in range(K):
-                tok = int(np.argmax(ctx.forward(tok, pos, view=True)))
-                dropin_tokens.append(tok)
-            out["dropin_tok_s"] = round(K / (time.perf_counter() - t0), 3)
+            rate, dropin_tokens = dropin_loop(ctx, K)
+            out["dropin_tok_s"] = round(rate, 3)
             out["parity"]["dropin_equal_to_reference_golden"] = parity_block(args.config, args.seed, dropin_tokens)["equal_to_reference_golden"]
+            out["napi_dropin_tok_s"] = napi_dropin(ctx, args.config, args.seed, K)      # the N-API addon under Node (small models: the 7B file is not written)
+            if configs.checkpoint_bytes(hdr) < (2 << 30):
+                out["dropin_tok_s_direct_dispatch_off"] = dropin_direct_dispatch_off(args.config, args.seed)
         out["roofline"] = roofline_block(ctx, cfg, K, *traffic[args.config], trace_us.get(args.config))
         out["per_kernel"] = per_kernel_block(ctx, cfg)
         S = hdr[6]

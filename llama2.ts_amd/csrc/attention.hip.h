@@ -100,7 +100,10 @@ __host__ __device__ inline size_t attn_tile_lds(int S, int nsplit, int NW, int N
 // are requested at once like always (the descriptor ends at row pos: the row being written reads as zeros and contributes
 // nothing); q, then k and v of row pos come as granules: the score of row pos is one wave's dot product of the q and k granules,
 // its share of the output att[pos] * v[pos] is added where the partial sums are folded -- fp64, one rounding, like every other row.
-template <int LR, int NW, int NT, bool FUSED = false>
+// MULTI: the workgroup's rows may take more than one round of NW * NT tiles (A / B register sets, the next round in flight while this
+// one is used).  Only the half-size body is ever built that way (attn_tile_dispatch): with both 16-tile sets live ACROSS a loop the
+// instance needed 255 VGPRs + 64 AGPRs as spill space (216 register copies in the loop); a single-round body drops the loop code.
+template <int LR, int NW, int NT, bool FUSED = false, bool MULTI = true>
 __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, const int h, const int sp, const int pos) {
   constexpr int RPT = 64 / LR;             // rows per tile
   constexpr int RG = NT * RPT;         // rows per wave per round
@@ -119,7 +122,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   const int chunk = attn_chunk(a, T);
   const int t0 = sp * chunk, t1 = min(T, t0 + chunk);
   const int n = max(t1 - t0, 0);                       // rows of this workgroup
-  const int rounds = (n + RR - 1) / RR;
+  const int rounds = MULTI ? (n + RR - 1) / RR : 1;
   const int r = lane / LR, c = lane % LR;
   const bool cl = 4 * c < hs;                           // lanes past the head's width carry zeros
   const int cc4 = cl ? 4 * c : 0;
@@ -146,7 +149,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   issue(ra, false, 0);
   f4 q4;
   if (!FUSED) q4 = *reinterpret_cast<const f4*>(a.q + (size_t)h * hs + cc4);
-  if (rounds <= 1) issue(rb, true, 0);
+  if (!MULTI || rounds <= 1) issue(rb, true, 0);
   // FUSED: the cache tiles are in flight; now ONE wait for everything of this position the lane will need: its four q values,
   // and -- the wave that scores row pos -- q[i] and k[i], and -- the threads that fold the output -- v[i] (hs <= 64: one each)
   float gk_q = 0.0f, gk_k = 0.0f, gv = 0.0f;
@@ -198,7 +201,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       if (lane == 0) sc[n - 1] = (float)(s * rsq);
     }
   }
-  if (rounds <= 1) {
+  if (!MULTI || rounds <= 1) {
     score_round(ra, 0);
   } else {
     for (int rd = 0; rd < rounds; rd += 2) {        // A / B register sets: the next round is in flight while this one is used
@@ -271,7 +274,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       else { o0 += at * (double)buf[j].x; o1 += at * (double)buf[j].y; o2 += at * (double)buf[j].z; o3 += at * (double)buf[j].w; }
     }
   };
-  if (rounds <= 1) {
+  if (!MULTI || rounds <= 1) {
     value_round(rb, 0);
   } else {
     for (int rd = 0; rd < rounds; rd += 2) {
@@ -386,9 +389,10 @@ __device__ __forceinline__ void attn_tile_dispatch(const AttnArgs& a, char* smem
   const int chunk = attn_chunk(a, T);
   const int n = min(T, sp * chunk + chunk) - sp * chunk;
   constexpr int RQ = NW * (NT / 4) * (64 / LR);
-  if (n <= RQ) attn_tile_body<LR, NW, NT / 4, FUSED>(a, smem, h, sp, pos);
-  else if (n <= 2 * RQ) attn_tile_body<LR, NW, NT / 2, FUSED>(a, smem, h, sp, pos);
-  else attn_tile_body<LR, NW, NT, FUSED>(a, smem, h, sp, pos);
+  if (n <= RQ) attn_tile_body<LR, NW, NT / 4, FUSED, false>(a, smem, h, sp, pos);
+  else if (n <= 2 * RQ) attn_tile_body<LR, NW, NT / 2, FUSED, false>(a, smem, h, sp, pos);
+  else if (n <= 4 * RQ) attn_tile_body<LR, NW, NT, FUSED, false>(a, smem, h, sp, pos);
+  else attn_tile_body<LR, NW, NT / 2, FUSED, true>(a, smem, h, sp, pos);      // several rounds: half-size register sets (see attn_tile_body)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -105,7 +105,7 @@ __global__ void loop_sum_kernel(double* out, const LoopPtrs in, int G, int n) {
 
 // one-shot peer-to-peer exchange (kernels and protocol: tp_p2p_* below)
 enum { P2P_MAXG = 8, P2P_FB = 64 };   // ranks; flag words per (parity, source): blocks of the widest exchange
-struct P2PPeers { unsigned long long* flags[P2P_MAXG]; double* inbox[P2P_MAXG]; float* logits[P2P_MAXG]; };
+struct P2PPeers { unsigned long long* flags[P2P_MAXG]; double* inbox[P2P_MAXG]; float* logits[P2P_MAXG]; unsigned long long* gin[P2P_MAXG]; };   // gin: granule inbox (pushed partials)
 struct P2PArgs {
   P2PPeers pr;
   unsigned long long* epoch;   // this rank's exchange counters, one per block
@@ -146,6 +146,8 @@ struct l2_ctx {
   P2PPeers p2p_peers = {};
   std::vector<void*> p2p_opened;     // IPC mappings to close
   bool p2p_peers_ready = false;
+  TpPush* tp_push = nullptr;         // device table of the peers' granule inboxes for the GEMV epilogues (kernels.hip.h: tp_push_row)
+  int opt_push = 1;                  // L2_TP_PUSH=0: partials through c->partial and the flag exchange (round-4 form; A/B, development switch)
   bool rccl_graph = false;           // the RCCL collectives of the step are captured into the per-token hipGraph (cleared if capture is refused)
   unsigned long long p2p_wait_ticks = 3000000000ull;   // L2_TP_WAIT_S (default 30 s) on the 100 MHz clock
   int p2p_fenced = 0;                // L2_TP_FENCED=1: the peer-to-peer exchange with system-scope fences around its flags

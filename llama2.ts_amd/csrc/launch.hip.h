@@ -151,15 +151,17 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   // the repacked copy is only good for the geometry it was packed for (U = 2: the only batch width with more than one batch per row)
   if (a.wp && !(g.U == 2 && g.U == c->packed[MODE].U && g.nwaves == c->packed[MODE].nwaves && g.grid == c->packed[MODE].grid)) a.wp = nullptr;
   if (!a.wp && !a.w0) return hipErrorInvalidValue;       // one copy of the weights: the row-major tensor is gone and this launch cannot read the repacked one
-#define L2_LAUNCH(UU, PP) do { if (UU == 2 && a.wp) { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, 2, PP, true>, lds); if (e_ != hipSuccess) return e_; \
-                                                      launch_probed(c, phase_kernel<MODE, 2, 2, PP, true>, grid, block, lds, st, a, MODE == MODE_W13); } \
-                               else { hipError_t e_ = lds_opt_in(&phase_kernel<MODE, 2, UU, PP>, lds); if (e_ != hipSuccess) return e_; \
-                                      launch_probed(c, phase_kernel<MODE, 2, UU, PP>, grid, block, lds, st, a, MODE == MODE_W13); } } while (0)
+  // (tensor-parallel push: an instance of its own for wo / w2, see phase_body)
+#define L2_LAUNCH_K(KERNEL) do { hipError_t e_ = lds_opt_in(&KERNEL, lds); if (e_ != hipSuccess) return e_; launch_probed(c, KERNEL, grid, block, lds, st, a, MODE == MODE_W13); } while (0)
+#define L2_LAUNCH(UU, PP) do { if constexpr (MODE == MODE_WO || MODE == MODE_W2) { if (a.push) { if (UU == 2 && a.wp) L2_LAUNCH_K((phase_kernel<MODE, 2, 2, PP, true, true>)); \
+                                                                                                else L2_LAUNCH_K((phase_kernel<MODE, 2, UU, PP, false, true>)); break; } } \
+                               if (UU == 2 && a.wp) L2_LAUNCH_K((phase_kernel<MODE, 2, 2, PP, true>)); else L2_LAUNCH_K((phase_kernel<MODE, 2, UU, PP>)); } while (0)
 #define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else if (g.pre == 4) L2_LAUNCH(UU, 4); else L2_LAUNCH(UU, 12); } while (0)
   if (g.U == 3) { if constexpr (MODE == MODE_CLS) { L2_LAUNCH_U(3); } }
   else if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
 #undef L2_LAUNCH_U
 #undef L2_LAUNCH
+#undef L2_LAUNCH_K
   return hipGetLastError();
 }
 

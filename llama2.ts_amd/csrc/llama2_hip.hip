@@ -93,6 +93,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   for (void* m : c->p2p_opened) hipIpcCloseMemHandle(m);
   if (c->p2p_base) hipFree(c->p2p_base);
   if (c->p2p_epoch) hipFree(c->p2p_epoch);
+  if (c->tp_push) hipFree(c->tp_push);
   if (c->p2p_err) hipHostFree(c->p2p_err);
   l2s::destroy(&c->samp);
   for (int k = 0; k < L2_T_COUNT; ++k)
@@ -124,6 +125,8 @@ static int ensure_rowmajor(l2_ctx* c, bool unpack);
 static int p2p_alloc(l2_ctx* c);
 static int p2p_connect_ipc(l2_ctx* c);
 static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits);
+static int p2p_publish_table(l2_ctx* c);
+static bool p2p_pushing(const l2_ctx* c);
 
 static int create_impl(const int32_t cfg[7], int device, int rank, int G, const void* nccl_id, l2_ctx** out, unsigned flags = 0) {
   if (!cfg || !out) return fail(L2_E_ARG, "null argument");
@@ -172,6 +175,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !hook_int("L2_TP_FORCE_COMM")) ? 1 : 0);
   c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
   c->p2p_fenced = env_int("L2_TP_FENCED", 0) ? 1 : 0;
+  c->opt_push = dev_int("L2_TP_PUSH", 1) && !c->p2p_fenced;      // (the fenced form is the flag exchange)
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
@@ -265,6 +269,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     c->solo = true;
     for (int r = 0; r < G; ++r) p2p_set_peer(c, r, c->p2p_base, c->logits);
     c->p2p = true; c->p2p_peers_ready = true; c->p2p_synced = true;
+    { const int rc_ = p2p_publish_table(c); if (rc_) { l2_destroy(c); return rc_; } }
   } else if (G > 1 && hook_int("L2_TP_NO_COMM")) {
     // shard-layout tests on a single GPU: the slices are real, the communicator is absent and every
     // forward on this context fails with L2_E_COMM
@@ -436,6 +441,7 @@ static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (lla
   a.in = c->xb; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; a.res = c->x; a.out = c->x; a.aux = c->opt_keep_state ? c->xb2 : nullptr;
   a.n = c->d_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
+  if (p2p_pushing(c)) { a.push = c->tp_push; a.push_epoch = c->p2p_epoch; }      // rows go straight into the peers' inboxes (tp_exchange.hip.h)
   a.wp = packed_of(c, MODE_WO, l);
   return a;
 }
@@ -455,6 +461,7 @@ static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (lla
   a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = (c->tp_path || !c->opt_keep_state) ? nullptr : c->xb;
   a.n = c->h_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
+  if (p2p_pushing(c)) { a.push = c->tp_push; a.push_epoch = c->p2p_epoch; }
   a.wp = packed_of(c, MODE_W2, l);
   return a;
 }

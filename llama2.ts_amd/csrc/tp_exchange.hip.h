@@ -110,6 +110,50 @@ __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, con
   p2p_end(a, e, tid);
 }
 
+// The pushed form of the same exchange (round 5): the wo / w2 GEMV's own waves have already stored every row's fp64 partial into
+// every peer's granule inbox (kernels.hip.h: tp_push_row -- two tagged 8-byte halves in one 16-byte system-scope store, the data is
+// its own flag), the moment the row was reduced: what is left for this launch is to wait for the G granule pairs of every element in
+// the LOCAL inbox, add them in rank order, round once, add the residual.  No payload load + G stores, no drain, no flag round trip
+// (4.5 us -> ~3 for a rank alone on its GPU), and on a node the xGMI hop runs while the GEMV's later rows are still being computed.
+// Slots alternate by the exchange's parity exactly as the flag form's do (a rank cannot push exchange e + 2 before every peer has
+// finished reading e: e + 1 needs their contribution first, and they push that only after their own e is combined).
+__global__ void __launch_bounds__(256) tp_p2p_combine_kernel(const P2PArgs a, float* x, const float* res_emb, float* mv_out, const int* tokpos) {
+  const int tid = threadIdx.x, stride = gridDim.x * 256;
+  const unsigned long long e = p2p_begin(a);
+  const unsigned tag = (unsigned)e;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.pr.gin[a.rank], 0, (unsigned)((size_t)2 * P2P_MAXG * a.n * 16), 0x00020000);
+  for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
+    const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : x[i];      // requested before the wait
+    const unsigned base = (unsigned)(((size_t)((unsigned)(e & 1) * P2P_MAXG) * a.n + i) * 16);
+    u32x4 g[P2P_MAXG];
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+#pragma unroll
+      for (int r = 0; r < P2P_MAXG; ++r)      // all requested at once; sources beyond G re-read source 0
+        g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)(r < a.G ? r : 0) * (unsigned)a.n * 16u, 0, 17));      // aux 17 = sc0 sc1
+      bool ok = true;
+#pragma unroll
+      for (int r = 0; r < P2P_MAXG; ++r) ok = ok & (g[r].y == tag) & (g[r].w == tag);
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255u) == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (!t0) t0 = now;
+        else if (now - t0 > a.wait_ticks) { *a.err = 1; break; }
+      }
+    }
+    double s = __longlong_as_double((long long)(((unsigned long long)g[0].z << 32) | g[0].x));
+#pragma unroll
+    for (int r = 1; r < P2P_MAXG; ++r)
+      if (r < a.G) s += __longlong_as_double((long long)(((unsigned long long)g[r].z << 32) | g[r].x));      // rank order on every rank
+    const float mv = (float)s;
+    x[i] = xr + mv;
+    if (mv_out) mv_out[i] = mv;
+  }
+  p2p_end(a, e, tid);
+}
+
 // all-gather of the logits slices: every rank writes its V/G floats into every peer's (uncached) logits vector
 template <int PART>
 __global__ void __launch_bounds__(256) tp_p2p_gather_kernel(const P2PArgs a, const float* mine) {
@@ -137,12 +181,25 @@ __global__ void tp_residual_kernel(float* x, const float* res_emb, const double*
 }
 
 // ---- peer-to-peer exchange: setup -----------------------------------------------------------------------------
-static size_t p2p_bytes(const l2_ctx* c) { return (size_t)2 * P2P_MAXG * P2P_FB * 8 + (size_t)2 * P2P_MAXG * c->d * 8; }
+// flags | inbox of fp64 partials (flag exchange) | inbox of granule pairs (pushed partials: 16 bytes per element)
+static size_t p2p_bytes(const l2_ctx* c) { return (size_t)2 * P2P_MAXG * P2P_FB * 8 + (size_t)2 * P2P_MAXG * c->d * 8 + (size_t)2 * P2P_MAXG * c->d * 16; }
 static void p2p_set_peer(l2_ctx* c, int r, void* base, float* logits) {
   c->p2p_peers.flags[r] = (unsigned long long*)base;
   c->p2p_peers.inbox[r] = (double*)((char*)base + (size_t)2 * P2P_MAXG * P2P_FB * 8);
+  c->p2p_peers.gin[r] = (unsigned long long*)((char*)base + (size_t)2 * P2P_MAXG * P2P_FB * 8 + (size_t)2 * P2P_MAXG * c->d * 8);
   c->p2p_peers.logits[r] = logits;
 }
+// the device table the GEMV epilogues read (once every peer is known)
+static int p2p_publish_table(l2_ctx* c) {
+  TpPush t;
+  memset(&t, 0, sizeof(t));
+  for (int r = 0; r < c->G && r < P2P_MAXG; ++r) t.gin[r] = c->p2p_peers.gin[r];
+  t.G = c->G; t.rank = c->rank; t.n = c->d; t.solo = c->solo ? 1 : 0;
+  if (!c->tp_push) HIPCHK(hipMalloc(&c->tp_push, sizeof(TpPush)));
+  HIPCHK(hipMemcpy(c->tp_push, &t, sizeof(t), hipMemcpyHostToDevice));
+  return L2_OK;
+}
+static bool p2p_pushing(const l2_ctx* c) { return c->p2p && !c->loop && c->opt_push && c->tp_push; }
 static P2PArgs p2p_args(const l2_ctx* c, int n) {
   P2PArgs a;
   a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = nullptr; a.err = c->p2p_err_dev;
@@ -174,6 +231,15 @@ enum { NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_MIN = 3 };
 __global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { partial[i] = (double)((rank + 1) * (k + 1)) + 0.5 * (double)i; x[i] = 0.0f; }
+}
+// the pushed form's stand-in for a GEMV epilogue: one wave per 64 elements, lane r < G hands element i to rank r (kernels.hip.h: tp_push_row)
+__global__ void p2p_selftest_push(const TpPush* p, const unsigned long long* epoch, float* x, int rank, int n, int k) {
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const PushCtx pc = tp_push_ctx(p, epoch, lane);
+  for (int j = 0; j < 64; ++j) {
+    const int i = wave * 64 + j;
+    if (i < n) { tp_push_row(pc, i, (double)((rank + 1) * (k + 1)) + 0.5 * (double)i, lane); if (lane == 0) x[i] = 0.0f; }
+  }
 }
 // ... and the check of what the exchange left in x, on the device: the soak below runs its exchanges back to back, like the
 // decode step does, not one per host round trip
@@ -262,15 +328,26 @@ static int p2p_connect_ipc(l2_ctx* c) {
     c->p2p_opened.push_back(pb); c->p2p_opened.push_back(pl);
     p2p_set_peer(c, r, pb, (float*)pl);
   }
+  if (ok && p2p_publish_table(c)) ok = false;
   // every rank learns whether every rank mapped everything BEFORE anybody waits on a peer
   int h_ok = ok ? 1 : 0;
   { const int rc_ = all_min(h_ok, &h_ok); if (rc_) return rc_; }
   if (h_ok) {   // four exchanges (each inbox slot is reused once) on known vectors: sum over ranks of ((rank + 1)(k + 1) + i / 2)
     const int n = c->d;
     std::vector<float> got(n);
+    // (the form the decode step will use: rows pushed by the "GEMV" + the combine launch, or partials + the flag exchange)
+    auto exchange = [&](int k) {
+      if (p2p_pushing(c)) {
+        hipLaunchKernelGGL(p2p_selftest_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->tp_push, c->p2p_epoch, c->xb2, c->rank, n, k);
+        hipLaunchKernelGGL(tp_p2p_combine_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->xb2, nullptr, nullptr, c->tokpos);
+      } else {
+        hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
+        hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
+      }
+    };
+    c->p2p = true;      // (p2p_pushing looks at it; settled below)
     for (int k = 0; k < 4 && h_ok; ++k) {
-      hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
-      hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
+      exchange(k);
       HIPCHK(hipStreamSynchronize(c->stream));
       HIPCHK(hipMemcpy(got.data(), c->xb2, (size_t)n * 4, hipMemcpyDeviceToHost));
       if (*c->p2p_err) h_ok = 0;
@@ -288,8 +365,7 @@ static int p2p_connect_ipc(l2_ctx* c) {
       HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
       const int nl = c->V_loc;
       for (int k = 4; k < 100; ++k) {
-        hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
-        hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
+        exchange(k);
         hipLaunchKernelGGL(p2p_selftest_check, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->xb2, G, n, k, d_bad);
         if (k % 3 == 0) {
           hipLaunchKernelGGL(p2p_selftest_fill_logits, dim3((nl + 255) / 256), dim3(256), 0, c->stream, c->logits_loc, c->rank, nl, k);
@@ -350,7 +426,9 @@ static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
 // runs its two halves around a host barrier instead (see tp_p2p_reduce_kernel)
 static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out) {
   const dim3 grid(p2p_grid(c->d));
-  if (!c->loop) {
+  if (p2p_pushing(c)) {
+    hipLaunchKernelGGL(tp_p2p_combine_kernel, grid, dim3(256), 0, st, p2p_args(c, c->d), c->x, res_emb, mv_out, c->tokpos);
+  } else if (!c->loop) {
     hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
   } else {
     hipLaunchKernelGGL(tp_p2p_reduce_kernel<1>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);

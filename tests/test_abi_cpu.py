@@ -139,3 +139,14 @@ def test_no_shipped_kernel_spills_registers(tmp_path):
             elif m.get("sgpr_spill_count"):
                 print("scalar registers kept in VGPR lanes:", m["sgpr_spill_count"], name)
     assert kernels > 100 and not bad, bad
+    # ... and none of them parks vector registers in the accumulator file: AGPRs are the MFMA kernels' accumulators; in a kernel with no
+    # MFMA a v_accvgpr_write is hipcc using them as spill space beyond 256 VGPRs (no scratch, so the metadata above says nothing:
+    # round 4's 16-tile attention instances carried 216 such copies in their multi-round loop)
+    parked = []
+    for o in objs:
+        dis = subprocess.check_output([objdump, "-d", "--no-show-raw-insn", str(tmp_path / o)]).decode()
+        for blk in re.split(r"\n(?=[0-9a-f]{16} <)", dis):
+            m = re.match(r"[0-9a-f]{16} <([^>]+)>:", blk)
+            if m and "v_accvgpr_write" in blk and "v_mfma" not in blk:
+                parked.append((m.group(1), blk.count("v_accvgpr_write"), blk.count("v_accvgpr_read")))
+    assert not parked, parked
