@@ -196,7 +196,11 @@ def dropin_direct_dispatch_off(name, seed):
         r = subprocess.run(cmd, env=clean_child_env(AMD_DIRECT_DISPATCH="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         j = json.loads(r.stdout.decode().strip().splitlines()[-1])
         gold = golden_argmax(name, seed)
-        return {"value": j["dropin_tok_s"], "env": "AMD_DIRECT_DISPATCH=0", "equal_to_reference_golden": (None if gold is None else j["tokens"] == gold[:len(j["tokens"])])}
+        same = None if gold is None else j["tokens"] == gold[:len(j["tokens"])]
+        out = {"value": j["dropin_tok_s"], "env": "AMD_DIRECT_DISPATCH=0", "equal_to_reference_golden": same}
+        if same is False:
+            out["first_mismatch"] = next(i for i, (a, b) in enumerate(zip(j["tokens"], gold)) if a != b)
+        return out
     except Exception as e:   # noqa: BLE001 -- a side measurement must not fail the benchmark
         return {"value": None, "why": "%s: %s" % (type(e).__name__, e)}
 

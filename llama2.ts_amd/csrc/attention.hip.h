@@ -44,8 +44,18 @@ struct AttnArgs {
   int fused_four_waves;            // fused launch: contexts of up to 128 rows on four waves (else eight)
   int* herr;                       // host-mapped: set when a granule wait gave up
   unsigned long long wait_ticks;   // bound of that wait on the 100 MHz clock
+  // fused attention + wo launch of a tensor-parallel rank (attn_wo_kernel): the output is ALSO published as granules for the wo
+  // workgroups of the same launch; tag = *gout_ep + 1 (advanced by the launch after this one: tp_p2p_combine_kernel)
+  unsigned long long* gout;
+  const unsigned* gout_ep;
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
 };
+
+// the attention output, element i of head h: RunState.xb, and the hand-off granule when a workgroup of this launch waits for it
+__device__ __forceinline__ void attn_out(const AttnArgs& a, size_t idx, float v, unsigned otag) {
+  if (a.gout) granule_store(a.gout + idx, v, otag);      // first: a workgroup of this launch waits for it
+  a.xb[idx] = v;
+}
 
 // A wave's wait for its hand-off granules (fused launch): every lane has up to N words to collect; all L1-bypassing loads of a pass
 // are issued together (ONE round trip per pass), and the wave leaves when every lane has every value.  Bounded by wall time: the
@@ -169,6 +179,8 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   }
   const double q0 = cl ? (double)q4.x : 0.0, q1 = cl ? (double)q4.y : 0.0, q2 = cl ? (double)q4.z : 0.0, q3 = cl ? (double)q4.w : 0.0;
   const double rsq = a.inv_sqrt_hs;             // 1 / sqrt(head_size), rounded once by the host (llama2.ts:253 divides)
+  // (requested here, used at the very end: the launch counter the output granules' tag comes from)
+  const unsigned otag = a.gout ? __hip_atomic_load(a.gout_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
   double* Pw = P + (size_t)wave * NT * ATT_PS;
   STAMP(1);
 
@@ -260,7 +272,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       const float* vp = a.vc + (size_t)hk * hs + i;
       float o = 0.0f;
       for (int t = 0; t < n; ++t) o = (float)((double)o + (double)sc[t] * (double)vp[(size_t)t * dim]);
-      a.xb[(size_t)h * hs + i] = o;
+      attn_out(a, (size_t)h * hs + i, o, otag);
     }
     return;
   }
@@ -305,7 +317,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       double own = 0.0;
       if (FUSED) { if (own_pos) own = (double)sc[n - 1] * (double)gv; }      // hs <= 64 <= NTH: i == tid
       if (FUSED) a.xb[(size_t)h * hs + i] = (float)(((c0 + c1) + (c2 + c3)) + own);   // ONE rounding of the fp64 sum
-      else a.xb[(size_t)h * hs + i] = (float)((c0 + c1) + (c2 + c3));
+      else attn_out(a, (size_t)h * hs + i, (float)((c0 + c1) + (c2 + c3)), otag);
     }
     STAMP(5);
     if (FUSED) fused_head_done(a, h, ftag, tid);
@@ -354,7 +366,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
         const double w = (k < NS) ? exp_fast(mm[k] - M) : 0.0;
         Lsum += w * ll[k]; num += w * aa[k];
       }
-      a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
+      attn_out(a, (size_t)h * hs + i, (float)(num / Lsum), otag);
     }
   } else {
     double M = -INFINITY;
@@ -364,7 +376,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
     for (int i = tid; i < hs; i += NTH) {
       double num = 0.0;
       for (int s2 = 0; s2 < NS; ++s2) num += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + i);
-      a.xb[(size_t)h * hs + i] = (float)(num / Lsum);
+      attn_out(a, (size_t)h * hs + i, (float)(num / Lsum), otag);
     }
   }
   if (a.att) {                                          // probabilities for parity reads of RunState.att (L2_OPT_KEEP_ATT)
@@ -429,6 +441,24 @@ __global__ void __launch_bounds__(512) qkv_attn_small_kernel(const PhaseArgs a, 
     return;
   }
   attn_tile_dispatch<LR, 8, NT, true>(at, smem, h, sp, pos);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ONE launch for attention and the wo GEMV of a TENSOR-PARALLEL rank (llama2.ts:244-267 -> 270).  wo is column-sharded, so a rank's
+// wo reads only the outputs of the rank's own H / G heads: the first `nattn` workgroups are those heads' attention workgroups
+// (the plain tile kernel, its output ALSO published as granules), the others are the latency-form wo phase whose x wave gathers the
+// d / G granules while its compute waves' weights -- which depend on nothing -- arrive: the rank's whole wo shard (8 MB at 8 ranks)
+// streams while the chip would otherwise idle behind four attention workgroups, and one launch boundary goes.  Rows leave through
+// tp_push_row like those of the wo launch.  Producers have the lower block ids (dispatched first); the wait is bounded anyway.
+template <int XV, int R, int LR, int NW, int NT>
+__global__ void __launch_bounds__(512) attn_wo_kernel(const AttnArgs at, const PhaseArgs wo, const int nattn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x >= nattn) { phase_small_body<MODE_WO, XV, R, true>(wo, smem, (int)blockIdx.x - nattn, (int)gridDim.x - nattn); return; }
+  if (NW * 64 < 512 && (int)threadIdx.x >= NW * 64) return;          // (a four-wave attention form in an eight-wave launch)
+  int sp = 0, h = (int)blockIdx.x;
+  while (h >= at.n_heads) { h -= at.n_heads; ++sp; }
+  const int pos = at.tokpos[1];
+  attn_tile_dispatch<LR, NW, NT>(at, smem, h, sp, pos);
 }
 
 template <int LR, int NW, int NT>

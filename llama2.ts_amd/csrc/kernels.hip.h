@@ -110,6 +110,13 @@ struct PhaseArgs {
   unsigned long long* gran;  // QKV of the fused QKV + attention launch: [dim + 2 kv_dim] hand-off granules {value, tag} for q, k, v of this position, or null
   const unsigned* gran_ep;   // per head: the launch counter the granule tags of that head come from (tag = gran_ep[h] + 1)
   unsigned gran_hmagic;      // ceil(2^20 / head_size): row / head_size without a division
+  // fused attention + wo launch of a tensor-parallel rank (attention.hip.h: attn_wo_kernel): the input vector arrives as granules from
+  // the attention workgroups of the SAME launch; tag = *gin_ep + 1 (the launch after this one advances the counter)
+  const unsigned long long* gin;
+  const unsigned* gin_ep;
+  int* gin_herr;
+  unsigned long long gin_wait_ticks;
+  int gin_nap;               // s_sleep between two sweeps of the x wave (0: none)
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
   unsigned long long* dbg_wg;  // the same: {start, end} of every workgroup
 };
@@ -151,6 +158,43 @@ __device__ __forceinline__ void tp_push_row(const PushCtx& c, int i, double v, i
 // itself advances when its last head is done), so a granule of an earlier launch never matches and nothing has to be zeroed.
 __device__ __forceinline__ void granule_store(unsigned long long* g, float v, unsigned tag) {
   __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Consumer side of a vector handed over as granules: float4 number u * 64 + lane of the vector, u < NU, = four consecutive granules =
+// two 16-byte loads past L1 (sc1); ALL loads of a pass are requested together, a pass is repeated until every lane has `tag` on all of
+// its granules.  Lanes past the vector's end re-read its last float4 (and see the same tags).  Bounded on the 100 MHz clock:
+// false = gave up (*herr is set).  Only ONE wave of a workgroup ever does this (MI355X guide, row polling-cost).
+typedef unsigned gu4 __attribute__((ext_vector_type(4)));
+template <int NU>
+__device__ __forceinline__ bool granules_gather_f4(const unsigned long long* g, int n, int lane, unsigned tag, f4 (&xr)[NU], int* herr, unsigned long long wait_ticks, int nap) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(g), 0, (unsigned)n * 8u, 0x00020000);
+  const int n4 = n >> 2;
+  unsigned off[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) off[u] = (unsigned)min(u * 64 + lane, n4 - 1) * 32u;
+  unsigned spins = 0;
+  unsigned long long t0 = 0;
+  for (;;) {
+    gu4 lo[NU], hi[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      lo[u] = __builtin_bit_cast(gu4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u], 0, 16));           // aux 16 = sc1
+      hi[u] = __builtin_bit_cast(gu4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + 16u, 0, 16));
+    }
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      ok = ok & (lo[u].y == tag) & (lo[u].w == tag) & (hi[u].y == tag) & (hi[u].w == tag);      // (bitwise: no branch per granule)
+      xr[u].x = __uint_as_float(lo[u].x); xr[u].y = __uint_as_float(lo[u].z); xr[u].z = __uint_as_float(hi[u].x); xr[u].w = __uint_as_float(hi[u].z);
+    }
+    if (__all(ok)) return true;
+    if (nap == 1) __builtin_amdgcn_s_sleep(4); else if (nap == 2) __builtin_amdgcn_s_sleep(16);      // (a long wait: fewer sweeps in the producers' way)
+    if ((++spins & 63u) == 0) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (!t0) t0 = now;
+      else if (now - t0 > wait_ticks) { if (lane == 0) *herr = 1; return false; }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -750,7 +794,9 @@ __global__ void __launch_bounds__(256) unpack_kernel(const PhaseArgs a, const f4
 //   * a wave's first two row groups are requested before the barrier, with the epilogue operands of each group
 //     (RoPE entries, residual value) behind them, so nothing is requested after a reduction.
 // Numerics are those of the streaming form: fp64 accumulate, one fp32 rounding per stored element.
-template <int MODE, int XV, int R>
+// GIN: the input vector is handed over as granules by workgroups of the same launch (a.gin): the x wave -- and only it -- polls them,
+// behind the compute waves' weight requests (those do not depend on the input: by the time the producers are done they have landed).
+template <int MODE, int XV, int R, bool GIN = false>
 __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem, const int vblock, const int vgrid) {
   constexpr int NC = 7;                             // compute waves; wave 0 is the x wave
   f4* xs4 = reinterpret_cast<f4*>(smem);            // 64 * XV float4, zero padded
@@ -788,8 +834,13 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   if (wave == 0) {
     const float* src = a.in;
     if (MODE == MODE_QKV) { if (a.emb) src = a.emb + (size_t)a.tokpos[0] * n; }   // only layer 0 waits for the token
+    if (GIN) {
+      const unsigned gtag_in = __hip_atomic_load(a.gin_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      granules_gather_f4<XV>(a.gin, n, lane, gtag_in, xr, a.gin_herr, a.gin_wait_ticks, a.gin_nap);
+    } else {
 #pragma unroll
-    for (int u = 0; u < XV; ++u) xr[u] = reinterpret_cast<const f4*>(src)[min(u * 64 + lane, n4 - 1)];
+      for (int u = 0; u < XV; ++u) xr[u] = reinterpret_cast<const f4*>(src)[min(u * 64 + lane, n4 - 1)];
+    }
     if (mode_has_norm<MODE>()) {
 #pragma unroll
       for (int u = 0; u < XV; ++u) wr[u] = reinterpret_cast<const f4*>(a.rmsw)[min(u * 64 + lane, n4 - 1)];

@@ -277,3 +277,35 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // att
   if (c->opt_exact) a.nsplit = 1;
   return launch_attn_tile(c, a, a.nsplit, -1, st);
 }
+
+// ---- the fused attention + wo launch of a tensor-parallel rank (attention.hip.h: attn_wo_kernel) ------------------------------
+// Taken when the rank's wo shard is the latency form with an input of 512 / 1024 / 2048 floats (Llama-2-7B at 8 / 4 / 2 ranks), heads
+// are 128 wide (the eight-wave tile kernel), the rows leave through the peer-to-peer push (the combine launch behind it advances
+// the launch counter) and the reference's own value accumulate is not asked for.  L2_TP_ATTN_WO=0 keeps the two launches.
+static bool attn_wo_ok(const l2_ctx* c) {
+  if (!c->opt_awo || !c->tp_path || !p2p_pushing(c) || !c->awo_gran || c->opt_exact || !attn_vec(c)) return false;
+  if (c->hs != 128 || attn_nw(c) != 8 || !use_small(c, MODE_WO, c->d, c->d_loc) || c->d <= c->n_cus * 7) return false;
+  const int xv = (c->d_loc / 4 + 63) / 64;
+  if (!(xv == 2 || xv == 4 || xv == 8) || c->d_loc % 256) return false;
+  return c->H_loc * c->cur_splits * 2 <= c->n_cus && (size_t)attn_tile_lds(c->S, c->cur_splits, 8, 8) <= 160 * 1024;
+}
+
+static hipError_t launch_attn_wo(const l2_ctx* c, int l, const PhaseArgs& wo_in, hipStream_t st) {
+  AttnArgs at;
+  fill_attn_args(c, l, at);
+  at.gout = c->awo_gran; at.gout_ep = c->awo_ep;
+  PhaseArgs wo = wo_in;
+  wo.gin = c->awo_gran; wo.gin_ep = c->awo_ep; wo.gin_herr = c->h_herr_dev; wo.gin_wait_ticks = 200000000ull; wo.gin_nap = c->awo_nap;
+  const int nattn = c->H_loc * at.nsplit, xv = (c->d_loc / 4 + 63) / 64;
+  const int groups = (wo.rows + 1) / 2;
+  int nwo = c->n_cus - nattn;                 // one workgroup per CU, the attention workgroups' CUs left to them
+  if (nwo < c->n_cus / 2) nwo = c->n_cus / 2;
+  if (nwo > groups) nwo = groups;
+  const size_t lds_a = attn_tile_lds(c->S, at.nsplit, 8, 8), lds_w = (size_t)xv * 64 * 16, lds = lds_a > lds_w ? lds_a : lds_w;
+  const dim3 grid(nattn + nwo), block(512);
+#define L2_AWO(XVV) do { hipError_t e_ = lds_opt_in(&attn_wo_kernel<XVV, 2, 32, 8, 8>, lds); if (e_ != hipSuccess) return e_; \
+                         hipLaunchKernelGGL((attn_wo_kernel<XVV, 2, 32, 8, 8>), grid, block, lds, st, at, wo, nattn); } while (0)
+  if (xv == 2) L2_AWO(2); else if (xv == 4) L2_AWO(4); else L2_AWO(8);
+#undef L2_AWO
+  return hipGetLastError();
+}

@@ -94,6 +94,8 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->p2p_base) hipFree(c->p2p_base);
   if (c->p2p_epoch) hipFree(c->p2p_epoch);
   if (c->tp_push) hipFree(c->tp_push);
+  if (c->awo_gran) hipFree(c->awo_gran);
+  if (c->awo_ep) hipFree(c->awo_ep);
   if (c->p2p_err) hipHostFree(c->p2p_err);
   l2s::destroy(&c->samp);
   for (int k = 0; k < L2_T_COUNT; ++k)
@@ -176,6 +178,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
   c->p2p_fenced = env_int("L2_TP_FENCED", 0) ? 1 : 0;
   c->opt_push = dev_int("L2_TP_PUSH", 1) && !c->p2p_fenced;      // (the fenced form is the flag exchange)
+  c->opt_awo = dev_int("L2_TP_ATTN_WO", 1);
+  c->awo_nap = dev_int("L2_TP_AWO_NAP", 1);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
@@ -207,6 +211,10 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   if (c->tp_path) CK(hipExtMallocWithFlags((void**)&c->logits, (size_t)V * 4, hipDeviceMallocUncached));
   else CK(hipMalloc(&c->logits, (size_t)V * 4));
   if (c->tp_path) { CK(hipMalloc(&c->logits_loc, (size_t)c->V_loc * 4)); CK(hipMalloc(&c->partial, (size_t)d * 8)); }
+  if (c->tp_path) {
+    CK(hipMalloc(&c->awo_gran, (size_t)c->d_loc * 8)); CK(hipMemsetAsync(c->awo_gran, 0, (size_t)c->d_loc * 8, c->stream));
+    CK(hipMalloc(&c->awo_ep, 16)); CK(hipMemsetAsync(c->awo_ep, 0, 16, c->stream));
+  }
   else c->logits_loc = c->logits;
   CK(hipMalloc(&c->kc, kv * 4)); CK(hipMalloc(&c->vc, kv * 4));
   CK(hipMemsetAsync(c->kc, 0, kv * 4, c->stream)); CK(hipMemsetAsync(c->vc, 0, kv * 4, c->stream));
@@ -626,12 +634,20 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
       LCHK(launch_qkv_attn(c, a, l, st));        // the head-local edge inside one launch (attention.hip.h: qkv_attn_small_kernel)
     } else {
       LCHK(launch_phase<MODE_QKV>(c, a, st));
-      LCHK(launch_attn(c, l, st));
+      if (attn_wo_ok(c)) {
+        LCHK(launch_attn_wo(c, l, wo_args(c, l), st));      // attention and the rank's wo shard in ONE launch (attention.hip.h: attn_wo_kernel)
+      } else {
+        LCHK(launch_attn(c, l, st));
+        a = wo_args(c, l);
+        LCHK(launch_phase<MODE_WO>(c, a, st));
+      }
     }
-    a = wo_args(c, l);
-    LCHK(launch_phase<MODE_WO>(c, a, st));
+    if (fused_qkv_attn_ok(c)) {
+      a = wo_args(c, l);
+      LCHK(launch_phase<MODE_WO>(c, a, st));
+    }
     if (c->p2p) {
-      const int rc_ = p2p_reduce(c, st, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->opt_keep_state ? c->xb2 : nullptr);
+      const int rc_ = p2p_reduce(c, st, (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr, c->opt_keep_state ? c->xb2 : nullptr, attn_wo_ok(c) ? c->awo_ep : nullptr);
       if (rc_) return rc_;
     } else if (c->tp_path) {
       { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }
@@ -643,7 +659,7 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
     a = w2_args(c, l);
     LCHK(launch_phase<MODE_W2>(c, a, st));
     if (c->p2p) {
-      const int rc_ = p2p_reduce(c, st, nullptr, nullptr);
+      const int rc_ = p2p_reduce(c, st, nullptr, nullptr, nullptr);
       if (rc_) return rc_;
     } else if (c->tp_path) {
       { const int rc_ = tp_all_reduce(c, st); if (rc_) return rc_; }

@@ -117,8 +117,11 @@ __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, con
 // (4.5 us -> ~3 for a rank alone on its GPU), and on a node the xGMI hop runs while the GEMV's later rows are still being computed.
 // Slots alternate by the exchange's parity exactly as the flag form's do (a rank cannot push exchange e + 2 before every peer has
 // finished reading e: e + 1 needs their contribution first, and they push that only after their own e is combined).
-__global__ void __launch_bounds__(256) tp_p2p_combine_kernel(const P2PArgs a, float* x, const float* res_emb, float* mv_out, const int* tokpos) {
+__global__ void __launch_bounds__(256) tp_p2p_combine_kernel(const P2PArgs a, float* x, const float* res_emb, float* mv_out, const int* tokpos, unsigned* bump) {
   const int tid = threadIdx.x, stride = gridDim.x * 256;
+  // the launch counter of the fused attention + wo launch in front of this one: every workgroup of that launch has read it (the
+  // launch is over), the next one reads the new number
+  if (bump && blockIdx.x == 0 && tid == 0) *bump = *bump + 1u;
   const unsigned long long e = p2p_begin(a);
   const unsigned tag = (unsigned)e;
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.pr.gin[a.rank], 0, (unsigned)((size_t)2 * P2P_MAXG * a.n * 16), 0x00020000);
@@ -339,7 +342,7 @@ static int p2p_connect_ipc(l2_ctx* c) {
     auto exchange = [&](int k) {
       if (p2p_pushing(c)) {
         hipLaunchKernelGGL(p2p_selftest_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->tp_push, c->p2p_epoch, c->xb2, c->rank, n, k);
-        hipLaunchKernelGGL(tp_p2p_combine_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->xb2, nullptr, nullptr, c->tokpos);
+        hipLaunchKernelGGL(tp_p2p_combine_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->xb2, nullptr, nullptr, c->tokpos, (unsigned*)nullptr);
       } else {
         hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
         hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
@@ -424,10 +427,10 @@ static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
 
 // one all-reduce + residual of the tensor-parallel step: ONE kernel; the loopback test group (all ranks on one GPU)
 // runs its two halves around a host barrier instead (see tp_p2p_reduce_kernel)
-static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out) {
+static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out, unsigned* bump) {
   const dim3 grid(p2p_grid(c->d));
   if (p2p_pushing(c)) {
-    hipLaunchKernelGGL(tp_p2p_combine_kernel, grid, dim3(256), 0, st, p2p_args(c, c->d), c->x, res_emb, mv_out, c->tokpos);
+    hipLaunchKernelGGL(tp_p2p_combine_kernel, grid, dim3(256), 0, st, p2p_args(c, c->d), c->x, res_emb, mv_out, c->tokpos, bump);
   } else if (!c->loop) {
     hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
   } else {

@@ -68,16 +68,21 @@ function hash32(a) {
   a ^= a >>> 16; a = Math.imul(a, 0x7feb352d); a ^= a >>> 15; a = Math.imul(a, 0x846ca68b); a ^= a >>> 16;
   return a >>> 0;
 }
-/** out[i] = bias + fl(c(g0 + i) * scale), c = a centred sum of four 16-bit uniforms hashed from the element's index in the float stream. */
+/** out[i] = bias + fl(c(g0 + i) * scale), c = a centred sum of four 16-bit uniforms hashed from the element's index in the float stream.
+ *  (One thread, like everything here: V8 ran the forward pass ~15 % slower in a process that had filled its arrays from worker threads,
+ *  whatever the arrays were backed by -- a baseline must not carry that.  The three hashes are written out: ~7 ns per element.) */
 function synthFill(out, g0, seed, scale, bias) {
   const sk = Math.imul(seed, 0x9E3779B9) ^ 0x85ebca6b;
   const n = out.length;
-  let lo = g0 % 4294967296, hi = Math.floor(g0 / 4294967296), k = hash32(hi ^ sk);
+  let lo = g0 % 4294967296, hi = Math.floor(g0 / 4294967296), k = hash32(hi ^ sk) | 0;
   for (let i = 0; i < n; ++i) {
-    const h1 = hash32((lo ^ k) >>> 0), h2 = hash32((h1 + 0x9E3779B9) >>> 0);
-    const c = (h1 & 0xffff) + (h1 >>> 16) + (h2 & 0xffff) + (h2 >>> 16) - 131070;
+    let a = (lo ^ k) | 0;
+    a ^= a >>> 16; a = Math.imul(a, 0x7feb352d); a ^= a >>> 15; a = Math.imul(a, 0x846ca68b); a ^= a >>> 16;      // h1 = hash32(lo ^ k)
+    let b = (a + 0x9E3779B9) | 0;
+    b ^= b >>> 16; b = Math.imul(b, 0x7feb352d); b ^= b >>> 15; b = Math.imul(b, 0x846ca68b); b ^= b >>> 16;      // h2 = hash32(h1 + golden)
+    const c = (a & 0xffff) + (a >>> 16) + (b & 0xffff) + (b >>> 16) - 131070;
     out[i] = bias + Math.fround(c * scale);             // the product rounded to fp32, the sum rounded by the store
-    if (++lo == 4294967296) { lo = 0; ++hi; k = hash32(hi ^ sk); }
+    if (++lo == 4294967296) { lo = 0; ++hi; k = hash32(hi ^ sk) | 0; }
   }
 }
 function detExp(x) {                                    // x in [-10, 0], IEEE basic operations only

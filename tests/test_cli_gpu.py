@@ -120,8 +120,9 @@ def test_metrics_line_on_stderr(workdir):
         m = json.loads([l for l in err.splitlines() if l.startswith("{")][-1])["metrics"]
         hdr = json.load(open(os.path.join(GOLD, "cli_greedy.json")))["header"]
         n = m["tokens_timed"]
-        assert n == int(flags["-n"]) and m["loop"] == loop and m["hbm_peak_gb_s"] == 8000
-        want_bytes = sum(configs.algorithmic_bytes_per_token(tuple(hdr), p) for p in range(n)) / n
+        # the clock starts after the first iteration, like the reference's (llama2.ts:507): positions 1 .. n are the timed ones
+        assert n == int(flags["-n"]) - 1 and m["loop"] == loop and m["hbm_peak_gb_s"] == 8000 and "llama2.ts:507" in m["timer"]
+        want_bytes = sum(configs.algorithmic_bytes_per_token(tuple(hdr), p) for p in range(1, n + 1)) / n
         assert abs(m["algorithmic_bytes_per_token"] - want_bytes) <= 1
         assert m["tok_s"] > 0 and abs(m["hbm_gb_s"] - m["tok_s"] * m["algorithmic_bytes_per_token"] / 1e9) / m["hbm_gb_s"] < 1e-3
         assert abs(m["hbm_frac"] - m["hbm_gb_s"] / 8000) < 1e-9

@@ -154,3 +154,35 @@ def test_js_restatement_is_bit_identical_to_the_reference(name, steps, tmp_path)
     j = json.loads(r.stdout.decode())
     assert j["steps"] == steps and j["sha256"] == meta["logits_sha256"][:steps]
     assert j["tokens"] == meta["argmax"][:steps]
+
+
+@pytest.mark.parametrize("name,steps", [("stories15M", 12), ("ragged", 8)])
+def test_js_in_process_generator_equals_the_checkpoint_file(name, steps, tmp_path):
+    """llama2_oracle.mjs --synth fills its typed arrays in process (bench.py's js_port leg at Llama-2-7B: a 27 GB checkpoint cannot go
+    through a file in a benchmark's time): the generator restated in JavaScript must produce, tensor by tensor, the bytes the C
+    generator writes into a checkpoint file (oracle_cli synth / orc_synth_write) -- sha256 per tensor in checkpoint order, the RoPE
+    tables included -- and the forward pass over them the real reference's logits (sha256 per step) and tokens."""
+    import shutil
+    import subprocess
+    if shutil.which("node") is None:
+        pytest.skip("no node")
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    hdr, seed = meta["header"], meta["seed"]
+    ck = str(tmp_path / "m.bin")
+    O.synth_write(hdr, seed, ck)
+    d, h, L, H, _kv, V, S = hdr
+    shared, V = V > 0, abs(V)
+    hs2 = (d // H) // 2
+    counts = [V * d, L * d, L * d * d, L * d * d, L * d * d, L * d * d, L * d, L * h * d, L * d * h, L * h * d, d, S * hs2, S * hs2] + ([] if shared else [V * d])
+    want = []
+    with open(ck, "rb") as f:
+        f.seek(28)
+        for n in counts:
+            want.append(hashlib.sha256(f.read(4 * n)).hexdigest())
+        assert f.read(1) == b""
+    r = subprocess.run(["node", os.path.join(ROOT, "oracle", "llama2_oracle.mjs"), "--synth", ",".join(str(v) for v in list(hdr) + [seed]), str(steps), "--sha", "--tensor-sha"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    j = json.loads(r.stdout.decode())
+    assert j["tensor_sha256"] == want
+    assert j["sha256"] == meta["logits_sha256"][:steps] and j["tokens"] == meta["argmax"][:steps]
