@@ -199,7 +199,10 @@ def dropin_direct_dispatch_off(name, seed):
         same = None if gold is None else j["tokens"] == gold[:len(j["tokens"])]
         out = {"value": j["dropin_tok_s"], "env": "AMD_DIRECT_DISPATCH=0", "equal_to_reference_golden": same}
         if same is False:
+            # seen on ROCm 7.2 (round 5): under AMD_DIRECT_DISPATCH=0 the blocking call hands back logits of the wrong step from the
+            # second token on (with and without the zero-copy logits) -- the rate above is then not a measurement of this path
             out["first_mismatch"] = next(i for i, (a, b) in enumerate(zip(j["tokens"], gold)) if a != b)
+            out["note"] = "tokens differ from the reference under this runtime setting: not a configuration to deploy; the rate is not comparable"
         return out
     except Exception as e:   # noqa: BLE001 -- a side measurement must not fail the benchmark
         return {"value": None, "why": "%s: %s" % (type(e).__name__, e)}
