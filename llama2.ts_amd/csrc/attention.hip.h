@@ -403,7 +403,7 @@ __device__ __forceinline__ void attn_tile_dispatch(const AttnArgs& a, char* smem
   constexpr int RQ = NW * (NT / 4) * (64 / LR);
   if (n <= RQ) attn_tile_body<LR, NW, NT / 4, FUSED, false>(a, smem, h, sp, pos);
   else if (n <= 2 * RQ) attn_tile_body<LR, NW, NT / 2, FUSED, false>(a, smem, h, sp, pos);
-  else if (n <= 4 * RQ) attn_tile_body<LR, NW, NT, FUSED, false>(a, smem, h, sp, pos);
+  else if (FUSED || n <= 4 * RQ) attn_tile_body<LR, NW, NT, FUSED, false>(a, smem, h, sp, pos);      // (the fused launch is only taken while one round covers the rows: launch.hip.h)
   else attn_tile_body<LR, NW, NT / 2, FUSED, true>(a, smem, h, sp, pos);      // several rounds: half-size register sets (see attn_tile_body)
 }
 

@@ -181,13 +181,11 @@ struct l2_ctx {
   int attn_splits_forced = 0;       // L2_ATTN_SPLITS: fixed split count (tests); 0 = by position
   int pf3 = 1;                      // L2_PF3: 1 (default) register-blocked prefill GEMMs where the shape allows, 0: the 16-row-tile kernels everywhere (A/B, tests)
   int pf_attn = 1;                  // L2_PF_ATTN: 1 (default) prompt attention on the fp64 MFMA (16 queries per workgroup), 0: the decode kernel per (head, query)
-  int pf_lds = 1;                   // L2_PF_LDS: 0 = prefill GEMMs load weights in MFMA operand layout, 1 = QKV/WO/W2 through an LDS tile, 2 = W13 too
   int cur_splits = 1;               // split count of the step being enqueued / captured
   bool cur_fused = false;           // ... and whether its QKV + attention are the fused launch
   int fuse_min_rows = 0;            // L2_FUSE_MIN_ROWS: the fused launch from this many cached rows on (0 for inputs below 512 floats, else 128)
   int split_rows = 144;             // L2_ATTN_SPLIT_ROWS: cached rows of a head beyond which attention runs 8 workgroups per head
   bool split_rows_set = false;      // the switch was given: it also overrides the fused launch's 256
-  int attn_nw = 0;                  // L2_ATTN_NW: waves per attention workgroup (0: by head size)
   int small_max = 0;                // L2_SMALL_MAX: largest matrix (floats) that takes the latency-form GEMV
   int n_cus = 256;
   std::string ipc_dir;              // L2_TP_IPC_DIR: ranks are processes that meet through files (test hook)

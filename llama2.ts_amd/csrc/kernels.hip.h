@@ -137,7 +137,7 @@ __device__ __forceinline__ void tp_push_store(unsigned long long* slot, double v
 // What a wave needs to push its rows, fetched ONCE when the kernel starts (the table load must not queue behind the weight stream):
 // lane r's target inbox, the group's shape, the number of this exchange (read past L1: the launch before advanced it; a scalar load
 // would see a stale copy under graph replay).
-struct PushCtx { unsigned long long* gin; int G, rank, n, solo; unsigned e; };
+struct PushCtx { unsigned long long* gin = nullptr; int G = 0, rank = 0, n = 0, solo = 0; unsigned e = 0; };
 __device__ __forceinline__ PushCtx tp_push_ctx(const TpPush* p, const unsigned long long* epoch, int lane) {
   PushCtx c;
   // (uniform values pinned to scalar registers: the context lives through the whole GEMV loop, where vector registers are the budget)
@@ -411,7 +411,7 @@ __device__ __forceinline__ EpiPre epi_prefetch(const PhaseArgs& a, int g, int la
 // Epilogue of one row group; every lane holds every reduced sum, lane p finishes output / pair p.
 template <int MODE, int R, bool PREF>
 __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const double (&acc)[R], int lane, int token, int pos, const EpiPre& pre,
-                                             unsigned long long& best, const PushCtx* pc = nullptr) {
+                                             unsigned long long& best, const PushCtx& pc = PushCtx(), const bool pushing = false) {
   if (MODE == MODE_QKV) {
     int m, i0;
     qkv_group(a, g, R, m, i0);
@@ -469,11 +469,11 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
     }
   } else {  // WO / W2: matmul store then residual accum (llama2.ts:270-273, 292-295)
     const int row0 = g * R;
-    if (pc) {
+    if (pushing) {
       // tensor parallel, peer-to-peer exchange: every lane holds every sum; lane r hands row i to rank r
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        if (row0 + r < a.rows) tp_push_row(*pc, row0 + r, acc[r], lane);
+        if (row0 + r < a.rows) tp_push_row(pc, row0 + r, acc[r], lane);
       return;
     }
 #pragma unroll
@@ -538,7 +538,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
 
   STAMP_INIT_WG(a.dbg, a.dbg_wg);
   STAMP(0);
-  PushCtx pctx = {};
+  PushCtx pctx;
   constexpr bool pushing = PUSH && (MODE == MODE_WO || MODE == MODE_W2);
   if (pushing) pctx = tp_push_ctx(a.push, a.push_epoch, threadIdx.x & 63);
   f4 bufA[R][U], bufB[R][U];
@@ -685,7 +685,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
       for (int r = 0; r < R; ++r) pacc[r] = wave_sum(pacc[r]);
     }
     STAMP(6);
-    finish_group<MODE, R, false>(a, pend, pacc, lane, token, pos, nopre, best, pushing ? &pctx : nullptr);
+    finish_group<MODE, R, false>(a, pend, pacc, lane, token, pos, nopre, best, pctx, pushing);
     STAMP(7);
     pend = -1;
   };
@@ -809,7 +809,7 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   STAMP_INIT(a.dbg);
   STAMP(0);
   int token = 0, pos = 0;
-  PushCtx pctx = {};
+  PushCtx pctx;
   const bool pushing = (MODE == MODE_WO || MODE == MODE_W2) && a.push;
   if (pushing && wave != 0) pctx = tp_push_ctx(a.push, a.push_epoch, lane);
   f4 bufA[R][XV], bufB[R][XV];
@@ -930,7 +930,7 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
     }
     STAMP(6);
     unsigned long long nobest = 0;
-    finish_group<MODE, R, true>(a, gi, acc, lane, token, pos, pre, nobest, pushing ? &pctx : nullptr);
+    finish_group<MODE, R, true>(a, gi, acc, lane, token, pos, pre, nobest, pctx, pushing);
     STAMP(7);
   };
   for (int k = 0;; k += 2) {
@@ -997,10 +997,10 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
     { const EpiPre nopre = {0.0f, 0.0f, 0u};
-      PushCtx pctx = {};
+      PushCtx pctx;
       const bool pushing = (MODE == MODE_WO || MODE == MODE_W2) && a.push;
       if (pushing) pctx = tp_push_ctx(a.push, a.push_epoch, lane);
-      finish_group<MODE, R, false>(a, g, acc, lane, token, pos, nopre, best, pushing ? &pctx : nullptr); }
+      finish_group<MODE, R, false>(a, g, acc, lane, token, pos, nopre, best, pctx, pushing); }
   }
   if (MODE == MODE_CLS && a.amax) {   // as in phase_body
     best = wave_max_u64(best);

@@ -8,7 +8,17 @@
 // register sets always full (the per-workgroup prologue is then amortised as well).
 struct Geo { int R, U, pre, nwaves, grid; bool vec; };
 
-static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
+// The tuning knobs a context carries (development switches) and the chip: everything pick_geo needs besides the shape, so that the
+// selection is a pure function (l2_debug_pick_geo: a CPU test walks every shape of configs.py, the tensor-parallel shards and a few
+// hundred random ones through it and checks that each selected template point is one the library instantiates).
+struct GeoKnobs { int n_cus, tune_U, tune_nwaves, tune_gridcap; };
+static GeoKnobs geo_knobs(const l2_ctx* c) { return {c->n_cus, c->tune_U, c->tune_nwaves, c->tune_gridcap}; }
+
+// Template points of the streaming kernel: U (64-lane float4 sub-batches per row and batch) in {2, 4} -- 3 for classifiers of
+// 513 .. 768 columns -- and PRE (float4 per thread per staging round) in {1, 4, 12}.  (Round 5: U = 1 and PRE = 2 are gone -- a
+// row of at most 64 float4 takes the two-sub-batch kernel, whose second sub-batch re-reads the row's last float4 against zeros of x;
+// a vector of up to two rounds of float4 is staged by the four-per-thread round -- 116 -> 65 instances of this kernel.)
+static Geo pick_geo_pure(const GeoKnobs& kb, int mode, int rows, int n) {
   Geo g;
   g.vec = (n % 4) == 0;
   const int n4 = n / 4;
@@ -17,26 +27,25 @@ static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
   // U = 2..4 (8..16 KiB in flight per wave, <= 64 VGPRs => 8 waves per SIMD) reach 6.0-6.4 TB/s, R = 4 / U = 8
   // variants (more bytes per wave, fewer waves) stay below 5.5.
   g.R = 2;
-  (void)dim;
-  int U = (n4 <= 64) ? 1 : 2;                    // a short row is a single batch
+  int U = 2;
   if (n4 > 128 && n4 <= 256) U = 4;
   if (mode == MODE_CLS && n4 > 128 && n4 <= 192) U = 3;   // 768 columns (stories110M): three float4 per lane cover a row exactly; with U = 4 a quarter of the lanes re-read the last one (16.8 -> 16.5 us)
-  if (c->tune_U == 1 || c->tune_U == 2 || c->tune_U == 4 || (c->tune_U == 3 && mode == MODE_CLS)) U = c->tune_U;
+  if (kb.tune_U == 2 || kb.tune_U == 4 || (kb.tune_U == 3 && mode == MODE_CLS)) U = kb.tune_U;
   g.U = U;
   const int groups = (rows * pair + g.R - 1) / g.R;
   // 4 waves per workgroup from 512 row groups on (2 up to round 3: the q / k / v shard of an 8-rank group -- 768 groups -- runs
   // 9.0 -> 7.1 us with 4: fewer, fuller workgroups share the staged x; tools/tp_shard_sweep.py)
   g.nwaves = groups >= 512 ? 4 : (groups >= 256 ? 2 : 1);
-  if (c->tune_nwaves == 1 || c->tune_nwaves == 2 || c->tune_nwaves == 4) g.nwaves = c->tune_nwaves;
+  if (kb.tune_nwaves == 1 || kb.tune_nwaves == 2 || kb.tune_nwaves == 4) g.nwaves = kb.tune_nwaves;
   // staging: PRE float4 per thread per round, one round if it can cover the (padded) vector
   const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 64 * g.nwaves;
   // one staging round whenever 12 float4 per thread cover the vector (w2 of Llama-2-7B: 11008 floats = 2752 float4 on 256
   // threads): every extra round is one more dependent L2 round trip in front of the first FMA
-  g.pre = (npad4 <= nth) ? 1 : (npad4 <= 2 * nth ? 2 : (npad4 <= 4 * nth ? 4 : 12));
+  g.pre = (npad4 <= nth) ? 1 : (npad4 <= 4 * nth ? 4 : 12);
   int grid = (groups + g.nwaves - 1) / g.nwaves;
   // persistent grid: 2 workgroups (8 waves) per CU, each wave looping over row groups with both register sets
   // full, measured best on the 7B shapes (129.6 us of GEMV per layer vs 134.1 at 6 per CU)
-  const int cap = c->tune_gridcap > 0 ? c->tune_gridcap : c->n_cus * 2;
+  const int cap = kb.tune_gridcap > 0 ? kb.tune_gridcap : kb.n_cus * 2;
   if (grid > cap) {
     // balanced: every wave gets the same number k of row groups (w1/w3 of 7B: 5504 groups on 2048 waves would
     // leave a third of the chip idle in the last round; 459 workgroups x 4 waves x 3 groups covers it evenly).
@@ -50,6 +59,7 @@ static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) {
   g.grid = grid < 1 ? 1 : grid;
   return g;
 }
+static Geo pick_geo(const l2_ctx* c, int mode, int rows, int n, int dim) { (void)dim; return pick_geo_pure(geo_knobs(c), mode, rows, n); }
 
 #ifdef L2_STAMPS
 static int g_stamp_slot = 0;   // each launch of the enqueue gets its own 36-stamp slot
@@ -84,11 +94,30 @@ static void launch_probed(const l2_ctx* c, K kernel, dim3 grid, dim3 block, size
 
 // Latency form (kernels.hip.h: phase_small_kernel) for matrices of at most `small_max` floats whose input vector fits
 // 8 float4 per lane; everything else (Llama-2-7B's phases, every classifier) streams through phase_kernel.
-static bool use_small(const l2_ctx* c, int mode, int rows, int n) {
+static bool use_small_pure(long long small_max, int mode, int rows, int n) {
   if (n % 4 || n > 2048 || mode == MODE_CLS) return false;
   if (mode == MODE_W13 && n > 1536) return false;      // two matrices x 8 float4 of x per lane do not fit the register file (the instance spilled): stream
   const long long elems = (long long)rows * n * (mode == MODE_W13 ? 2 : 1);
-  return elems <= (long long)c->small_max;
+  return elems <= small_max;
+}
+static bool use_small(const l2_ctx* c, int mode, int rows, int n) { return use_small_pure((long long)c->small_max, mode, rows, n); }
+
+// What launch_phase would launch for a phase of `rows` x `n` (pure: no context, no GPU): out = {form, U or XV, PRE or R, waves per workgroup,
+// grid, packed-capable}; form 0 = streaming vector kernel, 1 = latency form, 2 = scalar kernel (n % 4 != 0).
+extern "C" int l2_debug_pick_geo(int mode, int rows, int n, int n_cus, int small_max, int out[6]) {
+  if (!out || mode < 0 || mode > MODE_CLS || rows <= 0 || n <= 0 || n_cus <= 0) return L2_E_ARG;
+  if (use_small_pure(small_max, mode, rows, n)) {
+    const int xv = (n / 4 + 63) / 64, xvt = xv <= 4 ? xv : (xv <= 6 ? 6 : 8);
+    const bool pair = (mode == MODE_QKV || mode == MODE_W13), r1 = !pair && rows <= n_cus * 7;
+    const int rpg = (mode == MODE_W13) ? 1 : (r1 ? 1 : 2), groups = (rows + rpg - 1) / rpg;
+    out[0] = 1; out[1] = xvt; out[2] = (!pair && r1) ? 1 : 2; out[3] = 8; out[4] = groups < n_cus ? groups : n_cus; out[5] = 0;
+    return L2_OK;
+  }
+  const GeoKnobs kb = {n_cus, 0, 0, 0};
+  const Geo g = pick_geo_pure(kb, mode, rows, n);
+  out[0] = g.vec ? 0 : 2; out[1] = g.U; out[2] = g.pre; out[3] = g.nwaves; out[4] = g.grid;
+  out[5] = (g.vec && g.U == 2 && (n / 4) % 64 == 0 && n / 4 > 128) ? 1 : 0;
+  return L2_OK;
 }
 
 template <int MODE, int XV>
@@ -153,12 +182,20 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   if (!a.wp && !a.w0) return hipErrorInvalidValue;       // one copy of the weights: the row-major tensor is gone and this launch cannot read the repacked one
   // (tensor-parallel push: an instance of its own for wo / w2, see phase_body)
 #define L2_LAUNCH_K(KERNEL) do { hipError_t e_ = lds_opt_in(&KERNEL, lds); if (e_ != hipSuccess) return e_; launch_probed(c, KERNEL, grid, block, lds, st, a, MODE == MODE_W13); } while (0)
-#define L2_LAUNCH(UU, PP) do { if constexpr (MODE == MODE_WO || MODE == MODE_W2) { if (a.push) { if (UU == 2 && a.wp) L2_LAUNCH_K((phase_kernel<MODE, 2, 2, PP, true, true>)); \
-                                                                                                else L2_LAUNCH_K((phase_kernel<MODE, 2, UU, PP, false, true>)); break; } } \
-                               if (UU == 2 && a.wp) L2_LAUNCH_K((phase_kernel<MODE, 2, 2, PP, true>)); else L2_LAUNCH_K((phase_kernel<MODE, 2, UU, PP>)); } while (0)
-#define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 2) L2_LAUNCH(UU, 2); else if (g.pre == 4) L2_LAUNCH(UU, 4); else L2_LAUNCH(UU, 12); } while (0)
-  if (g.U == 3) { if constexpr (MODE == MODE_CLS) { L2_LAUNCH_U(3); } }
-  else if (g.U == 1) L2_LAUNCH_U(1); else if (g.U == 2) L2_LAUNCH_U(2); else L2_LAUNCH_U(4);
+  // (a repacked row has more than 256 float4: its staging round is never the one-per-thread one -- no repacked instance with PRE = 1)
+#define L2_LAUNCH(UU, PP) do { constexpr bool pk_ = (UU == 2 && PP != 1); \
+                               if constexpr (MODE == MODE_WO || MODE == MODE_W2) { if (a.push) { \
+                                 if constexpr (pk_) { if (a.wp) { L2_LAUNCH_K((phase_kernel<MODE, 2, 2, PP, pk_, true>)); break; } } \
+                                 L2_LAUNCH_K((phase_kernel<MODE, 2, UU, PP, false, true>)); break; } } \
+                               if constexpr (pk_) { if (a.wp) { L2_LAUNCH_K((phase_kernel<MODE, 2, 2, PP, pk_>)); break; } } \
+                               if (a.wp) return hipErrorInvalidValue; \
+                               L2_LAUNCH_K((phase_kernel<MODE, 2, UU, PP>)); } while (0)
+#define L2_LAUNCH_U(UU) do { if (g.pre == 1) L2_LAUNCH(UU, 1); else if (g.pre == 4) L2_LAUNCH(UU, 4); else L2_LAUNCH(UU, 12); } while (0)
+  if (g.U == 3) { if constexpr (MODE == MODE_CLS) { if (g.pre == 1) L2_LAUNCH(3, 1); else L2_LAUNCH(3, 4); } }
+  else if (g.U == 2) L2_LAUNCH_U(2);
+  else if (g.pre == 1) L2_LAUNCH(4, 1);      // (a row of at most 256 float4 never needs more than four per thread ...
+  else if constexpr (MODE != MODE_QKV) L2_LAUNCH(4, 4);      //  ... and q / k / v of such a width have the 512 row groups that put four waves in a workgroup: one round)
+  else return hipErrorInvalidValue;
 #undef L2_LAUNCH_U
 #undef L2_LAUNCH
 #undef L2_LAUNCH_K
@@ -185,30 +222,26 @@ static void fill_attn_args(const l2_ctx* c, int l, AttnArgs& a) {
 // 65 .. 128 floats (a round is then 256 rows), else 4 -- heads wider than 128 (a whole wave per row) keep the 4-wave form:
 // their 8-wave instance needs more than 256 registers and spilled.
 static int attn_lr(int hs) { int l = 4; while (l * 4 < hs) l <<= 1; return l; }
-static int attn_nw(const l2_ctx* c) {
-  if (c->hs > 128) return 4;
-  return (c->attn_nw == 4 || c->attn_nw == 8) ? c->attn_nw : (c->hs > 64 ? 8 : 4);
-}
+static int attn_nw(const l2_ctx* c) { return (c->hs > 64 && c->hs <= 128) ? 8 : 4; }
 
 // One launch of the tile kernel; ny = splits (decode) or queries of the chunk (prefill, pos0 >= 0).
 static hipError_t launch_attn_tile(const l2_ctx* c, const AttnArgs& a, int ny, int pos0, hipStream_t st) {
   const int lr = attn_lr(c->hs), nw = attn_nw(c);
   const size_t lds = attn_tile_lds(c->S, pos0 >= 0 ? 1 : a.nsplit, nw, nw == 8 ? 8 : 16);
   const dim3 grid(c->H_loc, ny), block(64 * nw);
-  // 4 waves x 16 tiles (one wave per SIMD, ~290 registers) or 8 waves x 8 tiles (two per SIMD, <= 256 registers)
+  // 4 waves x 16 tiles (one wave per SIMD) for heads up to 64 floats and beyond 128, 8 waves x 8 tiles (two per SIMD) for 65 .. 128
 #define L2_AT(LR, NW, NT) do { if (pos0 >= 0) { hipError_t e_ = lds_opt_in(&pf_attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
                                             hipLaunchKernelGGL((pf_attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a, pos0); } \
                            else { hipError_t e_ = lds_opt_in(&attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
                                   hipLaunchKernelGGL((attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a); } } while (0)
-#define L2_AT_NW(LR) do { if (nw == 8) L2_AT(LR, 8, 8); else L2_AT(LR, 4, 16); } while (0)
+  (void)nw;      // (one form per row width: the L2_ATTN_NW override and its four extra instances per kernel went in round 5)
   switch (lr) {
-    case 4: L2_AT_NW(4); break;
-    case 8: L2_AT_NW(8); break;
-    case 16: L2_AT_NW(16); break;
-    case 32: L2_AT_NW(32); break;
-    default: L2_AT(64, 4, 16); break;     // attn_nw(): never 8 waves for these
+    case 4: L2_AT(4, 4, 16); break;
+    case 8: L2_AT(8, 4, 16); break;
+    case 16: L2_AT(16, 4, 16); break;
+    case 32: L2_AT(32, 8, 8); break;
+    default: L2_AT(64, 4, 16); break;
   }
-#undef L2_AT_NW
 #undef L2_AT
   return hipGetLastError();
 }

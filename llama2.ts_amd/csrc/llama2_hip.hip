@@ -72,7 +72,9 @@ static bool fused_shape_ok(const l2_ctx* c);
 static int split_level(const l2_ctx* c, int pos) {
   if (c->attn_splits_forced > 0 || c->opt_exact) return 0;
   const bool fusable = fused_shape_ok(c);
-  const int rows = pos + 1, unsplit_to = (c->split_rows_set || !fusable) ? c->split_rows : 256;
+  int unsplit_to = (c->split_rows_set || !fusable) ? c->split_rows : 256;
+  if (fusable && unsplit_to > 256) unsplit_to = 256;      // the fused launch's attention role is built for one round of rows (attention.hip.h: attn_tile_dispatch)
+  const int rows = pos + 1;
   if (rows > unsplit_to) return 2;
   return (fusable && rows > c->fuse_min_rows) ? 1 : 0;
 }
@@ -225,12 +227,10 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMemsetAsync(c->logits, 0, (size_t)V * 4, c->stream));
   // split attention scratch (sized for the largest split count)
   c->attn_splits_forced = dev_int("L2_ATTN_SPLITS", 0);
-  c->attn_nw = dev_int("L2_ATTN_NW", 0);
   c->split_rows = dev_int("L2_ATTN_SPLIT_ROWS", 144);
   c->split_rows_set = dev_int("L2_ATTN_SPLIT_ROWS", -1) >= 0;
   c->small_max = dev_int("L2_SMALL_MAX", 8 << 20);
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->pf_lds = dev_int("L2_PF_LDS", 1);
   c->pf3 = dev_int("L2_PF3", 1);
   c->pf_attn = dev_int("L2_PF_ATTN", 1);
   if (c->attn_splits_forced > 64) c->attn_splits_forced = 64;

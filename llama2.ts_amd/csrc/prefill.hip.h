@@ -274,86 +274,10 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm_kernel(const PfArgs a) {
   for (int t = 0; t < TT; ++t) pf_emit<MODE>(a, acc.a[t][0], acc.c[t][0], m, i0 + j, j, kq, 16 * t);
 }
 
-// The same GEMM with the weight tile taken through LDS.  pf_gemm_kernel's loads follow the MFMA operand layout: one
-// instruction = 16 rows x 64 B, and tools/microbench_pattern.hip shows that shape alone caps a pure stream at
-// 4.7 TB/s on this chip, against 6.0 TB/s for 1 KB-per-row instructions.  Here a wave requests its 16 x 128-column
-// chunk as 8 instructions of 2 rows x 512 contiguous bytes, parks it in a wave-private LDS tile (row stride 132
-// floats: both the row-shaped writes and the (row j, piece kq) reads are conflict-free) and reads the B fragments
-// back in MFMA layout.  Activations still come straight from L2 in operand layout.  Measured on 7B shapes: QKV
-// 60.6 -> 54.5 us, W2 56.5 -> 49.7, WO unchanged, W13 (two tiles per wave) 96 -> 99: the load shape was worth ~10 %,
-// the rest of the gap to the 33 us stream time is MFMA / widening time that the few resident waves do not overlap.
-template <int MODE, int NW, int TT>
-__global__ void __launch_bounds__(64 * NW) pf_gemm_lds_kernel(const PfArgs a) {
-  constexpr bool DUAL = (MODE == MODE_W13);
-  constexpr int KC = 128, KB = KC / 16, WS = KC + 4, TILE = 16 * WS;      // floats
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = a.n, nblk = n >> 4, nch = (n + KC - 1) / KC;
-  const int row0 = blockIdx.x * 16;
-  int m = 0, i0 = row0;
-  const float* wbase = a.w0;
-  if (MODE == MODE_QKV) { m = row0 / a.dim; i0 = row0 - m * a.dim; wbase = (m == 0) ? a.w0 : (m == 1) ? a.w1 : a.w2; }
-  const int j = lane & 15, kq = lane >> 4, lr = lane >> 5, lc = lane & 31;
-  const float* wl = wbase + (size_t)(i0 + lr) * n;                        // row-shaped: instruction i = rows 2i, 2i + 1
-  const float* wl3 = DUAL ? a.w1 + (size_t)(i0 + lr) * n : nullptr;
-  const float* xrow = a.xin + (size_t)j * n + 4 * kq;
-  float* tile = lds + (size_t)wave * (DUAL ? 2 : 1) * TILE;
-  float* tile3 = tile + TILE;
-  PfAcc<TT, DUAL> acc;
-  acc.clear();
-  struct Batch { f4 wv[KB], w3[DUAL ? KB : 1], xv[KB][TT]; };
-  auto load = [&](Batch& b, int p) {
-    const int pc = min(p, nch - 1);
-    const int col = min(pc * KC + 4 * lc, n - 4);                         // clamped, never predicated; masked in mma()
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      b.wv[i] = ldg_nt(wl + (size_t)(2 * i) * n + col);
-      if (DUAL) b.w3[i] = ldg_nt(wl3 + (size_t)(2 * i) * n + col);
-    }
-#pragma unroll
-    for (int u = 0; u < KB; ++u)
-#pragma unroll
-      for (int t = 0; t < TT; ++t) b.xv[u][t] = *reinterpret_cast<const f4*>(xrow + (size_t)16 * t * n + 16 * min(pc * KB + u, nblk - 1));
-  };
-  auto mma = [&](const Batch& b, int p) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      *reinterpret_cast<f4*>(tile + (2 * i + lr) * WS + 4 * lc) = b.wv[i];
-      if (DUAL) *reinterpret_cast<f4*>(tile3 + (2 * i + lr) * WS + 4 * lc) = b.w3[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                // the tile is written and read by one wave
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int u = 0; u < KB; ++u) {
-      if (p * KB + u < nblk) {
-        const f4 wv = *reinterpret_cast<const f4*>(tile + j * WS + 16 * u + 4 * kq);
-        f4 w3 = wv;
-        if (DUAL) w3 = *reinterpret_cast<const f4*>(tile3 + j * WS + 16 * u + 4 * kq);
-        acc.block(wv, w3, b.xv[u]);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-  Batch A, B;
-  int p0 = wave;
-  if (p0 < nch) load(A, p0);
-  while (p0 < nch) {
-    const int p1 = p0 + NW;
-    load(B, p1 < nch ? p1 : p0);
-    mma(A, p0);
-    if (p1 >= nch) break;
-    const int p2 = p1 + NW;
-    load(A, p2 < nch ? p2 : p1);
-    mma(B, p1);
-    p0 = p2;
-  }
-  __syncthreads();                                                          // tiles are dead: reuse the LDS for the split-K partials
-  if (!acc.template combine<NW>(reinterpret_cast<double*>(lds), wave, lane)) return;
-#pragma unroll
-  for (int t = 0; t < TT; ++t) pf_emit<MODE>(a, acc.a[t][0], acc.c[t][0], m, i0 + j, j, kq, 16 * t);
-}
-
+// (An LDS-tile variant of this kernel -- the weight chunk requested as 2 rows x 512 contiguous bytes per instruction and re-read in MFMA
+// layout from a wave-private tile: QKV 60.6 -> 54.5 us, W2 56.5 -> 49.7 at 7B width -- shipped until round 4 for chunks of at most 32
+// tokens over row-major tensors; with the register-blocked form below taking every 64-token chunk and the repacked copies not
+// row-shaped, it served short chunks of the small models only and was removed: profiles/r05/pruned_instances.txt.)
 
 // ------------------------------------------------------------------------------------------------
 // Register-blocked form.  On gfx950 v_mfma_f64_16x16x4_f64 IS the fp64 vector pipe (fp64 matrix peak = fp64 vector peak, 64

@@ -7,8 +7,8 @@ static bool can_prefill(const l2_ctx* c) {
   return !c->tp_path && c->kvd == c->d && (c->d % 16 == 0) && (c->h % 16 == 0) && (c->hs % 4 == 0) && attn_vec(c);
 }
 
-// One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1, 2 or 4).  QKV / WO / W2 take their weights through an LDS
-// tile by default (L2_PF_LDS: 0 never, 1 default, 2 W13 too -- its two tiles per wave measured slower).
+// One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1, 2 or 4).  (The 16-row-tile kernel's LDS-tile variant -- short chunks over
+// row-major tensors only -- went in round 5: 8 instances, one of them at 256 VGPRs + 134 AGPRs, for chunks of at most 32 tokens.)
 // register-blocked form (prefill.hip.h: pf_gemm3_kernel): RT row tiles per wave, 4 waves split K, `chunks` 64-token chunks per launch
 template <int MODE, int RT>
 static void launch_pf3(const PfArgs& a, int chunks, hipStream_t st) {
@@ -37,22 +37,6 @@ static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int
     }
   }
   const dim3 grid(a.rows / 16);
-  // (the LDS form reads row-shaped pieces of the row-major tensor: a repacked-only phase takes the operand-layout kernel)
-  // (four token tiles never take the LDS form: its 8-block register sets spilled -- 3200 vs 3490 tok/s -- and that instance is gone)
-  if (c->pf_lds >= ((MODE == MODE_W13) ? 2 : 1) && tt < 4 && !a.wp) {
-    const size_t tiles = (size_t)4 * ((MODE == MODE_W13) ? 2 : 1) * 16 * 132 * 4;
-    const size_t parts = (size_t)4 * 2 * 3 * 4 * 64 * 8;
-    const size_t lds = tiles > parts ? tiles : parts;
-    static bool attr = false;
-    if (!attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_lds_kernel<MODE, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
-    if (tt == 2) hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 2>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((pf_gemm_lds_kernel<MODE, 4, 1>), grid, dim3(256), lds, st, a);
-    return;
-  }
   // four waves split K (the eight-wave instances spilled and were never launched: removed)
   (void)nw;
   if (tt == 4) hipLaunchKernelGGL((pf_gemm_kernel<MODE, 4, 4>), grid, dim3(256), 0, st, a);

@@ -399,7 +399,7 @@ def test_prefill_equals_token_by_token(built, name, n):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("form", ["register-blocked", "16-row tiles", "16-row tiles, no LDS"])
+@pytest.mark.parametrize("form", ["register-blocked", "16-row tiles"])
 @pytest.mark.parametrize("name,n", [("stories110M", 128), ("stories110M", 256), ("llama2_7b_L2", 64), ("llama2_7b_L2", 128), ("llama2_7b_L2", 256)])
 def test_prefill_at_the_widths_the_bench_times(built, name, n, form, monkeypatch):
     """Prompt ingestion where bench.py reports `prefill_tok_s` (d = 4096 / h = 11008, and the 110M width): the first n
@@ -409,7 +409,6 @@ def test_prefill_at_the_widths_the_bench_times(built, name, n, form, monkeypatch
     reference's tokens through the next kept position.  Every form of the GEMMs: the register-blocked kernels (default: up to
     four 64-token chunks per launch) and the older 16-row-tile kernels with and without the LDS weight tile."""
     monkeypatch.setenv("L2_PF3", "1" if form == "register-blocked" else "0")
-    monkeypatch.setenv("L2_PF_LDS", "0" if form.endswith("no LDS") else "1")
     meta, g = load_gold(name)
     keep = {p: i for i, p in enumerate(meta["logit_positions"])}
     assert n - 1 in keep, "fixture keeps no logits at %d" % (n - 1)
@@ -703,14 +702,12 @@ def test_device_sampler_other_forms_reproduce_the_reference_run(monkeypatch, for
         ctx.close()
 
 
-@pytest.mark.parametrize("name,env", [("llama2_7b_L2", {"L2_ATTN_NW": "4"}), ("stories110M", {"L2_ATTN_NW": "8"}), ("stories15M", {"L2_ATTN_NW": "8"}),
-                                      ("stories110M", {"L2_SMALL_MAX": "0"}), ("stories15M", {"L2_SMALL_MAX": "0"}),
+@pytest.mark.parametrize("name,env", [("stories110M", {"L2_SMALL_MAX": "0"}), ("stories15M", {"L2_SMALL_MAX": "0"}),
                                       ("llama2_7b_L2", {"L2_TUNE_ROT": "0"}), ("llama2_7b_L2", {"L2_TUNE_ROT": "3"}),
                                       ("llama2_7b_L2", {"L2_PACKED": "0"}), ("llama2_7b_L2", {"L2_PACKED": "0", "L2_TUNE_ROT": "0"}),
                                       ("stories110M", {"L2_SMALL_MAX": "0", "L2_TUNE_ROT": "7"})])
 def test_launch_geometry_variants_match_reference(monkeypatch, name, env):
-    """The other geometry of the attention tile kernel (4 waves x 16 tiles / 8 waves x 8 tiles per round), the
-    streaming form of the GEMV phases on shapes that default to the latency form, other starting columns of its rows, and the
+    """The streaming form of the GEMV phases on shapes that default to the latency form, other starting columns of its rows, and the
     row-major tensors streamed instead of their repacked copies (the default at this width): same goldens, same tolerance,
     tokens exact."""
     for k, v in env.items():
