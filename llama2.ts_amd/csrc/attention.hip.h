@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnArgs a) {
   // behind it -- left alone, hipcc fetches the arguments in two dependent rounds before it even asks for pos (see qkv_attn_small_kernel)
   asm volatile("" ::"s"(a.q), "s"(a.kc), "s"(a.vc), "s"(a.att), "s"(a.xb), "s"(a.tokpos), "s"(a.part), "s"(a.counter));
   const int pos = a.tokpos[1];
-  asm volatile("" ::"s"(a.dim), "s"(a.head_size), "s"(a.seq_len), "s"(a.n_heads), "s"(a.nsplit), "s"(a.kv_dim), "s"(a.kv_mul), "s"(a.inv_sqrt_hs));
+  asm volatile("" ::"s"(a.dim), "s"(a.head_size), "s"(a.seq_len), "s"(a.n_heads), "s"(a.nsplit), "s"(a.kv_dim), "s"(a.kv_mul), "s"(a.inv_sqrt_hs), "s"(a.gout), "s"(a.gout_ep));
   attn_tile_dispatch<LR, NW, NT>(a, smem, blockIdx.x, blockIdx.y, pos);
 }
 

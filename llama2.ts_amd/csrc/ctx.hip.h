@@ -150,7 +150,6 @@ struct l2_ctx {
   unsigned long long* awo_gran = nullptr;   // [d / G] hand-off granules: the attention output of this rank's heads
   unsigned* awo_ep = nullptr;               // its launch counter (advanced by the combine launch that follows)
   int opt_awo = 1;                          // L2_TP_ATTN_WO=0: attention and wo as two launches (A/B, development switch)
-  int awo_nap = 1;                          // L2_TP_AWO_NAP: s_sleep between two sweeps of a wo workgroup's x wave (0 none, 1 short, 2 long)
   TpPush* tp_push = nullptr;         // device table of the peers' granule inboxes for the GEMV epilogues (kernels.hip.h: tp_push_row)
   int opt_push = 1;                  // L2_TP_PUSH=0: partials through c->partial and the flag exchange (round-4 form; A/B, development switch)
   bool rccl_graph = false;           // the RCCL collectives of the step are captured into the per-token hipGraph (cleared if capture is refused)

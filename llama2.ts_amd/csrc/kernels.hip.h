@@ -101,8 +101,7 @@ struct PhaseArgs {
   double* partial;    // non-null (WO/W2 of a tensor-parallel rank): out[i] is not written, partial[i] = fp64 sum
   // ... or, with the one-shot peer-to-peer exchange (tp_exchange.hip.h), pushed straight into every peer's inbox by the lanes of the
   // wave that reduced it: `push` = device table of the peers' inboxes, `push_epoch` = the exchange counter the tags come from
-  const struct TpPush* push;
-  const unsigned long long* push_epoch;
+  const struct TpPush* push;   // (the table also names the exchange counter the tags come from)
   double inv_n;       // 1.0 / n, correctly rounded by the host (rmsnorm's mean, llama2.ts:174)
   int rot;            // streaming form: row group g starts its rows at column batch (g * rot) % batches and wraps (0: every row from column 0)
   const float* wp;    // streaming form: this launch's matrix (matrices) repacked in the order the chip consumes it (pack_kernel), or null
@@ -110,20 +109,20 @@ struct PhaseArgs {
   unsigned long long* gran;  // QKV of the fused QKV + attention launch: [dim + 2 kv_dim] hand-off granules {value, tag} for q, k, v of this position, or null
   const unsigned* gran_ep;   // per head: the launch counter the granule tags of that head come from (tag = gran_ep[h] + 1)
   unsigned gran_hmagic;      // ceil(2^20 / head_size): row / head_size without a division
-  // fused attention + wo launch of a tensor-parallel rank (attention.hip.h: attn_wo_kernel): the input vector arrives as granules from
-  // the attention workgroups of the SAME launch; tag = *gin_ep + 1 (the launch after this one advances the counter)
-  const unsigned long long* gin;
-  const unsigned* gin_ep;
+  // fused attention + wo launch of a tensor-parallel rank (attention.hip.h: attn_wo_kernel; WO only): the input vector arrives as granules
+  // from the attention workgroups of the SAME launch -- `gran` are those granules, tag = *gran_ep + 1 (the launch after this one advances
+  // the counter), and a wait that gives up says so here
   int* gin_herr;
-  unsigned long long gin_wait_ticks;
-  int gin_nap;               // s_sleep between two sweeps of the x wave (0: none)
-  unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds), else null
-  unsigned long long* dbg_wg;  // the same: {start, end} of every workgroup
+#ifdef L2_STAMPS
+  unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds only: the argument block of the product build stays within four 64-byte
+  unsigned long long* dbg_wg;  // lines -- a fifth cost every launch of the small models ~0.1 us, 2 % of a stories110M token)
+#endif
 };
+static_assert(sizeof(void*) != 8 || sizeof(PhaseArgs) <= 224 + 16, "PhaseArgs: keep the kernel-argument block within four 64-byte lines");
 
 // Tensor-parallel push (tp_exchange.hip.h): where the fp64 partial of a row goes.  gin[r] = rank r's inbox of granule pairs,
 // [2 parities][MAXG sources][n] x 16 bytes, mapped into this process (uncached memory); in a shard-timing context every "peer" is this rank.
-struct TpPush { unsigned long long* gin[8]; int G, rank, n, solo; };
+struct TpPush { unsigned long long* gin[8]; const unsigned long long* epoch; int G, rank, n, solo; };
 
 // One fp64 partial = two hand-off granules {low word, tag}, {high word, tag} written by ONE 16-byte system-scope store (sc0 sc1: past
 // L1 and L2, over xGMI for a peer's memory); each 8-byte half is its own flag (MI355X guide, recipe R2: 8-byte halves of a 16-byte
@@ -138,13 +137,13 @@ __device__ __forceinline__ void tp_push_store(unsigned long long* slot, double v
 // lane r's target inbox, the group's shape, the number of this exchange (read past L1: the launch before advanced it; a scalar load
 // would see a stale copy under graph replay).
 struct PushCtx { unsigned long long* gin = nullptr; int G = 0, rank = 0, n = 0, solo = 0; unsigned e = 0; };
-__device__ __forceinline__ PushCtx tp_push_ctx(const TpPush* p, const unsigned long long* epoch, int lane) {
+__device__ __forceinline__ PushCtx tp_push_ctx(const TpPush* p, int lane) {
   PushCtx c;
   // (uniform values pinned to scalar registers: the context lives through the whole GEMV loop, where vector registers are the budget)
   c.G = __builtin_amdgcn_readfirstlane(p->G); c.rank = __builtin_amdgcn_readfirstlane(p->rank);
   c.n = __builtin_amdgcn_readfirstlane(p->n); c.solo = __builtin_amdgcn_readfirstlane(p->solo);
   c.gin = p->gin[c.solo ? c.rank : min(lane, c.G - 1)];
-  c.e = __builtin_amdgcn_readfirstlane((unsigned)__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+  c.e = __builtin_amdgcn_readfirstlane((unsigned)__hip_atomic_load(p->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
   return c;
 }
 // lane r < G of the wave that holds the reduced sum stores it into rank r's inbox, slot [parity of the exchange][this rank][row i]
@@ -540,7 +539,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   STAMP(0);
   PushCtx pctx;
   constexpr bool pushing = PUSH && (MODE == MODE_WO || MODE == MODE_W2);
-  if (pushing) pctx = tp_push_ctx(a.push, a.push_epoch, threadIdx.x & 63);
+  if (pushing) pctx = tp_push_ctx(a.push, threadIdx.x & 63);
   f4 bufA[R][U], bufB[R][U];
   const int ulast = (n4 - (nchunks - 1) * CPI) >> 6;   // PK: 64-lane sub-batches of a row's last batch
   // rnd (PK only) = which of its row groups the wave is at: gi = (place in the round) + rnd * wstride
@@ -810,8 +809,6 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   STAMP(0);
   int token = 0, pos = 0;
   PushCtx pctx;
-  const bool pushing = (MODE == MODE_WO || MODE == MODE_W2) && a.push;
-  if (pushing && wave != 0) pctx = tp_push_ctx(a.push, a.push_epoch, lane);
   f4 bufA[R][XV], bufB[R][XV];
   EpiPre preA = {0.0f, 0.0f, 0u}, preB = {0.0f, 0.0f, 0u};
   // the wave's k-th row group (`groups` = none): consecutive row groups go to different CUs
@@ -835,8 +832,8 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
     const float* src = a.in;
     if (MODE == MODE_QKV) { if (a.emb) src = a.emb + (size_t)a.tokpos[0] * n; }   // only layer 0 waits for the token
     if (GIN) {
-      const unsigned gtag_in = __hip_atomic_load(a.gin_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-      granules_gather_f4<XV>(a.gin, n, lane, gtag_in, xr, a.gin_herr, a.gin_wait_ticks, a.gin_nap);
+      const unsigned gtag_in = __hip_atomic_load(a.gran_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      granules_gather_f4<XV>(a.gran, n, lane, gtag_in, xr, a.gin_herr, 200000000ull, 1);      // bounded at 2 s; a short nap between sweeps (the wait is a whole attention long)
     } else {
 #pragma unroll
       for (int u = 0; u < XV; ++u) xr[u] = reinterpret_cast<const f4*>(src)[min(u * 64 + lane, n4 - 1)];
@@ -890,6 +887,11 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   STAMP(3);
   if (wave == 0 || gA0 >= groups) return;
   if (MODE == MODE_QKV || MODE == MODE_WO) { token = a.tokpos[0]; pos = a.tokpos[1]; }
+  // (the tensor-parallel push pointer is looked at HERE, behind the weight requests: hipcc fetches a kernel argument where it is first
+  // used, and a test of it in front of them put one more cold scalar-cache round -- 0.4 us -- before the first weight request of EVERY
+  // wo launch, tensor parallel or not: stories110M 4 010 -> 3 930 tok/s until it was found by a same-box run of the round-4 library)
+  const bool pushing = (MODE == MODE_WO || MODE == MODE_W2) && a.push;
+  if (pushing) pctx = tp_push_ctx(a.push, lane);
   // hand-off tag of a row group = its head's launch counter + 1 (advanced by an EARLIER launch: an ordinary load)
   auto gtag = [&](int gi) -> unsigned {
     if (!(MODE == MODE_QKV) || !a.gran) return 0u;
@@ -999,7 +1001,7 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
     { const EpiPre nopre = {0.0f, 0.0f, 0u};
       PushCtx pctx;
       const bool pushing = (MODE == MODE_WO || MODE == MODE_W2) && a.push;
-      if (pushing) pctx = tp_push_ctx(a.push, a.push_epoch, lane);
+      if (pushing) pctx = tp_push_ctx(a.push, lane);
       finish_group<MODE, R, false>(a, g, acc, lane, token, pos, nopre, best, pctx, pushing); }
   }
   if (MODE == MODE_CLS && a.amax) {   // as in phase_body

@@ -328,7 +328,7 @@ static hipError_t launch_attn_wo(const l2_ctx* c, int l, const PhaseArgs& wo_in,
   fill_attn_args(c, l, at);
   at.gout = c->awo_gran; at.gout_ep = c->awo_ep;
   PhaseArgs wo = wo_in;
-  wo.gin = c->awo_gran; wo.gin_ep = c->awo_ep; wo.gin_herr = c->h_herr_dev; wo.gin_wait_ticks = 200000000ull; wo.gin_nap = c->awo_nap;
+  wo.gran = c->awo_gran; wo.gran_ep = c->awo_ep; wo.gin_herr = c->h_herr_dev;
   const int nattn = c->H_loc * at.nsplit, xv = (c->d_loc / 4 + 63) / 64;
   const int groups = (wo.rows + 1) / 2;
   int nwo = c->n_cus - nattn;                 // one workgroup per CU, the attention workgroups' CUs left to them

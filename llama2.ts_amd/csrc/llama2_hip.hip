@@ -181,7 +181,6 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->p2p_fenced = env_int("L2_TP_FENCED", 0) ? 1 : 0;
   c->opt_push = dev_int("L2_TP_PUSH", 1) && !c->p2p_fenced;      // (the fenced form is the flag exchange)
   c->opt_awo = dev_int("L2_TP_ATTN_WO", 1);
-  c->awo_nap = dev_int("L2_TP_AWO_NAP", 1);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
@@ -449,7 +448,7 @@ static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (lla
   a.in = c->xb; a.emb = (l == 0) ? c->w[L2_T_TOKEN_EMBEDDING] : nullptr; a.res = c->x; a.out = c->x; a.aux = c->opt_keep_state ? c->xb2 : nullptr;
   a.n = c->d_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
-  if (p2p_pushing(c)) { a.push = c->tp_push; a.push_epoch = c->p2p_epoch; }      // rows go straight into the peers' inboxes (tp_exchange.hip.h)
+  if (p2p_pushing(c)) a.push = c->tp_push;      // rows go straight into the peers' inboxes (tp_exchange.hip.h)
   a.wp = packed_of(c, MODE_WO, l);
   return a;
 }
@@ -469,7 +468,7 @@ static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (lla
   a.in = c->hb; a.res = c->x; a.out = c->x; a.aux = (c->tp_path || !c->opt_keep_state) ? nullptr : c->xb;
   a.n = c->h_loc; a.rows = c->d;
   if (c->tp_path) a.partial = c->partial;
-  if (p2p_pushing(c)) { a.push = c->tp_push; a.push_epoch = c->p2p_epoch; }
+  if (p2p_pushing(c)) a.push = c->tp_push;
   a.wp = packed_of(c, MODE_W2, l);
   return a;
 }

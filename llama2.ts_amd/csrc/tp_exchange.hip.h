@@ -197,7 +197,7 @@ static int p2p_publish_table(l2_ctx* c) {
   TpPush t;
   memset(&t, 0, sizeof(t));
   for (int r = 0; r < c->G && r < P2P_MAXG; ++r) t.gin[r] = c->p2p_peers.gin[r];
-  t.G = c->G; t.rank = c->rank; t.n = c->d; t.solo = c->solo ? 1 : 0;
+  t.G = c->G; t.rank = c->rank; t.n = c->d; t.solo = c->solo ? 1 : 0; t.epoch = c->p2p_epoch;
   if (!c->tp_push) HIPCHK(hipMalloc(&c->tp_push, sizeof(TpPush)));
   HIPCHK(hipMemcpy(c->tp_push, &t, sizeof(t), hipMemcpyHostToDevice));
   return L2_OK;
@@ -236,9 +236,9 @@ __global__ void p2p_selftest_fill(double* partial, float* x, int rank, int n, in
   if (i < n) { partial[i] = (double)((rank + 1) * (k + 1)) + 0.5 * (double)i; x[i] = 0.0f; }
 }
 // the pushed form's stand-in for a GEMV epilogue: one wave per 64 elements, lane r < G hands element i to rank r (kernels.hip.h: tp_push_row)
-__global__ void p2p_selftest_push(const TpPush* p, const unsigned long long* epoch, float* x, int rank, int n, int k) {
+__global__ void p2p_selftest_push(const TpPush* p, float* x, int rank, int n, int k) {
   const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const PushCtx pc = tp_push_ctx(p, epoch, lane);
+  const PushCtx pc = tp_push_ctx(p, lane);
   for (int j = 0; j < 64; ++j) {
     const int i = wave * 64 + j;
     if (i < n) { tp_push_row(pc, i, (double)((rank + 1) * (k + 1)) + 0.5 * (double)i, lane); if (lane == 0) x[i] = 0.0f; }
@@ -341,7 +341,7 @@ static int p2p_connect_ipc(l2_ctx* c) {
     // (the form the decode step will use: rows pushed by the "GEMV" + the combine launch, or partials + the flag exchange)
     auto exchange = [&](int k) {
       if (p2p_pushing(c)) {
-        hipLaunchKernelGGL(p2p_selftest_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->tp_push, c->p2p_epoch, c->xb2, c->rank, n, k);
+        hipLaunchKernelGGL(p2p_selftest_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->tp_push, c->xb2, c->rank, n, k);
         hipLaunchKernelGGL(tp_p2p_combine_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->xb2, nullptr, nullptr, c->tokpos, (unsigned*)nullptr);
       } else {
         hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
