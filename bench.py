@@ -678,7 +678,7 @@ def main():
 
         def attempt(env, fresh_id=True):
             """Two phases, each ended by a report of every rank over gloo: (1) create the context (communicator, peer mappings,
-            start-up self-test) -- if ANY rank failed, every rank closes and nobody enters a collective; (2) fill and decode three
+            start-up self-test) -- if ANY rank failed, every rank closes and nobody enters a collective; (2) fill and decode sixteen
             tokens.  (RCCL has no timeout: a rank that entered an all-reduce its peer never reaches would hang the job instead of
             printing the fallback line.)"""
             err, c, toks = "", None, []
@@ -719,7 +719,7 @@ def main():
                 # ---- phase 2: every rank has a context: fill, decode, compare
                 try:
                     c.synth_fill(args.seed)
-                    toks = c.decode_greedy(1, 0, min(3, K)).tolist()
+                    toks = c.decode_greedy(1, 0, min(16, K)).tolist()      # (16 tokens: 1 040 exchanges at 32 layers, every one of them part of the proof)
                 except Exception as e:      # noqa: BLE001
                     err = "%s: %s" % (type(e).__name__, e)
                 mine = {"rank": rank, "err": err, "tokens": toks, "mode": c.tp_mode_id() if not err else -1}

@@ -61,14 +61,19 @@ __device__ __forceinline__ void attn_out(const AttnArgs& a, size_t idx, float v,
 // are issued together (ONE round trip per pass), and the wave leaves when every lane has every value.  Bounded by wall time: the
 // producers are workgroups of the same launch with LOWER block ids, already dispatched when this workgroup runs, so the wait can
 // only give up if the launch itself is broken -- then the host hears about it (herr) instead of the GPU hanging.
+// `dead`: the device-side error word, set by the first wait that gave up and read by every fused launch when it starts: a launch that
+// finds it set does not wait again (a systematically broken launch would otherwise spend the full bound in every layer of every token
+// before the host hears about it); the host clears it when it reports the error (check_p2p).
 template <int N>
-__device__ __forceinline__ void granules_wait(const unsigned long long* const (&g)[N], float (&v)[N], unsigned tag, int* herr, unsigned long long wait_ticks) {
+__device__ __forceinline__ void granules_wait(const unsigned long long* const (&g)[N], float (&v)[N], unsigned tag, int* herr, unsigned long long wait_ticks, unsigned* dead) {
   unsigned spins = 0;
   unsigned long long t0 = 0;
   for (;;) {
     unsigned long long x[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = __hip_atomic_load(g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the error word rides along with the FIRST sweep: a test in front of it would be a round trip of its own before the wait begins)
+    if (spins == 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < N; ++k) { ok = ok && (unsigned)(x[k] >> 32) == tag; v[k] = __uint_as_float((unsigned)x[k]); }
@@ -76,7 +81,7 @@ __device__ __forceinline__ void granules_wait(const unsigned long long* const (&
     if ((++spins & 255u) == 0) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (!t0) t0 = now;
-      else if (now - t0 > wait_ticks) { *herr = 1; return; }
+      else if (now - t0 > wait_ticks) { *herr = 1; __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     }
   }
 }
@@ -172,7 +177,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
         need_k ? a.gran + (size_t)h * hs + lane : gq, need_k ? a.gran + (size_t)a.dim + (size_t)hk * hs + lane : gq,
         need_v ? a.gran + (size_t)a.dim + a.kv_dim + (size_t)hk * hs + tid : gq};
     float gvals[7];
-    granules_wait<7>(gp, gvals, tag, a.herr, a.wait_ticks);
+    granules_wait<7>(gp, gvals, tag, a.herr, a.wait_ticks, a.gran_ep + a.n_heads);      // (the word behind the heads' counters)
     STAMP(6);
     q4.x = gvals[0]; q4.y = gvals[1]; q4.z = gvals[2]; q4.w = gvals[3];
     gk_q = need_k ? gvals[4] : 0.0f; gk_k = need_k ? gvals[5] : 0.0f; gv = need_v ? gvals[6] : 0.0f;

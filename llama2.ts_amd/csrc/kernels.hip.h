@@ -165,7 +165,7 @@ __device__ __forceinline__ void granule_store(unsigned long long* g, float v, un
 // false = gave up (*herr is set).  Only ONE wave of a workgroup ever does this (MI355X guide, row polling-cost).
 typedef unsigned gu4 __attribute__((ext_vector_type(4)));
 template <int NU>
-__device__ __forceinline__ bool granules_gather_f4(const unsigned long long* g, int n, int lane, unsigned tag, f4 (&xr)[NU], int* herr, unsigned long long wait_ticks, int nap) {
+__device__ __forceinline__ bool granules_gather_f4(const unsigned long long* g, int n, int lane, unsigned tag, f4 (&xr)[NU], int* herr, unsigned long long wait_ticks, int nap, unsigned* dead) {
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(g), 0, (unsigned)n * 8u, 0x00020000);
   const int n4 = n >> 2;
   unsigned off[NU];
@@ -180,6 +180,13 @@ __device__ __forceinline__ bool granules_gather_f4(const unsigned long long* g, 
       lo[u] = __builtin_bit_cast(gu4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u], 0, 16));           // aux 16 = sc1
       hi[u] = __builtin_bit_cast(gu4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + 16u, 0, 16));
     }
+    // `dead`: device-side error word -- an earlier wait of this context gave up: do not wait again (the host clears it when it reports the
+    // error).  It rides along with the first sweep: a test in front of it would be a round trip of its own.
+    if (spins == 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) xr[u] = f4{0.f, 0.f, 0.f, 0.f};
+      return false;
+    }
     bool ok = true;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -191,7 +198,7 @@ __device__ __forceinline__ bool granules_gather_f4(const unsigned long long* g, 
     if ((++spins & 63u) == 0) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (!t0) t0 = now;
-      else if (now - t0 > wait_ticks) { if (lane == 0) *herr = 1; return false; }
+      else if (now - t0 > wait_ticks) { if (lane == 0) { *herr = 1; __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return false; }
     }
   }
 }
@@ -833,7 +840,7 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
     if (MODE == MODE_QKV) { if (a.emb) src = a.emb + (size_t)a.tokpos[0] * n; }   // only layer 0 waits for the token
     if (GIN) {
       const unsigned gtag_in = __hip_atomic_load(a.gran_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-      granules_gather_f4<XV>(a.gran, n, lane, gtag_in, xr, a.gin_herr, 200000000ull, 1);      // bounded at 2 s; a short nap between sweeps (the wait is a whole attention long)
+      granules_gather_f4<XV>(a.gran, n, lane, gtag_in, xr, a.gin_herr, 200000000ull, 1, const_cast<unsigned*>(a.gran_ep) + 1);      // bounded at 2 s; a short nap between sweeps (the wait is a whole attention long)
     } else {
 #pragma unroll
       for (int u = 0; u < XV; ++u) xr[u] = reinterpret_cast<const f4*>(src)[min(u * 64 + lane, n4 - 1)];

@@ -466,6 +466,8 @@ static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer w
   if (c->h_herr && *c->h_herr) {
     *c->h_herr = 0;
     hipMemsetAsync(c->gran, 0, ((size_t)c->d_loc + 2 * (size_t)c->kvd_loc) * 8, c->stream);      // tags of the broken launch: gone (the counters only ever grow)
+    hipMemsetAsync(c->gran_ep + c->H_loc, 0, 4, c->stream);                                      // the device-side "a wait gave up" words: armed again
+    if (c->awo_ep) { hipMemsetAsync(c->awo_ep + 1, 0, 4, c->stream); hipMemsetAsync(c->awo_gran, 0, (size_t)c->d_loc * 8, c->stream); }
     hipStreamSynchronize(c->stream);
     return fail(L2_E_HIP, "a hand-off granule inside a fused launch never arrived (bounded wait gave up); the step's results are invalid");
   }

@@ -1,14 +1,14 @@
-# The one GPU-box command that regenerates profiles/r04/ (copy gpurun_out/r04/* there afterwards):
+# The one GPU-box command that regenerates profiles/r05/ (copy gpurun_out/r05prof/* there afterwards):
 #   bash tools/refresh_profiles.sh
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-out=gpurun_out/r04
+out=gpurun_out/r05prof
 rm -rf $out; mkdir -p $out
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $out/pytest_gpu.txt
 # bench lines (default = what the driver runs; parity of the timed tokens against the reference goldens, roofline.traffic from the PMC
 # passes inside the run, kernel_trace_us from a rocprofv3 --kernel-trace child, cpu_baseline on this box, tp_predicted from shard-timing contexts)
 python bench.py > $out/bench_default_llama2_7b.json 2> $out/bench_default.err
-python bench.py --steps 20 --warmup 5 > $out/bench_driver_style_llama2_7b.json 2>/dev/null
+L2_BENCH_SKIP_JS_7B=1 python bench.py --steps 20 --warmup 5 > $out/bench_driver_style_llama2_7b.json 2>/dev/null      # (the in-process JS baseline of the 7B shape: once is enough)
 python bench.py --config stories110M > $out/stories110M_bench.json 2>/dev/null
 python bench.py --config stories15M > $out/stories15M_bench.json 2>/dev/null
 # what `python bench.py --gpus N` prints when all ranks land on this one GPU (the ranks meet through files; proof tokens in the line)
@@ -24,13 +24,23 @@ done
 python tools/prefill_bench.py llama2_7b > $out/prefill_bench_llama2_7b.txt 2>&1
 python tools/prefill_bench.py stories110M > $out/prefill_bench_stories110M.txt 2>&1
 for c in stories110M stories110M stories15M llama2_7b_L2; do python tools/sampler_bench.py $c; done > $out/sampler_bench_run.txt 2>&1
-# the host's opt-in metrics line (llama2.ts:511 prints tok/s only)
+# one rank's shard of the tensor-parallel step alone on this GPU (l2_tp_mode 5): ms per token at 8 / 4 / 2 ranks, then per kernel under rocprofv3
+( export L2_TEST_HOOKS=1
+  for G in 8 4 2; do python3 tools/tp_solo_step.py $G llama2_7b 64; done
+  for G in 8 2; do
+    rm -rf $out/tps$G
+    L2_USE_GRAPH=0 L2_PROFILE_SYNC=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/tps$G -o p -- python3 tools/tp_solo_step.py $G llama2_7b 16 > /dev/null 2>&1
+    echo "== G=$G (eager, kernel trace)"
+    python3 tools/kernel_stats_table.py $out/tps$G
+    rm -rf $out/tps$G
+  done ) > $out/tp_shard_step_kernels.txt 2>&1
+# the host's opt-in metrics line (llama2.ts:511 prints tok/s only), on a checkpoint written from a context's own weights
 python - <<'PY' > $out/l2_run_metrics.txt 2>&1
-import json, os, subprocess, sys
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-import oracle_lib as O
-from llama2_ts_amd import configs
-O.synth_write(configs.header("stories15M"), 1, "/tmp/s15.bin")
+import subprocess
+import bench
+from llama2_ts_amd import configs, runtime
+ctx = runtime.Context(configs.header("stories15M")); ctx.synth_fill(1)
+bench.write_checkpoint(ctx, "/tmp/s15.bin"); ctx.close()
 for loop in ("host", "device"):
     r = subprocess.run(["node", "llama2.ts_amd/host/l2_run.mjs", "/tmp/s15.bin", "--steps", "256", "--loop", loop, "--metrics"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     print(loop, r.stderr.decode().strip())
