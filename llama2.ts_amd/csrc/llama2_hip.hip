@@ -842,7 +842,6 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   if (!c->samp.V) {
     if (c->V > l2s::MAX_VOCAB) return fail(L2_E_CONFIG, "device sampler supports vocabularies up to %d", (int)l2s::MAX_VOCAB);
     HIPCHK(l2s::create(&c->samp, c->V));
-    c->samp.herr_dev = c->h_herr_dev;      // a hand-off wait of the fused sample launch that gives up is reported like the other fused launches' (check_p2p)
   }
   const double params[2] = {temperature, topp};
   c->samp_mode = (topp <= 0 || topp >= 1) ? 0 : 1;        // llama2.ts:486: plain sample unless 0 < topp < 1

@@ -43,11 +43,6 @@ struct Sampler {
   bool force_serial = false;     // L2_SAMPLER_FORCE_SERIAL=1: the margin form treats every token as undecided
   unsigned* rank_acc = nullptr;  // (G * 1024) the rank merge's per-element accumulators {groups reported : 8, elements in front : 24}, zero between tokens
   bool serial = false;           // L2_SAMPLER_SERIAL=1: one lane accumulates (the straightforward form, kept for A/B)
-  // fused plain sample (sampler_margin.hip.h: sample_margin_kernel<true>): tile sums of the exps as tagged granule pairs, the launch counter
-  // their tags come from, a host-mapped word a wait that gives up sets
-  unsigned long long* gpart = nullptr;
-  unsigned* epoch = nullptr;
-  int* herr_dev = nullptr;       // (the context's: set by the owner after create(); null = the two-launch form)
 };
 
 enum { MAX_VOCAB = 256 * 1024 };   // one chain thread per 1024-element tile

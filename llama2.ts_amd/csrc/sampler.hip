@@ -145,10 +145,6 @@ hipError_t create(Sampler* s, int V) {
     auto hook = [&](const char* name) { const char* e_ = getenv(name); return g_ && atoi(g_) != 0 && e_ && atoi(e_) != 0; };
     s->serial = hook("L2_SAMPLER_SERIAL"); s->chain = hook("L2_SAMPLER_CHAIN"); s->force_serial = hook("L2_SAMPLER_FORCE_SERIAL");
   }
-  L2S(hipMalloc(&s->gpart, (size_t)s->G * 16));
-  L2S(hipMemset(s->gpart, 0, (size_t)s->G * 16));
-  L2S(hipMalloc(&s->epoch, 16));
-  L2S(hipMemset(s->epoch, 0, 16));
   L2S(hipMalloc(&s->rank_acc, padded * sizeof(unsigned)));       // the rank merge's per-element accumulators: zero between tokens
   L2S(hipMemset(s->rank_acc, 0, padded * sizeof(unsigned)));
 #undef L2S
@@ -158,7 +154,7 @@ hipError_t create(Sampler* s, int V) {
 void destroy(Sampler* s) {
   void* bufs[] = {s->probs, s->probs_n, s->probs_sorted, s->idx, s->idx_sorted, s->run_p, s->params, s->rng, s->part, s->part_sorted,
                   s->recs, s->recs2, s->cnt, s->cnt2, s->off, s->runS, s->runEnd, s->runBad, s->cq, s->cm, s->mxkey,
-                  s->part2, s->amb, s->ticket, s->stats, s->rank_acc, s->total, s->gpart, s->epoch};
+                  s->part2, s->amb, s->ticket, s->stats, s->rank_acc, s->total};
   for (void* b : bufs) if (b) (void)hipFree(b);
   *s = Sampler();
 }
@@ -192,15 +188,6 @@ hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* t
     hipLaunchKernelGGL(topp_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.rng, tokpos, tokens_out);
     return hipGetLastError();
   }
-  if (!s.chain && !topp_mode && amax && s.herr_dev) {
-    // plain sample(), margin form, the maximum from the classifier's argmax keys: exps, tile sums, probabilities and pick in ONE launch
-    MarginArgs m = {};
-    m.part = s.part; m.V = s.V; m.G = s.G; m.part2 = s.part2; m.amb = s.amb; m.ticket = s.ticket; m.params = s.params; m.rng = s.rng;
-    m.tokpos = tokpos; m.tokens_out = tokens_out; m.mxkey = s.mxkey; m.amax = amax; m.stats = s.stats; m.force_serial = s.force_serial ? 1 : 0;
-    m.logits = logits; m.exps_out = s.probs; m.gpart = s.gpart; m.epoch = s.epoch; m.herr = s.herr_dev;
-    hipLaunchKernelGGL(sample_margin_kernel<true>, dim3(s.G), dim3(TN), 0, st, m);
-    return hipGetLastError();
-  }
   // temperature + exp (:481-483, :183-188), runs of the exps' running sum
   if (!amax) hipLaunchKernelGGL(scaled_max_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey);
   hipLaunchKernelGGL(exp_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey, amax, s.probs, s.part);
@@ -210,7 +197,7 @@ hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* t
     m.sorted = s.probs_sorted; m.ids = s.idx_sorted; m.part_sorted = s.part_sorted; m.params = s.params; m.rng = s.rng;
     m.tokpos = tokpos; m.tokens_out = tokens_out; m.mxkey = s.mxkey; m.amax = amax; m.stats = s.stats; m.force_serial = s.force_serial ? 1 : 0;
     if (!topp_mode) {
-      hipLaunchKernelGGL(sample_margin_kernel<false>, dim3(s.G), dim3(TN), 0, st, m);
+      hipLaunchKernelGGL(sample_margin_kernel, dim3(s.G), dim3(TN), 0, st, m);
       return hipGetLastError();
     }
     // the descending order needs the exact probabilities: runs of the exps, [exact total -> probabilities -> sorted tiles], rank merge

@@ -40,16 +40,7 @@ struct MarginArgs {
   unsigned long long* amax;      // or the classifier's 8 argmax keys
   unsigned long long* stats;     // {tokens, tokens that took the serial loop}
   int force_serial;
-  // fused form of plain sample() (sample_margin_kernel<true>): exps, their tile sums' hand-off and the pick in ONE launch
-  const float* logits;           // (V) what the classifier left
-  float* exps_out;               // (V) = exps, written through (the picking workgroup reads another workgroup's tile)
-  unsigned long long* gpart;     // (G) x 16 bytes: a tile sum as two tagged granules {low word, tag}, {high word, tag}
-  unsigned* epoch;               // launch counter the tags come from (advanced by the picking workgroup)
-  int* herr;                     // host-mapped: a wait gave up
 };
-
-__device__ __forceinline__ float ld_through(const float* p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ __forceinline__ void st_through(float* p, float v) { __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct MarginShared {
   double wsum[NWV], wamb[NWV];
@@ -206,70 +197,13 @@ __device__ __forceinline__ void pick_done(const MarginArgs& a, int token, bool s
 }
 
 // ---- plain sample(): probabilities' tile sums by every workgroup, the pick by the last one to arrive ----------------------------
-// FUSED (round 5: the default when the classifier's argmax keys carry the maximum): the exps are made HERE, from the logits -- the launch
-// that used to make them and the boundary behind it are gone.  A workgroup's exps stay in its registers; their tile sum is handed to the
-// other workgroups (G <= 256, all co-resident) as two tagged 8-byte granules in one 16-byte write-through store, thread t polls tile
-// t's pair past L1, and the total is then formed from an LDS copy by the SAME instruction sequence (tile_base) as in the two-launch
-// form: the same bits in every lane of every workgroup.  The exps themselves are written through too: the picking workgroup reads
-// another workgroup's tile (decide_first, or all of them in the serial loop) behind the ticket, with loads past L1.
-template <bool FUSED>
 __global__ void __launch_bounds__(TN) sample_margin_kernel(const MarginArgs a) {
   __shared__ MarginShared sh;
   const int tid = threadIdx.x, tile = blockIdx.x, n = a.V;
+  const double T = tile_base(a.part, a.G);                     // tree total of the exps: the same bits in every lane of every workgroup
   const int win = mr::window(n);
   float v[IT];
-  double T;
-  unsigned e = 0u;
-  if (FUSED) {
-    __shared__ double partbuf[MAX_VOCAB / TILE];
-    e = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;      // requested first, used after the exps
-    load_tile(a.logits, n, tile, v);
-    const double temp = a.params[0];
-    unsigned long long k = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const unsigned long long kj = a.amax[(size_t)j * 16]; k = kj > k ? kj : k; }
-    const float mx = (float)((double)order_value((unsigned)(k >> 32)) / temp);      // as exp_kernel: the scaled maximum is the maximum of the scaled logits
-    const int i0 = tile * TILE + tid * IT;
-#pragma unroll
-    for (int q = 0; q < IT; ++q) {
-      const float x = (float)((double)v[q] / temp);
-      v[q] = (i0 + q < n) ? (float)exp((double)x - (double)mx) : 0.0f;
-      if (i0 + q < n) st_through(a.exps_out + i0 + q, v[q]);
-    }
-    const double te = tile_total(v, sh.wsum);
-    if (tid == 0) {
-      const unsigned long long b = (unsigned long long)__double_as_longlong(te);
-      typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-      const u32x4_ w = {(unsigned)b, e, (unsigned)(b >> 32), e};
-      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(a.gpart + 2 * (size_t)tile), "v"(w) : "memory");
-    }
-    // every tile's sum: thread t waits for tile t's pair (bounded; all G workgroups are resident: G <= 256 <= CUs)
-    unsigned spins = 0;
-    unsigned long long t0 = 0;
-    for (;;) {
-      bool ok = true;
-      if (tid < a.G) {
-        const unsigned long long lo = __hip_atomic_load(a.gpart + 2 * (size_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hi = __hip_atomic_load(a.gpart + 2 * (size_t)tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = (unsigned)(lo >> 32) == e && (unsigned)(hi >> 32) == e;
-        partbuf[tid] = __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
-      }
-      if (__syncthreads_and(ok ? 1 : 0)) break;
-      if ((++spins & 63u) == 0) {      // (bounded: 2 s on the 100 MHz clock, decided by ONE thread for the workgroup; the host hears about it)
-        bool expired = false;
-        if (tid == 0) {
-          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-          if (!t0) t0 = now;
-          else if (now - t0 > 200000000ull) { *a.herr = 1; expired = true; }
-        }
-        if (__syncthreads_or(expired ? 1 : 0)) break;
-      }
-    }
-    T = tile_base(partbuf, a.G);
-  } else {
-    T = tile_base(a.part, a.G);                                // tree total of the exps: the same bits in every lane of every workgroup
-    load_tile(a.exps, n, tile, v);
-  }
+  load_tile(a.exps, n, tile, v);
   double amb = 0.0;
 #pragma unroll
   for (int k = 0; k < IT; ++k) v[k] = mr::quotient_checked(v[k], T, win, &amb);      // padding: e = 0 -> p = 0
@@ -277,7 +211,6 @@ __global__ void __launch_bounds__(TN) sample_margin_kernel(const MarginArgs a) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) amb += __shfl_xor(amb, off, 64);
   if ((tid & 63) == 0) sh.wamb[tid >> 6] = amb;
-  if (FUSED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY wave's write-through exps have left before the ticket is taken
   __syncthreads();
   if (tid == 0) {
     // write-through stores another CU's L1-bypassing loads see, drained before the ticket is taken (MI355X_MICROARCH.md, hand-off forms)
@@ -298,22 +231,19 @@ __global__ void __launch_bounds__(TN) sample_margin_kernel(const MarginArgs a) {
   __syncthreads();
   const double u = sh.val[1];
   const double M = mr::margin(n, Qn, A);
-  const float* exps = FUSED ? a.exps_out : a.exps;
-  auto ex = [&](int i) { return FUSED ? ld_through(exps + i) : exps[i]; };      // (fused: written by other workgroups of this launch)
-  auto prob = [&](int i) { return (float)((double)ex(i) / T); };
+  auto prob = [&](int i) { return (float)((double)a.exps[i] / T); };
   int hit = -2;
   double qhit;
   if (!a.force_serial && Qn > 0.0 && Qn <= 1.7976931348623157e308) hit = decide_first(prob, n, a.G, u * Qn, M, n, incl, own, sh, &qhit);   // randValue = random_f32() * sum (:370)
   const bool serial = hit == -2;
   if (serial) {                                                // llama2.ts:189-192, :368-376 as written
     double total, sum;
-    serial_sum([&](int i) { return ex(i); }, n, sh, &total, false, INFINITY);
-    auto p = [&](int i) { return (float)((double)ex(i) / total); };
+    serial_sum([&](int i) { return a.exps[i]; }, n, sh, &total, false, INFINITY);
+    auto p = [&](int i) { return (float)((double)a.exps[i] / total); };
     serial_sum(p, n, sh, &sum, true, INFINITY);
     hit = serial_first(p, n, u * sum, sh);
   }
   pick_done(a, hit < 0 ? 0 : hit, serial);                     // fall-through returns 0 (:375)
-  if (FUSED && tid == 0) *a.epoch = e;                         // every workgroup of the launch has read it (each took its ticket behind its read)
 }
 
 // ---- sample_topp() behind the sort: one workgroup ------------------------------------------------------------------------------
