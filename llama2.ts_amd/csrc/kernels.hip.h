@@ -38,8 +38,9 @@ struct Stamps {
   unsigned long long* dst;
   unsigned long long* wg;      // every workgroup: {start, end} on the constant 100 MHz clock all XCDs share (s_memrealtime)
   unsigned long long rt0;
-  __device__ __forceinline__ Stamps(unsigned long long* dbg, unsigned long long* dbg_wg = nullptr, int force_sel = -2) {
-    wg = (dbg_wg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) ? dbg_wg + 2 * blockIdx.x : nullptr;
+  __device__ __forceinline__ Stamps(unsigned long long* dbg, unsigned long long* dbg_wg = nullptr, int force_sel = -2, bool last_wave = false) {
+    // (latency form: wave 0 is the x wave and leaves at the barrier -- the workgroup's lifetime is taken from its last wave)
+    wg = (dbg_wg && threadIdx.x == (last_wave ? blockDim.x - 64 : 0) && blockIdx.y == 0 && blockIdx.x < 1024) ? dbg_wg + 2 * blockIdx.x : nullptr;
     rt0 = __builtin_readcyclecounter();
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0));
 #pragma unroll
@@ -67,11 +68,13 @@ struct Stamps {
 };
 #define STAMP_INIT(dbg) Stamps st_(dbg)
 #define STAMP_INIT_WG(dbg, wg) Stamps st_(dbg, wg)
+#define STAMP_INIT_WGL(dbg, wg) Stamps st_(dbg, wg, -2, true)
 #define STAMP_INIT_SEL(dbg, sel) Stamps st_(dbg, nullptr, sel)
 #define STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_.t[k])::"memory")
 #else
 #define STAMP_INIT(dbg) do { } while (0)
 #define STAMP_INIT_WG(dbg, wg) do { } while (0)
+#define STAMP_INIT_WGL(dbg, wg) do { } while (0)
 #define STAMP_INIT_SEL(dbg, sel) do { } while (0)
 #define STAMP(k) do { } while (0)
 #endif
@@ -812,7 +815,7 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   const int groups = (a.rows + RPG - 1) / RPG;
   const int gstride = vgrid * NC;
 
-  STAMP_INIT(a.dbg);
+  STAMP_INIT_WGL(a.dbg, a.dbg_wg);
   STAMP(0);
   int token = 0, pos = 0;
   PushCtx pctx;
