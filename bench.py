@@ -441,6 +441,18 @@ def reference_js_figure(name):
 
 
 # ---- one config on one GPU: decode loop + roofline + CPU baseline ------------------------------------------------
+def dispatch_note(ctx):
+    """How the device-resident loop's launches reached the chip in the run just made (L2_OPT_AQL_QUEUE, include/llama2_hip.h)."""
+    try:
+        if ctx.get_option(runtime.OPT_AQL_QUEUE):
+            return ("a token's launches written as AQL packets on the library's own HSA queue: barrier bit, agent-scope release, "
+                    "no acquire fence between the launches of a token (csrc/aql_queue.h)")
+        why = runtime.lib().l2_last_error().decode("utf8", "replace")
+        return "one hipGraph replay per token" + ((" (%s)" % why) if "AQL" in why else "")
+    except Exception as e:      # an older library
+        return "one hipGraph replay per token (%s)" % type(e).__name__
+
+
 def roofline_block(ctx, cfg, K, traffic, traffic_how, trace_us=None):
     iters = 200 if cfg.dim * cfg.hidden_dim < (1 << 24) else 50
     kms_isolated = ctx.bench_gemv(runtime.T_W1, cfg.n_layers // 2, iters)
@@ -493,6 +505,7 @@ def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None):
            "algorithmic_bytes_per_token": int(bpt),
            "hbm_gbs_end_to_end": round(bpt * K / wall / 1e9, 2),
            "hbm_frac_end_to_end": round(bpt * K / wall / 1e9 / HBM_PEAK_GBS, 4),
+           "loop": "device-resident (forward + argmax on GPU, %s)" % dispatch_note(ctx),
            "parity": parity}
     # the same K steps through the blocking drop-in boundary (llama2.ts:468 -> 478: logits to the host every token, argmax there)
     rate, dropin_tokens = dropin_loop(ctx, K)
@@ -817,7 +830,7 @@ def main():
         "config": {"workload": "%s batch-1 greedy decode, %d tokens from BOS (-t 0 -s 1 -n %d)" % (args.config, K, K),
                    "header": list(hdr), "parallelism": ("tp%d" % world) if shards else ("replicas%d" % world if world > 1 else "single"),
                    "loop": ("device-resident (forward + argmax on GPU); tensor-parallel step: %s" % ctx.tp_mode()
-                            if shards else "device-resident (forward + argmax on GPU, one hipGraph replay per token)"),
+                            if shards else "device-resident (forward + argmax on GPU, %s)" % dispatch_note(ctx)),
                    "weights": "fp32, ONE copy on the device (%d MiB): the matrices of the streaming phases repacked in the order the chip consumes them "
                               "(%d MiB, DESIGN.md section 3), everything else row-major as the checkpoint stores it"
                               % (ctx.get_option(runtime.OPT_WEIGHT_MIB), ctx.get_option(runtime.OPT_PACKED_MIB)),

@@ -77,9 +77,13 @@ enum {
   L2_OPT_WEIGHT_MIB = 5,      /* read-only: MiB of device memory held by ALL weights right now (row-major tensors + repacked copies).  After
                                  the first step a repacked matrix exists once: its row-major tensor has been given back */
   L2_OPT_SAMPLED_TOKENS = 6,  /* read-only: tokens l2_decode_sample has picked on this context with temperature != 0 (saturates at INT_MAX) */
-  L2_OPT_SAMPLED_SERIAL = 7   /* read-only: of those, the tokens whose running sums came within the proven margin of the threshold and were
+  L2_OPT_SAMPLED_SERIAL = 7,  /* read-only: of those, the tokens whose running sums came within the proven margin of the threshold and were
                                  therefore picked by the reference's loop run as written (csrc/sampler_margin.hip.h); the others by the
                                  margin rule */
+  L2_OPT_AQL_QUEUE = 8        /* 1 (default): l2_decode_greedy submits a token's launches as hand-written AQL packets on a queue of the
+                                 library's own (csrc/aql_queue.h: barrier bit, no cache fences between the launches of a run); 0: a replayed
+                                 hipGraph per token.  Reading it AFTER a greedy run tells what that run used: 1 the queue, 0 hipGraphs
+                                 (switched off, a tensor-parallel context, or the queue could not be had: l2_last_error() then holds the reason) */
 };
 
 typedef struct l2_ctx l2_ctx;

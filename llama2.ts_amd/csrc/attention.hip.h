@@ -91,7 +91,7 @@ __device__ __forceinline__ void granules_wait(const unsigned long long* const (&
 // store nobody waits for.  Every reader of gran_ep[h] in this launch has read it by then: the attention workgroups of head h read
 // it before they take their ticket, and a QKV wave reads it before it stores a granule that head h waits for.
 __device__ __forceinline__ void fused_head_done(const AttnArgs& a, int h, unsigned tag, int tid) {
-  if (tid == 0) a.gran_ep[h] = tag;
+  if (tid == 0) __hip_atomic_store(a.gran_ep + h, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // rows of a split: ceil(T / nsplit).  (A shift for power-of-two split counts behind a run-time test was measured: hipcc then carries
@@ -159,18 +159,18 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   auto issue = [&](f4 (&buf)[NT], bool values, int rd) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      buf[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(values ? vrs : krs, voff, (unsigned)(rd * NT + j) * tstride, 0));
+      buf[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(values ? vrs : krs, voff, (unsigned)(rd * NT + j) * tstride, 16));      // aux 16 = sc1: cache rows are written by launches of this run (coherence rule, kernels.hip.h)
   };
   issue(ra, false, 0);
   f4 q4;
-  if (!FUSED) q4 = *reinterpret_cast<const f4*>(a.q + (size_t)h * hs + cc4);
+  if (!FUSED) { const auto qrs = L2_ACT_RSRC(a.q, a.dim); q4 = L2_ACT_LD4(qrs, ((size_t)h * hs + cc4) >> 2); }
   if (!MULTI || rounds <= 1) issue(rb, true, 0);
   // FUSED: the cache tiles are in flight; now ONE wait for everything of this position the lane will need: its four q values,
   // and -- the wave that scores row pos -- q[i] and k[i], and -- the threads that fold the output -- v[i] (hs <= 64: one each)
   float gk_q = 0.0f, gk_k = 0.0f, gv = 0.0f;
   unsigned ftag = 0;
   if (FUSED) {
-    const unsigned tag = ftag = const_cast<const unsigned*>(a.gran_ep)[h] + 1u;      // advanced by an EARLIER launch (and again only when this head is done)
+    const unsigned tag = ftag = ld_word(const_cast<const unsigned*>(a.gran_ep) + h) + 1u;      // advanced by an EARLIER launch (and again only when this head is done)
     const unsigned long long* gq = a.gran + (size_t)h * hs + cc4;
     const bool need_k = own_pos && wave == NW - 1 && lane < hs, need_v = own_pos && tid < hs;
     const unsigned long long* const gp[7] = {gq, gq + 1, gq + 2, gq + 3,
@@ -276,7 +276,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
     for (int i = tid; i < hs; i += NTH) {
       const float* vp = a.vc + (size_t)hk * hs + i;
       float o = 0.0f;
-      for (int t = 0; t < n; ++t) o = (float)((double)o + (double)sc[t] * (double)vp[(size_t)t * dim]);
+      for (int t = 0; t < n; ++t) o = (float)((double)o + (double)sc[t] * (double)ld_sc1(vp + (size_t)t * dim));
       attn_out(a, (size_t)h * hs + i, o, otag);
     }
     return;
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int 
   for (int t = tid; t <= pos; t += 256) {
     const float* kp = a.kc + (size_t)t * kvd + (size_t)hk * hs;
     double s = 0.0;
-    for (int i = 0; i < hs; ++i) s += (double)q[i] * (double)kp[i];
+    for (int i = 0; i < hs; ++i) s += (double)ld_sc1(q + i) * (double)ld_sc1(kp + i);
     att[t] = (float)(s / rsq);
   }
   __syncthreads();
@@ -530,11 +530,11 @@ __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int 
     const float* vp = a.vc + (size_t)hk * hs + i;
     if (a.exact) {
       float o = 0.0f;
-      for (int t = 0; t <= pos; ++t) o = (float)((double)o + (double)att[t] * (double)vp[(size_t)t * kvd]);
+      for (int t = 0; t <= pos; ++t) o = (float)((double)o + (double)att[t] * (double)ld_sc1(vp + (size_t)t * kvd));
       xb[i] = o;
     } else {
       double o = 0.0;
-      for (int t = 0; t <= pos; ++t) o += (double)att[t] * (double)vp[(size_t)t * kvd];
+      for (int t = 0; t <= pos; ++t) o += (double)att[t] * (double)ld_sc1(vp + (size_t)t * kvd);
       xb[i] = (float)o;
     }
   }

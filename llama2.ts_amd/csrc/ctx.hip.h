@@ -204,6 +204,16 @@ struct l2_ctx {
   unsigned long long* dbg = nullptr;  // L2_STAMPS builds
 
   hipGraphExec_t g_step[NLEV] = {}, g_greedy[NLEV] = {};   // one captured graph per attention split level
+  // The greedy loop as hand-written AQL packets on a queue of the library's own (aql_queue.h): the step of a level is RECORDED once
+  // (the same enqueue that a hipGraph captures) and replayed for every token with fence-free packet headers.
+  AqlQueue* aql = nullptr;
+  AqlProgram* aql_greedy[NLEV] = {};
+  AqlProgram* aql_rec = nullptr;    // non-null while enqueue_* records instead of launching
+  bool aql_rec_failed = false;
+  bool aql_tried = false;
+  int opt_aql = 1;                  // L2_AQL=0: replayed hipGraphs for the greedy loop (the blocking call and the sampled loop always use them)
+  int aql_fence = 20;               // acquire scope + 4 * release scope + 16 * (agent acquire on a token's first launch): aql_queue.h, create_impl
+  std::string aql_note;             // why the queue is not in use, if it is not
   int opt_exact = 0, opt_graph = 1, opt_keep_state = 0;
   int next_pos = 0;
   bool ran_forward = false;

@@ -332,6 +332,26 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 __device__ __forceinline__ float ld_sc1(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// ------------------------------------------------------------------------------------------------
+// COHERENCE RULE of the decode step's kernels.  On the library's own queue (aql_queue.h) the launches of a token carry a RELEASE
+// fence only (the command processor writes the L2s' dirty lines back when a launch ends; the chip then keeps its eight L2s
+// coherent by itself) and NO acquire: nothing invalidates a CU's vector L1 between two launches.  So every VECTOR load of a byte
+// that an earlier launch of the run wrote -- activations, cache rows, launch counters, argmax keys -- goes past L1 (sc1: a buffer
+// load with the sc1 bit for 16 bytes, a relaxed agent-scope atomic load for a word).  Stores stay plain.  {token, pos, step} change
+// once per token, in its last launch, and are read through the SCALAR cache as before: the first launch of every token acquires at
+// agent scope, which refreshes it.  Weights, norm weights, RoPE tables and the embedding table are immutable during a run and keep
+// their plain / non-temporal loads.  (Measured on the way, tools/aql/microbench_aql.cpp + profiles/r05/aql_*: write-through stores
+// instead of the release fence cost every launch 0.3 - 0.9 us -- a 4-byte sc1 store is a fabric write of its own; {token, pos} as
+// vector loads queue behind the weight requests of the latency form and delay its epilogue operands.)
+//
+// a launch counter of the fused launch (it changes from launch to launch): ONE vector load past L1, broadcast through a scalar register
+__device__ __forceinline__ unsigned ld_word(const unsigned* p) {
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// 16 bytes of an activation vector past L1: a buffer load with the sc1 bit (aux 16), tracked by the compiler's wait counts like any
+// other load; the descriptor ends at the vector's end (elements past it read as zeros)
+#define L2_ACT_RSRC(ptr, n_floats) __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (unsigned)(n_floats) * 4u, 0x00020000)
+#define L2_ACT_LD4(rs, idx4) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(idx4) * 16u, 0, 16))
 
 // QKV row groups: all q rows (dim), then k, then v (kv_dim each).
 __device__ __forceinline__ void qkv_group(const PhaseArgs& a, int g, int R, int& m, int& i0) {
@@ -410,7 +430,7 @@ __device__ __forceinline__ EpiPre epi_prefetch(const PhaseArgs& a, int g, int la
   } else if (MODE == MODE_WO || MODE == MODE_W2) {
     if (!a.partial && !a.push) {
       const int i = min(g * R + min(lane, R - 1), a.rows - 1);
-      e.e0 = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : a.res[i];
+      e.e0 = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : ld_sc1(a.res + i);
     }
 
   }
@@ -492,7 +512,7 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         if (a.partial) {
           a.partial[i] = acc[r];
         } else {
-          const float xr = PREF ? pre.e0 : ((MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : a.res[i]);
+          const float xr = PREF ? pre.e0 : ((MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : ld_sc1(a.res + i));
           const float mv = (float)acc[r];   // xb2 (WO) / xb (W2) as the reference stores it
           a.out[i] = xr + mv;
           if (a.aux) a.aux[i] = mv;
@@ -616,7 +636,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   if (MODE == MODE_QKV || MODE == MODE_WO) { token = a.tokpos[0]; pos = a.tokpos[1]; }
   const float* src = a.in;
   if (MODE == MODE_QKV) { if (a.emb) src = a.emb + (size_t)token * n; }
-  const f4* src4 = reinterpret_cast<const f4*>(src);
+  const auto srs = L2_ACT_RSRC(src, n);      // (the input vector: past L1 -- the coherence rule above)
   const f4* rw4 = reinterpret_cast<const f4*>(a.rmsw);
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   double ss = 0.0, ss1 = 0.0, ss2 = 0.0, ss3 = 0.0;   // four chains: fp64 FMA latency is not on the path
@@ -624,7 +644,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const int cc = min(base + tid + k * nthreads, n4 - 1);
-      xr[k] = src4[cc];
+      xr[k] = L2_ACT_LD4(srs, cc);
       if (mode_has_norm<MODE>()) wr[k] = rw4[cc];
     }
   };
@@ -845,8 +865,9 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
       const unsigned gtag_in = __hip_atomic_load(a.gran_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
       granules_gather_f4<XV>(a.gran, n, lane, gtag_in, xr, a.gin_herr, 200000000ull, 1, const_cast<unsigned*>(a.gran_ep) + 1);      // bounded at 2 s; a short nap between sweeps (the wait is a whole attention long)
     } else {
+      const auto srs = L2_ACT_RSRC(src, n);
 #pragma unroll
-      for (int u = 0; u < XV; ++u) xr[u] = reinterpret_cast<const f4*>(src)[min(u * 64 + lane, n4 - 1)];
+      for (int u = 0; u < XV; ++u) xr[u] = L2_ACT_LD4(srs, min(u * 64 + lane, n4 - 1));
     }
     if (mode_has_norm<MODE>()) {
 #pragma unroll
@@ -907,7 +928,7 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
     if (!(MODE == MODE_QKV) || !a.gran) return 0u;
     int m, i0;
     qkv_group(a, gi, R, m, i0);
-    return a.gran_ep[((unsigned)i0 * a.gran_hmagic) >> 20] + 1u;
+    return ld_word(a.gran_ep + (((unsigned)i0 * a.gran_hmagic) >> 20)) + 1u;
   };
   preA = epi_prefetch<MODE, R>(a, gA0, lane, token, pos); preA.tag = gtag(gA0);
   if (gB0 < groups) { preB = epi_prefetch<MODE, R>(a, gB0, lane, token, pos); preB.tag = gtag(gB0); }
@@ -979,16 +1000,16 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
   if ((MODE == MODE_QKV) && a.emb) src = a.emb + (size_t)token * n;
   if (mode_has_norm<MODE>()) {
     double ss = 0.0;
-    for (int j = tid; j < n; j += nthreads) { const double v = src[j]; ss += v * v; }
+    for (int j = tid; j < n; j += nthreads) { const double v = ld_sc1(src + j); ss += v * v; }
     ss = block_sum(ss, red, tid, nthreads);
     ss = rms_scale(ss, a.inv_n);
     for (int j = tid; j < n; j += nthreads) {
-      const float o = (float)((double)a.rmsw[j] * (ss * (double)src[j]));
+      const float o = (float)((double)a.rmsw[j] * (ss * (double)ld_sc1(src + j)));
       xs[j] = o;
       if (MODE == MODE_CLS && blockIdx.x == 0 && a.aux) a.aux[j] = o;
     }
   } else {
-    for (int j = tid; j < n; j += nthreads) xs[j] = src[j];
+    for (int j = tid; j < n; j += nthreads) xs[j] = ld_sc1(src + j);
   }
   __syncthreads();
   const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
@@ -1037,7 +1058,7 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
 __global__ void __launch_bounds__(64) argmax_finish_kernel(unsigned long long* amax, int* tokpos, int* tokens_out) {
   const int lane = threadIdx.x;
   const int p1 = tokpos[1], step = tokpos[2];
-  unsigned long long k = lane < 8 ? amax[(size_t)lane * 16] : 0ull;
+  unsigned long long k = lane < 8 ? __hip_atomic_load(amax + (size_t)lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;      // (past L1: the coherence rule)
   if (lane < 8) amax[(size_t)lane * 16] = 0ull;
   k = wave_max_u64(k);
   if (lane == 0) {

@@ -78,6 +78,32 @@ static hipError_t lds_opt_in(K kernel, size_t lds) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+// Every launch of the decode step goes through here: a HIP launch (eager, or captured into a hipGraph), or -- while the step of a
+// level is being recorded for the library's own AQL queue (aql_queue.h) -- one packet of that recording: the kernel by its name in
+// the code object, the explicit arguments packed as the kernel-argument segment lays them out (each at its natural alignment).
+template <class T>
+static void aql_pack(char* buf, size_t& off, const T& v) {
+  off = (off + alignof(T) - 1) & ~(alignof(T) - 1);
+  memcpy(buf + off, &v, sizeof(T));
+  off += sizeof(T);
+}
+template <class... KA, class... A>
+static void l2_launch(const l2_ctx* c, void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t st, const A&... a) {
+  static_assert(sizeof...(KA) == sizeof...(A), "argument count");
+  if (c->aql_rec) {
+    l2_ctx* m = const_cast<l2_ctx*>(c);
+    char buf[1024];
+    size_t off = 0;
+    static_assert((sizeof(KA) + ... + 0) + 8 * sizeof...(KA) <= sizeof(buf), "kernel arguments exceed the packing buffer");
+    (aql_pack<KA>(buf, off, static_cast<KA>(a)), ...);
+    const char* name = hipKernelNameRefByPtr(reinterpret_cast<const void*>(kernel), st);
+    const unsigned g[3] = {grid.x, grid.y, grid.z}, b[3] = {block.x, block.y, block.z};
+    if (!name || aql_record(m->aql, m->aql_rec, name, g, b, (unsigned)lds, buf, off)) m->aql_rec_failed = true;
+    return;
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, st, a...);
+}
+
 // Launch with optional start / stop events on THE DISPATCH (hipExtLaunchKernelGGL): their elapsed time is the kernel's
 // own execution time, as a kernel trace reports it -- no launch boundary, no event-record latency (the in-situ probe).
 template <class K, class A>
@@ -88,7 +114,7 @@ static void launch_probed(const l2_ctx* c, K kernel, dim3 grid, dim3 block, size
     m->probe_used += 2;
     hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0, e1, 0, a);
   } else {
-    hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
+    l2_launch(c, kernel, grid, block, lds, st, a);
   }
 }
 
@@ -168,7 +194,7 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
     const size_t lds = (((size_t)a.n * 4 + 15) & ~(size_t)15) + 64;
     hipError_t e = lds_opt_in(&phase_kernel_scalar<MODE>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((phase_kernel_scalar<MODE>), grid, block, lds, st, a);
+    l2_launch(c, phase_kernel_scalar<MODE>, grid, block, lds, st, a);
     return hipGetLastError();
   }
   const int n4 = a.n / 4, cpi = 64 * g.U;
@@ -233,7 +259,7 @@ static hipError_t launch_attn_tile(const l2_ctx* c, const AttnArgs& a, int ny, i
 #define L2_AT(LR, NW, NT) do { if (pos0 >= 0) { hipError_t e_ = lds_opt_in(&pf_attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
                                             hipLaunchKernelGGL((pf_attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a, pos0); } \
                            else { hipError_t e_ = lds_opt_in(&attn_tile_kernel<LR, NW, NT>, lds); if (e_ != hipSuccess) return e_; \
-                                  hipLaunchKernelGGL((attn_tile_kernel<LR, NW, NT>), grid, block, lds, st, a); } } while (0)
+                                  l2_launch(c, attn_tile_kernel<LR, NW, NT>, grid, block, lds, st, a); } } while (0)
   (void)nw;      // (one form per row width: the L2_ATTN_NW override and its four extra instances per kernel went in round 5)
   switch (lr) {
     case 4: L2_AT(4, 4, 16); break;
@@ -275,7 +301,7 @@ static hipError_t launch_qkv_attn_xv(const l2_ctx* c, const PhaseArgs& qa, const
   const size_t lds = lds_q > lds_a ? lds_q : lds_a;
   hipError_t e = lds_opt_in(&qkv_attn_small_kernel<XV, 16, 8>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((qkv_attn_small_kernel<XV, 16, 8>), dim3(nq + nattn), dim3(512), lds, st, qa, at, nattn);
+  l2_launch(c, qkv_attn_small_kernel<XV, 16, 8>, dim3(nq + nattn), dim3(512), lds, st, qa, at, nattn);
   return hipGetLastError();
 }
 
@@ -304,7 +330,7 @@ static hipError_t launch_attn(const l2_ctx* c, int l, hipStream_t st) {   // att
     const size_t lds = (size_t)((c->S + 3) & ~3) * 4 + 64;
     hipError_t e = lds_opt_in(&attn_scalar_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_scalar_kernel, dim3(c->H_loc, 1), dim3(256), lds, st, a, 0);
+    l2_launch(c, attn_scalar_kernel, dim3(c->H_loc, 1), dim3(256), lds, st, a, 0);
     return hipGetLastError();
   }
   if (c->opt_exact) a.nsplit = 1;

@@ -32,6 +32,7 @@
 #include "attention.hip.h"
 #include "prefill.hip.h"
 #include "sampler.h"
+#include "aql_queue.h"
 
 using namespace l2k;
 
@@ -50,6 +51,8 @@ extern "C" int l2_device_count(void) {
 }
 
 static void destroy_graphs(l2_ctx* c) {
+  for (int i = 0; i < NLEV; ++i) if (c->aql_greedy[i]) { aql_program_free(c->aql_greedy[i]); c->aql_greedy[i] = nullptr; }      // (their kernel arguments hold pointers and shapes of the step as it was)
+  if (c->aql) aql_reset(c->aql);
   for (int i = 0; i < NLEV; ++i) {
     if (c->g_step[i]) { hipGraphExecDestroy(c->g_step[i]); c->g_step[i] = nullptr; }
     if (c->g_greedy[i]) { hipGraphExecDestroy(c->g_greedy[i]); c->g_greedy[i] = nullptr; }
@@ -90,6 +93,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   destroy_graphs(c);
+  if (c->aql) { aql_destroy(c->aql); c->aql = nullptr; }
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   if (c->loop_tmp) hipFree(c->loop_tmp);
   for (void* m : c->p2p_opened) hipIpcCloseMemHandle(m);
@@ -178,6 +182,12 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->opt_one_copy = dev_int("L2_ONE_COPY", 1);
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !hook_int("L2_TP_FORCE_COMM")) ? 1 : 0);
   c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
+  c->opt_aql = env_int("L2_AQL", 1);
+  // fences between the launches of a run on the library's own queue: no acquire, an agent-scope release, and an agent-scope acquire
+  // on the first launch of every token (kernels.hip.h: the coherence rule).  L2_AQL_FENCE=<scope> sets both (1 = what a hipGraph
+  // node carries); L2_AQL_ACQ / L2_AQL_REL / L2_AQL_TOKACQ one at a time (A/B, development switches)
+  { const int f = dev_int("L2_AQL_FENCE", -1);
+    c->aql_fence = dev_int("L2_AQL_ACQ", f < 0 ? 0 : f) + 4 * dev_int("L2_AQL_REL", f < 0 ? 1 : f) + 16 * dev_int("L2_AQL_TOKACQ", f < 0 ? 1 : 0); }
   c->p2p_fenced = env_int("L2_TP_FENCED", 0) ? 1 : 0;
   c->opt_push = dev_int("L2_TP_PUSH", 1) && !c->p2p_fenced;      // (the fenced form is the flag exchange)
   c->opt_awo = dev_int("L2_TP_ATTN_WO", 1);
@@ -713,8 +723,8 @@ static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step:
   const bool fold = !c->tp_path;
   int rc = enqueue_forward_impl(c, st, false, fold);
   if (rc) return rc;
-  if (fold) hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(64), 0, st, c->amax, c->tokpos, c->d_tokens);
-  else hipLaunchKernelGGL(argmax_advance_kernel, dim3(1), dim3(1024), 0, st, c->logits, c->V, c->tokpos, c->d_tokens);
+  if (fold) l2_launch(c, argmax_finish_kernel, dim3(1), dim3(64), 0, st, c->amax, c->tokpos, c->d_tokens);
+  else l2_launch(c, argmax_advance_kernel, dim3(1), dim3(1024), 0, st, (const float*)c->logits, c->V, c->tokpos, c->d_tokens);
   LCHK(hipGetLastError());
   return L2_OK;
 }
@@ -792,6 +802,62 @@ extern "C" float* l2_logits_host(l2_ctx* c) { return c ? c->h_logits : nullptr; 
 
 #include "prefill_host.hip.h"
 
+// ---- the greedy loop on the library's own AQL queue (aql_queue.h) ---------------------------------------------------------------
+// One GPU, the step a pure chain of kernels (no RCCL, no loopback barriers), graphs enabled, no probe: everything a hipGraph would
+// replay is replayed as hand-written packets instead.
+static bool aql_usable(const l2_ctx* c) {
+  return c->opt_aql && c->opt_graph && !c->tp_path && !c->loop && !c->probe_on && !c->profile_sync && (c->aql || !c->aql_tried);
+}
+
+static int aql_open(l2_ctx* c) {
+  c->aql_tried = true;
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), c->device) != hipSuccess) { c->aql_note = "hipDeviceGetPCIBusId failed"; return -1; }
+  unsigned dom = 0, b = 0, d = 0, f = 0;
+  if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) { c->aql_note = std::string("cannot parse PCI bus id ") + bus; return -1; }
+  Dl_info info;
+  if (!dladdr((const void*)&l2_abi_version, &info) || !info.dli_fname) { c->aql_note = "dladdr: the library cannot find its own file"; return -1; }
+  char err[512] = "";
+  c->aql = aql_create((int)dom, (int)b, (int)d, (int)f, info.dli_fname, err, sizeof(err));
+  if (!c->aql) { c->aql_note = err; return -1; }
+  return 0;
+}
+
+static int enqueue_greedy(l2_ctx* c, hipStream_t st);
+
+static int run_greedy_aql(l2_ctx* c, int pos0, int steps, bool timed, float* ms) {
+  if (!c->aql && aql_open(c)) return L2_RUN_EAGER;
+  // record the step of every level this run crosses (once per level: destroy_graphs drops the recordings with the graphs)
+  bool recorded = false;
+  for (int s = 0; s < steps; ++s) {
+    const int lvl = split_level(c, pos0 + s);
+    if (c->aql_greedy[lvl]) continue;
+    set_level(c, lvl);
+    AqlProgram* p = aql_program_new(c->aql);
+    c->aql_rec = p; c->aql_rec_failed = false;
+    const int rc = enqueue_greedy(c, c->stream);
+    c->aql_rec = nullptr;
+    if (rc || c->aql_rec_failed) {
+      c->aql_note = std::string("recording the step failed: ") + (rc ? l2_last_error() : aql_last_error(c->aql));
+      aql_program_free(p);
+      destroy_graphs(c);
+      aql_destroy(c->aql); c->aql = nullptr;
+      return L2_RUN_EAGER;
+    }
+    c->aql_greedy[lvl] = p;
+    recorded = true;
+  }
+  if (recorded && aql_upload(c->aql)) { c->aql_note = aql_last_error(c->aql); destroy_graphs(c); aql_destroy(c->aql); c->aql = nullptr; return L2_RUN_EAGER; }
+  HIPCHK(hipStreamSynchronize(c->stream));      // {token, pos}, the argmax keys: the HIP stream's work is done before the queue starts
+  std::vector<AqlProgram*> per(steps);
+  for (int s = 0; s < steps; ++s) per[s] = c->aql_greedy[split_level(c, pos0 + s)];
+  double us = 0.0;
+  if (aql_run(c->aql, steps, per.data(), c->aql_fence, &us)) return fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
+  if (timed && ms) *ms = (float)(us * 1e-3);
+  c->ran_forward = true;
+  return check_p2p(c);
+}
+
 static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool timed, float* ms) {
   if (!c) return fail(L2_E_ARG, "null context");
   if (steps < 0 || pos0 < 0 || pos0 + steps > c->S) return fail(L2_E_ARG, "pos0 %d + steps %d exceeds seq_len %d", pos0, steps, c->S);
@@ -802,6 +868,10 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(c->amax, 0, 8 * 16 * 8, c->stream));   // argmax keys: zero at the start of every run (an aborted sampled step may have left some)
+  if (aql_usable(c)) {
+    const int rc_a = run_greedy_aql(c, pos0, steps, timed, ms);
+    if (rc_a != L2_RUN_EAGER) return rc_a;      // (L2_RUN_EAGER: the queue could not be had -- the note says why -- and the run goes on below)
+  }
   if (c->opt_graph) {   // capture what this run needs before the timed region
     for (int s = 0; s < steps; ++s) {
       const int lvl = split_level(c, pos0 + s);
@@ -945,6 +1015,7 @@ extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
       return L2_OK;
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
     case L2_OPT_KEEP_STATE: if (c->opt_keep_state != !!value) { c->opt_keep_state = !!value; destroy_graphs(c); } return L2_OK;
+    case L2_OPT_AQL_QUEUE: c->opt_aql = !!value; if (value) c->aql_tried = false; return L2_OK;
     case L2_OPT_PACKED_MIB: case L2_OPT_WEIGHT_MIB: case L2_OPT_SAMPLED_TOKENS: case L2_OPT_SAMPLED_SERIAL:
       return fail(L2_E_ARG, "option %d is read-only", key);
     default: return fail(L2_E_ARG, "unknown option %d", key);
@@ -957,6 +1028,10 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
     case L2_OPT_EXACT_ATTENTION: *value = c->opt_exact; return L2_OK;
     case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
     case L2_OPT_KEEP_STATE: *value = c->opt_keep_state; return L2_OK;
+    case L2_OPT_AQL_QUEUE:
+      *value = (c->opt_aql && (c->aql || !c->aql_tried) && !c->tp_path && !c->loop) ? 1 : 0;
+      if (!*value && !c->aql_note.empty()) fail(L2_OK, "AQL queue not in use: %s", c->aql_note.c_str());
+      return L2_OK;
     case L2_OPT_PACKED_MIB: {
       size_t floats = 0;
       if (c->packed_valid) for (int m = 0; m < 5; ++m) if (c->packed[m].buf) floats += c->packed[m].layer_elems * (size_t)(m == MODE_CLS ? 1 : c->L);

@@ -25,7 +25,7 @@ TENSOR_NAMES = ["token_embedding_table", "rms_att_weight", "wq", "wk", "wv", "wo
 S_X, S_XB, S_XB2, S_HB, S_HB2, S_Q, S_K, S_V, S_ATT, S_LOGITS, S_KEY_CACHE, S_VALUE_CACHE = range(12)
 STATE_IDS = dict(x=S_X, xb=S_XB, xb2=S_XB2, hb=S_HB, hb2=S_HB2, q=S_Q, k=S_K, v=S_V, att=S_ATT, logits=S_LOGITS,
                  key_cache=S_KEY_CACHE, value_cache=S_VALUE_CACHE)
-OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_KEEP_STATE, OPT_PACKED_MIB, OPT_WEIGHT_MIB, OPT_SAMPLED_TOKENS, OPT_SAMPLED_SERIAL = 1, 2, 3, 4, 5, 6, 7
+OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_KEEP_STATE, OPT_PACKED_MIB, OPT_WEIGHT_MIB, OPT_SAMPLED_TOKENS, OPT_SAMPLED_SERIAL, OPT_AQL_QUEUE = 1, 2, 3, 4, 5, 6, 7, 8
 F_GQA, F_GENERATE_ROPE = 1, 2     # l2_create_ex flags
 TP_SOLO_ID = b"L2-SOLO-SHARD-TIMING"   # l2_create_tp id of a shard-timing context (include/llama2_hip.h: L2_TP_SOLO_ID)
 
