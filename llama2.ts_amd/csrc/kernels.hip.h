@@ -1068,6 +1068,13 @@ __global__ void __launch_bounds__(64) argmax_finish_kernel(unsigned long long* a
   }
 }
 
+// The blocking call (llama2.ts:468) on the library's own queue: {token, pos} of the call come from pinned host memory -- one load over
+// PCIe by one wave in front of the step, instead of a stream copy and its boundary in front of a graph launch.
+__global__ void __launch_bounds__(64) set_tokpos_kernel(const int* host_tokpos, int* tokpos) {
+  const int lane = threadIdx.x;
+  if (lane < 4) tokpos[lane] = __hip_atomic_load(host_tokpos + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void __launch_bounds__(1024) argmax_advance_kernel(const float* logits, int V, int* tokpos, int* tokens_out) {
   __shared__ unsigned long long sk[16];
   const int tid = threadIdx.x;

@@ -51,7 +51,10 @@ extern "C" int l2_device_count(void) {
 }
 
 static void destroy_graphs(l2_ctx* c) {
-  for (int i = 0; i < NLEV; ++i) if (c->aql_greedy[i]) { aql_program_free(c->aql_greedy[i]); c->aql_greedy[i] = nullptr; }      // (their kernel arguments hold pointers and shapes of the step as it was)
+  for (int i = 0; i < NLEV; ++i) {      // (their kernel arguments hold pointers and shapes of the step as it was)
+    if (c->aql_greedy[i]) { aql_program_free(c->aql_greedy[i]); c->aql_greedy[i] = nullptr; }
+    if (c->aql_step[i]) { aql_program_free(c->aql_step[i]); c->aql_step[i] = nullptr; }
+  }
   if (c->aql) aql_reset(c->aql);
   for (int i = 0; i < NLEV; ++i) {
     if (c->g_step[i]) { hipGraphExecDestroy(c->g_step[i]); c->g_step[i] = nullptr; }
@@ -267,6 +270,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
   CK(hipMalloc(&c->d_tokens, (size_t)S * sizeof(int)));
   CK(hipHostMalloc(&c->h_tokpos, 4 * sizeof(int), hipHostMallocDefault));
+  CK(hipHostGetDevicePointer((void**)&c->h_tokpos_dev, c->h_tokpos, 0));
   CK(hipHostMalloc(&c->h_logits, (size_t)V * 4, hipHostMallocMapped));
   memset(c->h_logits, 0, (size_t)V * 4);
   CK(hipHostGetDevicePointer((void**)&c->h_logits_dev, c->h_logits, 0));
@@ -694,6 +698,11 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
 }
 
 static int enqueue_forward_host(l2_ctx* c, hipStream_t st) { return enqueue_forward_impl(c, st, true); }
+// ... behind the launch that fetches {token, pos} of the call from pinned host memory (the blocking call on the library's own queue)
+static int enqueue_forward_call(l2_ctx* c, hipStream_t st) {
+  l2_launch(c, set_tokpos_kernel, dim3(1), dim3(64), 0, st, (const int*)c->h_tokpos_dev, c->tokpos);
+  return enqueue_forward_impl(c, st, true);
+}
 
 static int ensure_ready(l2_ctx* c) {
   // everything below may allocate and launch (ensure_packed): the context's device first, whatever the calling thread had current
@@ -766,42 +775,6 @@ static int capture(l2_ctx* c, int (*enq)(l2_ctx*, hipStream_t), hipGraphExec_t* 
   return rc;
 }
 
-extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
-  if (!c) return fail(L2_E_ARG, "null context");
-  if (pos < 0 || pos >= c->S) return fail(L2_E_ARG, "pos %d outside [0, seq_len=%d)", pos, c->S);
-  if (token < 0 || token >= c->V) return fail(L2_E_ARG, "token %d outside [0, vocab_size=%d)", token, c->V);
-  int rc = ensure_ready(c);
-  if (rc) return rc;
-  HIPCHK(hipSetDevice(c->device));
-  c->h_tokpos[0] = token; c->h_tokpos[1] = pos; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
-  // {token,pos} in and logits out travel as plain stream copies around the replayed kernel graph
-  // (memcpy nodes inside a captured graph crash rocprofv3's kernel trace on ROCm 7.2)
-  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  const int lvl = split_level(c, pos);
-  set_level(c, lvl);
-  if (c->opt_graph) {
-    if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc && rc != L2_RUN_EAGER) return rc; }
-  }
-  if (c->opt_graph) {
-    HIPCHK(hipGraphLaunch(c->g_step[lvl], c->stream));
-  } else {
-    rc = enqueue_forward_host(c, c->stream);
-    if (rc) return rc;
-  }
-  if (!(c->opt_zero_copy && !c->tp_path))
-    HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  c->ran_forward = true;
-  rc = check_p2p(c);
-  if (rc) return rc;
-  if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
-  return L2_OK;
-}
-
-extern "C" float* l2_logits_host(l2_ctx* c) { return c ? c->h_logits : nullptr; }
-
-#include "prefill_host.hip.h"
-
 // ---- the greedy loop on the library's own AQL queue (aql_queue.h) ---------------------------------------------------------------
 // One GPU, the step a pure chain of kernels (no RCCL, no loopback barriers), graphs enabled, no probe: everything a hipGraph would
 // replay is replayed as hand-written packets instead.
@@ -825,29 +798,29 @@ static int aql_open(l2_ctx* c) {
 
 static int enqueue_greedy(l2_ctx* c, hipStream_t st);
 
+// Record the step of level `lvl` (once per level: destroy_graphs drops the recordings with the graphs) -- the same enqueue a hipGraph
+// captures, every launch turned into a packet by l2_launch.  L2_RUN_EAGER: the queue is given up (the note says why).
+static int aql_record_level(l2_ctx* c, int lvl, int (*enq)(l2_ctx*, hipStream_t), AqlProgram** slot) {
+  if (*slot) return L2_OK;
+  set_level(c, lvl);
+  AqlProgram* p = aql_program_new(c->aql);
+  c->aql_rec = p; c->aql_rec_failed = false;
+  const int rc = enq(c, c->stream);
+  c->aql_rec = nullptr;
+  if (!rc && !c->aql_rec_failed && !aql_upload(c->aql)) { *slot = p; return L2_OK; }
+  c->aql_note = std::string("recording the step failed: ") + (rc ? l2_last_error() : aql_last_error(c->aql));
+  aql_program_free(p);
+  destroy_graphs(c);
+  aql_destroy(c->aql); c->aql = nullptr;
+  return L2_RUN_EAGER;
+}
+
 static int run_greedy_aql(l2_ctx* c, int pos0, int steps, bool timed, float* ms) {
   if (!c->aql && aql_open(c)) return L2_RUN_EAGER;
-  // record the step of every level this run crosses (once per level: destroy_graphs drops the recordings with the graphs)
-  bool recorded = false;
   for (int s = 0; s < steps; ++s) {
     const int lvl = split_level(c, pos0 + s);
-    if (c->aql_greedy[lvl]) continue;
-    set_level(c, lvl);
-    AqlProgram* p = aql_program_new(c->aql);
-    c->aql_rec = p; c->aql_rec_failed = false;
-    const int rc = enqueue_greedy(c, c->stream);
-    c->aql_rec = nullptr;
-    if (rc || c->aql_rec_failed) {
-      c->aql_note = std::string("recording the step failed: ") + (rc ? l2_last_error() : aql_last_error(c->aql));
-      aql_program_free(p);
-      destroy_graphs(c);
-      aql_destroy(c->aql); c->aql = nullptr;
-      return L2_RUN_EAGER;
-    }
-    c->aql_greedy[lvl] = p;
-    recorded = true;
+    if (aql_record_level(c, lvl, enqueue_greedy, &c->aql_greedy[lvl])) return L2_RUN_EAGER;
   }
-  if (recorded && aql_upload(c->aql)) { c->aql_note = aql_last_error(c->aql); destroy_graphs(c); aql_destroy(c->aql); c->aql = nullptr; return L2_RUN_EAGER; }
   HIPCHK(hipStreamSynchronize(c->stream));      // {token, pos}, the argmax keys: the HIP stream's work is done before the queue starts
   std::vector<AqlProgram*> per(steps);
   for (int s = 0; s < steps; ++s) per[s] = c->aql_greedy[split_level(c, pos0 + s)];
@@ -857,6 +830,54 @@ static int run_greedy_aql(l2_ctx* c, int pos0, int steps, bool timed, float* ms)
   c->ran_forward = true;
   return check_p2p(c);
 }
+
+extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
+  if (!c) return fail(L2_E_ARG, "null context");
+  if (pos < 0 || pos >= c->S) return fail(L2_E_ARG, "pos %d outside [0, seq_len=%d)", pos, c->S);
+  if (token < 0 || token >= c->V) return fail(L2_E_ARG, "token %d outside [0, vocab_size=%d)", token, c->V);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  c->h_tokpos[0] = token; c->h_tokpos[1] = pos; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
+  const int lvl = split_level(c, pos);
+  set_level(c, lvl);
+  if (aql_usable(c) && c->opt_zero_copy && (c->aql || !aql_open(c)) && !aql_record_level(c, lvl, enqueue_forward_call, &c->aql_step[lvl])) {
+    // the library's own queue: {token, pos} read from pinned host memory by the first launch, logits written straight into the
+    // host's buffer by the classifier, one doorbell, one signal
+    HIPCHK(hipStreamSynchronize(c->stream));      // (uploads, an earlier graph's work)
+    if (aql_run(c->aql, 1, &c->aql_step[lvl], c->aql_fence, nullptr)) return fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
+    c->ran_forward = true;
+    rc = check_p2p(c);
+    if (rc) return rc;
+    if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
+    return L2_OK;
+  }
+  set_level(c, lvl);
+  // {token,pos} in and logits out travel as plain stream copies around the replayed kernel graph
+  // (memcpy nodes inside a captured graph crash rocprofv3's kernel trace on ROCm 7.2)
+  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (c->opt_graph) {
+    if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc && rc != L2_RUN_EAGER) return rc; }
+  }
+  if (c->opt_graph) {
+    HIPCHK(hipGraphLaunch(c->g_step[lvl], c->stream));
+  } else {
+    rc = enqueue_forward_host(c, c->stream);
+    if (rc) return rc;
+  }
+  if (!(c->opt_zero_copy && !c->tp_path))
+    HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->V * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->ran_forward = true;
+  rc = check_p2p(c);
+  if (rc) return rc;
+  if (logits_out) memcpy(logits_out, c->h_logits, (size_t)c->V * 4);
+  return L2_OK;
+}
+
+extern "C" float* l2_logits_host(l2_ctx* c) { return c ? c->h_logits : nullptr; }
+
+#include "prefill_host.hip.h"
 
 static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool timed, float* ms) {
   if (!c) return fail(L2_E_ARG, "null context");
