@@ -113,6 +113,24 @@ static std::vector<Bundle> find_code_objects(const std::vector<char>& f) {
   return out;
 }
 
+static bool read_file(const char* path, std::vector<char>& out) {
+  FILE* f = path ? fopen(path, "rb") : nullptr;
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(sz > 0 ? (size_t)sz : 0);
+  const size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), f);
+  fclose(f);
+  return got == out.size() && got > 0;
+}
+
+int aql_count_code_objects(const char* so_path) {
+  std::vector<char> f;
+  if (!read_file(so_path, f)) return -1;
+  return (int)find_code_objects(f).size();
+}
+
 AqlQueue* aql_create(int pci_domain, int pci_bus, int pci_device, int pci_function, const char* so_path, char* err, size_t errlen) {
   AqlQueue* q = new AqlQueue();
   auto bail = [&](const char* what, hsa_status_t s) -> AqlQueue* {
@@ -132,15 +150,7 @@ AqlQueue* aql_create(int pci_domain, int pci_bus, int pci_device, int pci_functi
   if (!fp.found) { snprintf(q->err, sizeof(q->err), "the GPU agent has no coarse-grained pool"); return bail("pool", HSA_STATUS_SUCCESS); }
   q->dev_pool = fp.out;
   // ---- the kernels: the library's own gfx950 code objects
-  FILE* f = so_path ? fopen(so_path, "rb") : nullptr;
-  if (!f) { snprintf(q->err, sizeof(q->err), "cannot open %s", so_path ? so_path : "(null)"); return bail("library", HSA_STATUS_SUCCESS); }
-  fseek(f, 0, SEEK_END);
-  const long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  q->file.resize(sz > 0 ? (size_t)sz : 0);
-  const size_t got = fread(q->file.data(), 1, q->file.size(), f);
-  fclose(f);
-  if (got != q->file.size() || !got) { snprintf(q->err, sizeof(q->err), "short read of %s", so_path); return bail("library", HSA_STATUS_SUCCESS); }
+  if (!read_file(so_path, q->file)) { snprintf(q->err, sizeof(q->err), "cannot read %s", so_path ? so_path : "(null)"); return bail("library", HSA_STATUS_SUCCESS); }
   const std::vector<Bundle> cos = find_code_objects(q->file);
   if (cos.empty()) { snprintf(q->err, sizeof(q->err), "no gfx950 code object in %s", so_path); return bail("library", HSA_STATUS_SUCCESS); }
   s = hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &q->exe);

@@ -44,3 +44,5 @@ int aql_upload(AqlQueue* q);
 // launches (AQL_FENCE_*; the run's first acquire and last release are always system scope).  elapsed_us (optional): first doorbell -> completion.
 int aql_run(AqlQueue* q, int ntok, AqlProgram* const* per_token, int fence, double* elapsed_us);
 const char* aql_last_error(const AqlQueue* q);
+// How many gfx950 code objects the offload bundles of `so_path` hold (file parsing only: no GPU, no HSA); -1: the file cannot be read.
+int aql_count_code_objects(const char* so_path);

@@ -1079,20 +1079,23 @@ __global__ void __launch_bounds__(1024) argmax_advance_kernel(const float* logit
   __shared__ unsigned long long sk[16];
   const int tid = threadIdx.x;
   int p1 = 0, step = 0;
-  if (tid == 0) { p1 = tokpos[1]; step = tokpos[2]; }
+  if (tid == 0) {      // (past L1: the coherence rule)
+    p1 = (int)__hip_atomic_load(reinterpret_cast<const unsigned*>(tokpos + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    step = (int)__hip_atomic_load(reinterpret_cast<const unsigned*>(tokpos + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   unsigned long long best = 0;
   if ((V & 3) == 0) {   // 16-byte loads, all issued before the first compare
-    const f4* l4 = reinterpret_cast<const f4*>(logits);
+    const auto lrs = L2_ACT_RSRC(logits, V);
 #pragma unroll 8
     for (int c = tid; c < V / 4; c += 1024) {
-      const f4 v = l4[c];
+      const f4 v = L2_ACT_LD4(lrs, c);
       unsigned long long k = argmax_key(v.x, 4 * c); best = k > best ? k : best;
       k = argmax_key(v.y, 4 * c + 1); best = k > best ? k : best;
       k = argmax_key(v.z, 4 * c + 2); best = k > best ? k : best;
       k = argmax_key(v.w, 4 * c + 3); best = k > best ? k : best;
     }
   } else {
-    for (int i = tid; i < V; i += 1024) { const unsigned long long k = argmax_key(logits[i], i); best = k > best ? k : best; }
+    for (int i = tid; i < V; i += 1024) { const unsigned long long k = argmax_key(ld_sc1(logits + i), i); best = k > best ? k : best; }
   }
   best = wave_max_u64(best);
   if ((tid & 63) == 0) sk[tid >> 6] = best;

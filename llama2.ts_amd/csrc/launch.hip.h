@@ -363,7 +363,7 @@ static hipError_t launch_attn_wo(const l2_ctx* c, int l, const PhaseArgs& wo_in,
   const size_t lds_a = attn_tile_lds(c->S, at.nsplit, 8, 8), lds_w = (size_t)xv * 64 * 16, lds = lds_a > lds_w ? lds_a : lds_w;
   const dim3 grid(nattn + nwo), block(512);
 #define L2_AWO(XVV) do { hipError_t e_ = lds_opt_in(&attn_wo_kernel<XVV, 2, 32, 8, 8>, lds); if (e_ != hipSuccess) return e_; \
-                         hipLaunchKernelGGL((attn_wo_kernel<XVV, 2, 32, 8, 8>), grid, block, lds, st, at, wo, nattn); } while (0)
+                         l2_launch(c, attn_wo_kernel<XVV, 2, 32, 8, 8>, grid, block, lds, st, at, wo, nattn); } while (0)
   if (xv == 2) L2_AWO(2); else if (xv == 4) L2_AWO(4); else L2_AWO(8);
 #undef L2_AWO
   return hipGetLastError();

@@ -685,7 +685,7 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
   LCHK(launch_phase<MODE_CLS>(c, a, st));
   if (c->p2p) {
     const dim3 grid(p2p_grid(c->V_loc));
-    if (!c->loop) hipLaunchKernelGGL(tp_p2p_gather_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->V_loc), c->logits_loc);
+    if (!c->loop) l2_launch(c, tp_p2p_gather_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->V_loc), (const float*)c->logits_loc);
     else {
       hipLaunchKernelGGL(tp_p2p_gather_kernel<1>, grid, dim3(256), 0, st, p2p_args(c, c->V_loc), c->logits_loc);
       HIPCHK(hipStreamSynchronize(st));
@@ -779,11 +779,29 @@ static int capture(l2_ctx* c, int (*enq)(l2_ctx*, hipStream_t), hipGraphExec_t* 
 // One GPU, the step a pure chain of kernels (no RCCL, no loopback barriers), graphs enabled, no probe: everything a hipGraph would
 // replay is replayed as hand-written packets instead.
 static bool aql_usable(const l2_ctx* c) {
-  return c->opt_aql && c->opt_graph && !c->tp_path && !c->loop && !c->probe_on && !c->profile_sync && (c->aql || !c->aql_tried);
+  // (a tensor-parallel rank: only when its exchanges are kernels too -- the one-shot peer-to-peer form; RCCL collectives are the runtime's)
+  if (c->tp_path && !(c->p2p && !c->loop && c->p2p_peers_ready)) return false;
+  return c->opt_aql && c->opt_graph && !c->loop && !c->probe_on && !c->profile_sync && (c->aql || !c->aql_tried);
+}
+
+// A profiler's tool library wraps every HSA queue of the process in an intercept queue and rewrites the packets it finds there;
+// rocprofv3 (ROCm 7.2) crashes on packets written by hand (profiles/r05/aql_under_rocprof.txt).  Under one, the loop stays with HIP launches.
+static bool hsa_tools_loaded() {
+  for (const char* k : {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIBRARY", "ROCPROFILER_REGISTER_FORCE_LOAD"}) { const char* v = getenv(k); if (v && *v) return true; }
+  const char* pre = getenv("LD_PRELOAD");
+  return pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer"));
+}
+
+// (tests, no GPU needed) how many gfx950 code objects the AQL queue would load out of this library's own file
+extern "C" int l2_debug_aql_code_objects(void) {
+  Dl_info info;
+  if (!dladdr((const void*)&l2_abi_version, &info) || !info.dli_fname) return -1;
+  return aql_count_code_objects(info.dli_fname);
 }
 
 static int aql_open(l2_ctx* c) {
   c->aql_tried = true;
+  if (hsa_tools_loaded()) { c->aql_note = "a profiler's tool library intercepts the HSA queues of this process"; return -1; }
   char bus[64] = "";
   if (hipDeviceGetPCIBusId(bus, sizeof(bus), c->device) != hipSuccess) { c->aql_note = "hipDeviceGetPCIBusId failed"; return -1; }
   unsigned dom = 0, b = 0, d = 0, f = 0;
@@ -841,7 +859,7 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
   c->h_tokpos[0] = token; c->h_tokpos[1] = pos; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   const int lvl = split_level(c, pos);
   set_level(c, lvl);
-  if (aql_usable(c) && c->opt_zero_copy && (c->aql || !aql_open(c)) && !aql_record_level(c, lvl, enqueue_forward_call, &c->aql_step[lvl])) {
+  if (aql_usable(c) && c->opt_zero_copy && !c->tp_path && (c->aql || !aql_open(c)) && !aql_record_level(c, lvl, enqueue_forward_call, &c->aql_step[lvl])) {
     // the library's own queue: {token, pos} read from pinned host memory by the first launch, logits written straight into the
     // host's buffer by the classifier, one doorbell, one signal
     HIPCHK(hipStreamSynchronize(c->stream));      // (uploads, an earlier graph's work)
@@ -1050,7 +1068,7 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
     case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
     case L2_OPT_KEEP_STATE: *value = c->opt_keep_state; return L2_OK;
     case L2_OPT_AQL_QUEUE:
-      *value = (c->opt_aql && (c->aql || !c->aql_tried) && !c->tp_path && !c->loop) ? 1 : 0;
+      *value = aql_usable(c) ? 1 : 0;
       if (!*value && !c->aql_note.empty()) fail(L2_OK, "AQL queue not in use: %s", c->aql_note.c_str());
       return L2_OK;
     case L2_OPT_PACKED_MIB: {

@@ -27,7 +27,11 @@
 //     the fence-free one is guarded by the soak at creation (below) and by bench.py's golden check before it times anything -- a
 //     deployment that sees ranks diverge has this switch before it has a new build.
 
-__device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) { return a.epoch[blockIdx.x] + 1; }
+// (past L1 and not through the scalar cache: the launch before this one advanced it -- the coherence rule of kernels.hip.h)
+__device__ __forceinline__ unsigned long long p2p_begin(const P2PArgs& a) {
+  const unsigned long long e = __hip_atomic_load(a.epoch + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(e >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)e)) + 1;
+}
 
 __device__ __forceinline__ void p2p_store(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, con
   const size_t slot = (size_t)((int)(e & 1) * P2P_MAXG) * a.n;      // (e: this block's epoch -- every block of a launch has the same one in a reduce)
   if (PART != 2) {
     for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
-      const double v = partial[i];
+      const double v = ld_sc1(partial + i);
       for (int p = 0; p < a.G; ++p) p2p_store(a.pr.inbox[a.solo ? a.rank : p] + slot + (size_t)(a.solo ? p : a.rank) * a.n + i, v);
     }
   }
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(256) tp_p2p_reduce_kernel(const P2PArgs a, con
     double s = part[0];
 #pragma unroll
     for (int r = 1; r < P2P_MAXG; ++r) if (r < a.G) s += part[r];      // rank order on every rank
-    const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : x[i];
+    const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : ld_sc1(x + i);
     const float mv = (float)s;
     x[i] = xr + mv;
     if (mv_out) mv_out[i] = mv;
@@ -121,12 +125,12 @@ __global__ void __launch_bounds__(256) tp_p2p_combine_kernel(const P2PArgs a, fl
   const int tid = threadIdx.x, stride = gridDim.x * 256;
   // the launch counter of the fused attention + wo launch in front of this one: every workgroup of that launch has read it (the
   // launch is over), the next one reads the new number
-  if (bump && blockIdx.x == 0 && tid == 0) *bump = *bump + 1u;
+  if (bump && blockIdx.x == 0 && tid == 0) __hip_atomic_store(bump, __hip_atomic_load(bump, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long e = p2p_begin(a);
   const unsigned tag = (unsigned)e;
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.pr.gin[a.rank], 0, (unsigned)((size_t)2 * P2P_MAXG * a.n * 16), 0x00020000);
   for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
-    const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : x[i];      // requested before the wait
+    const float xr = res_emb ? res_emb[(size_t)tokpos[0] * a.n + i] : ld_sc1(x + i);      // requested before the wait
     const unsigned base = (unsigned)(((size_t)((unsigned)(e & 1) * P2P_MAXG) * a.n + i) * 16);
     u32x4 g[P2P_MAXG];
     unsigned spins = 0;
@@ -164,7 +168,7 @@ __global__ void __launch_bounds__(256) tp_p2p_gather_kernel(const P2PArgs a, con
   const unsigned long long e = p2p_begin(a);
   if (PART != 2) {
     for (int i = blockIdx.x * 256 + tid; i < a.n; i += stride) {
-      const float v = mine[i];
+      const float v = ld_sc1(mine + i);
       for (int p = 0; p < a.G; ++p) p2p_store(a.pr.logits[a.solo ? a.rank : p] + (size_t)(a.solo ? p : a.rank) * a.n + i, v);
     }
   }
@@ -430,9 +434,9 @@ static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
 static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out, unsigned* bump) {
   const dim3 grid(p2p_grid(c->d));
   if (p2p_pushing(c)) {
-    hipLaunchKernelGGL(tp_p2p_combine_kernel, grid, dim3(256), 0, st, p2p_args(c, c->d), c->x, res_emb, mv_out, c->tokpos, bump);
+    l2_launch(c, tp_p2p_combine_kernel, grid, dim3(256), 0, st, p2p_args(c, c->d), c->x, res_emb, mv_out, (const int*)c->tokpos, bump);
   } else if (!c->loop) {
-    hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
+    l2_launch(c, tp_p2p_reduce_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->d), (const double*)c->partial, c->x, res_emb, mv_out, (const int*)c->tokpos);
   } else {
     hipLaunchKernelGGL(tp_p2p_reduce_kernel<1>, grid, dim3(256), 0, st, p2p_args(c, c->d), c->partial, c->x, res_emb, mv_out, c->tokpos);
     HIPCHK(hipStreamSynchronize(st));

@@ -1,0 +1,105 @@
+"""The decode step on the library's own AQL queue (csrc/aql_queue.h; llama2.ts:465-508 for the greedy loop, :468 for the blocking
+call): a token's launches as hand-written packets with an agent-scope release and NO acquire fence between them, the kernels
+loading every byte an earlier launch wrote past L1 (kernels.hip.h: the coherence rule).  Everything it decodes must equal what the
+same context decodes through replayed hipGraphs (the runtime's own fences around every kernel node) and the real reference's goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from llama2_ts_amd import configs, runtime
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold_tokens(name):
+    return json.load(open(os.path.join(GOLD, name + ".json")))["argmax"]
+
+
+@pytest.mark.parametrize("name,steps", [("tiny", 64), ("ragged", 33), ("tinylong", 1280), ("stories15M", 256), ("stories110M", 1024), ("llama2_7b_L2", 300)])
+def test_greedy_loop_on_the_queue_equals_graph_replay_and_the_reference(name, steps):
+    """Every step level a run crosses (one workgroup per head, the fused QKV + attention launch, eight workgroups per head), the
+    latency and the streaming form, n % 4 != 0 shapes (scalar kernels): queue == graphs == the reference's tokens; a second run over
+    the same context (the cache rows of the first run are still in somebody's L2), a run that starts in mid-context."""
+    ctx = runtime.Context(configs.header(name))
+    ctx.synth_fill(configs.DEFAULT_SEED)
+    a = ctx.decode_greedy(1, 0, steps).tolist()
+    assert ctx.get_option(runtime.OPT_AQL_QUEUE) == 1, runtime.lib().l2_last_error()
+    want = gold_tokens(name)
+    assert a == want[:steps]
+    again = ctx.decode_greedy(1, 0, steps).tolist()
+    assert again == a
+    mid = steps // 3
+    assert ctx.decode_greedy(a[mid - 1], mid, steps - mid).tolist() == a[mid:]
+    ctx.set_option(runtime.OPT_AQL_QUEUE, 0)
+    assert ctx.get_option(runtime.OPT_AQL_QUEUE) == 0
+    assert ctx.decode_greedy(1, 0, steps).tolist() == a
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "stories15M", "stories110M"])
+def test_blocking_call_on_the_queue_equals_graph_replay_bit_for_bit(name):
+    """l2_forward through the queue ({token, pos} fetched from pinned host memory by the first launch, logits written straight into
+    the host's buffer) against l2_forward through a replayed hipGraph: the same kernels in the same order -- logits bit for bit, at
+    positions on both sides of every level change, with the greedy loop and prompt ingestion run in between (they leave their own
+    lines in the caches the call must not trust)."""
+    hdr = configs.header(name)
+    q, g = runtime.Context(hdr), runtime.Context(hdr)
+    for c in (q, g):
+        c.synth_fill(configs.DEFAULT_SEED)
+    g.set_option(runtime.OPT_AQL_QUEUE, 0)
+    S = hdr[6]
+    tok = 1
+    for pos in range(min(S, 300)):
+        a = np.array(q.forward(tok, pos), copy=True)
+        b = g.forward(tok, pos)
+        assert np.array_equal(a, b), (name, pos)
+        tok = runtime.argmax(a)
+        if pos == 40:      # the device loop in between, then the same position again
+            assert q.decode_greedy(tok, pos + 1, 8).tolist() == g.decode_greedy(tok, pos + 1, 8).tolist()
+    assert q.get_option(runtime.OPT_AQL_QUEUE) == 1 and g.get_option(runtime.OPT_AQL_QUEUE) == 0
+    toks = gold_tokens(name)[:20]
+    la, lb = q.prefill([1] + toks[:19], 0), g.prefill([1] + toks[:19], 0)
+    assert np.array_equal(la, lb)
+    assert np.array_equal(q.forward(toks[19], 20), g.forward(toks[19], 20))
+    q.close(); g.close()
+
+
+def test_fence_scopes_are_switches_not_requirements(monkeypatch):
+    """The packets' fence scopes can be raised for A/B runs (L2_AQL_FENCE=1: what a hipGraph node carries); results do not change."""
+    name, steps = "stories15M", 256
+    want = gold_tokens(name)[:steps]
+    for env in ({"L2_AQL_FENCE": "1"}, {"L2_AQL_FENCE": "2"}, {"L2_AQL_ACQ": "1", "L2_AQL_REL": "1", "L2_AQL_TOKACQ": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = runtime.Context(configs.header(name))
+        ctx.synth_fill(configs.DEFAULT_SEED)
+        assert ctx.decode_greedy(1, 0, steps).tolist() == want and ctx.get_option(runtime.OPT_AQL_QUEUE) == 1
+        ctx.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_queue_follows_option_changes_and_uploads():
+    """A recording holds the step's kernel arguments (pointers, shapes): whatever invalidates a captured graph invalidates it --
+    kept-state reads switched on (other launches), a matrix uploaded again."""
+    hdr = configs.header("stories15M")
+    ctx = runtime.Context(hdr)
+    ctx.synth_fill(configs.DEFAULT_SEED)
+    a = ctx.decode_greedy(1, 0, 40).tolist()
+    ctx.set_option(runtime.OPT_KEEP_STATE, 1)
+    assert ctx.decode_greedy(1, 0, 40).tolist() == a
+    assert np.abs(ctx.read_state("xb2")).max() > 0
+    ctx.set_option(runtime.OPT_KEEP_STATE, 0)
+    n = hdr[0] * hdr[0]
+    ctx.upload(runtime.T_WO, 2, np.zeros(n, dtype=np.float32))
+    b = ctx.decode_greedy(1, 0, 40).tolist()
+    assert b != a
+    other = runtime.Context(hdr)
+    other.set_option(runtime.OPT_AQL_QUEUE, 0)
+    other.synth_fill(configs.DEFAULT_SEED)
+    other.upload(runtime.T_WO, 2, np.zeros(n, dtype=np.float32))
+    assert other.decode_greedy(1, 0, 40).tolist() == b
+    ctx.close(); other.close()
