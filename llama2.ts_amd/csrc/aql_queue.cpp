@@ -22,6 +22,7 @@ struct Bundle { size_t off, size; };
 
 struct AqlProgram {
   std::vector<hsa_kernel_dispatch_packet_t> pk;      // header = 0 here; written last at submission
+  std::vector<uint8_t> flags;                        // AQL_LAUNCH_* per packet
 };
 
 struct AqlQueue {
@@ -212,7 +213,7 @@ static const Kernel* find_kernel(AqlQueue* q, const char* name) {
 }
 
 int aql_record(AqlQueue* q, AqlProgram* p, const char* kernel_name, const unsigned grid[3], const unsigned block[3], unsigned lds_dynamic,
-               const void* args, size_t arg_bytes) {
+               const void* args, size_t arg_bytes, unsigned flags) {
   if (!q || !p || !kernel_name) return -1;
   const Kernel* k = find_kernel(q, kernel_name);
   if (!k) return -1;
@@ -246,6 +247,7 @@ int aql_record(AqlQueue* q, AqlProgram* p, const char* kernel_name, const unsign
   pk.kernel_object = k->object;
   pk.kernarg_address = q->karg_dev + at;
   p->pk.push_back(pk);
+  p->flags.push_back((uint8_t)flags);
   return 0;
 }
 
@@ -296,7 +298,8 @@ int aql_run(AqlQueue* q, int ntok, AqlProgram* const* per_token, int fence, doub
       dst->completion_signal.handle = last ? q->done.handle : 0;
       // (fence bit 16: the FIRST launch of every token acquires at agent scope -- it refreshes the scalar caches, through which the
       // kernels read {token, pos}: those words change once per token, in its last launch)
-      const int acq_tok = ((fence & 16) && i == 0 && scope_a == HSA_FENCE_SCOPE_NONE) ? HSA_FENCE_SCOPE_AGENT : scope_a;
+      const bool wants_acq = ((fence & 16) && i == 0) || (p->flags[i] & AQL_LAUNCH_ACQUIRES);
+      const int acq_tok = (wants_acq && scope_a == HSA_FENCE_SCOPE_NONE) ? HSA_FENCE_SCOPE_AGENT : scope_a;
       const int acq = first ? HSA_FENCE_SCOPE_SYSTEM : acq_tok, rel = last ? HSA_FENCE_SCOPE_SYSTEM : scope_r;
       const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                          (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));

@@ -35,8 +35,11 @@ int aql_program_launches(const AqlProgram* p);
 // One launch: `kernel_name` as the code object names it (mangled), explicit arguments packed as the kernel-argument segment lays
 // them out (each at its natural alignment); the hidden arguments (block counts, group sizes, grid dimensions, dynamic LDS) are
 // filled in here.  0 or -1 (reason: aql_last_error).
+// flags: AQL_LAUNCH_ACQUIRES -- this launch acquires at agent scope whatever the run's fence setting: its kernel is not under the
+// coherence rule (kernels.hip.h) and reads earlier launches' bytes through its CU's caches (the sampler's kernels).
+enum { AQL_LAUNCH_ACQUIRES = 1 };
 int aql_record(AqlQueue* q, AqlProgram* p, const char* kernel_name, const unsigned grid_blocks[3], const unsigned block[3],
-               unsigned lds_dynamic, const void* args, size_t arg_bytes);
+               unsigned lds_dynamic, const void* args, size_t arg_bytes, unsigned flags = 0);
 // Kernel arguments of everything recorded so far -> device memory.  Call once after recording, before the first run.
 int aql_upload(AqlQueue* q);
 

@@ -54,6 +54,7 @@ static void destroy_graphs(l2_ctx* c) {
   for (int i = 0; i < NLEV; ++i) {      // (their kernel arguments hold pointers and shapes of the step as it was)
     if (c->aql_greedy[i]) { aql_program_free(c->aql_greedy[i]); c->aql_greedy[i] = nullptr; }
     if (c->aql_step[i]) { aql_program_free(c->aql_step[i]); c->aql_step[i] = nullptr; }
+    for (int m = 0; m < 4; ++m) if (c->aql_sample[i][m]) { aql_program_free(c->aql_sample[i][m]); c->aql_sample[i][m] = nullptr; }
   }
   if (c->aql) aql_reset(c->aql);
   for (int i = 0; i < NLEV; ++i) {
@@ -741,6 +742,21 @@ static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step:
 static int enqueue_sample(l2_ctx* c, hipStream_t st) {  // device-resident sampled step: forward, temperature/softmax/sample(_topp), advance
   int rc = enqueue_forward_impl(c, st, false, c->samp_amax);
   if (rc) return rc;
+  if (c->aql_rec) {
+    // the sampler's launches (their own translation unit) are handed over by its recorder; its kernels read logits, keys and
+    // {token, pos} through their CU's caches: each of them acquires (AQL_LAUNCH_ACQUIRES)
+    l2s::set_recorder([](void* user, const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t s2, const void* args, size_t nb) -> bool {
+      l2_ctx* m = (l2_ctx*)user;
+      const char* name = hipKernelNameRefByPtr(fn, s2);
+      const unsigned g[3] = {grid.x, grid.y, grid.z}, b[3] = {block.x, block.y, block.z};
+      return name && !aql_record(m->aql, m->aql_rec, name, g, b, (unsigned)lds, args, nb, AQL_LAUNCH_ACQUIRES);
+    }, c);
+    const hipError_t e = l2s::enqueue(c->samp, c->logits, c->samp_mode == 1, c->tokpos, c->d_tokens, c->samp_amax ? c->amax : nullptr, st);
+    if (l2s::recorder_failed()) c->aql_rec_failed = true;
+    l2s::set_recorder(nullptr, nullptr);
+    LCHK(e);
+    return L2_OK;
+  }
   LCHK(l2s::enqueue(c->samp, c->logits, c->samp_mode == 1, c->tokpos, c->d_tokens, c->samp_amax ? c->amax : nullptr, st));
   return L2_OK;
 }
@@ -962,6 +978,25 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
   HIPCHK(hipMemcpyAsync(c->samp.params, params, sizeof(params), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->samp.rng, rng_state, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));                 // the host sources above are stack / caller memory
+  if (aql_usable(c) && (c->aql || !aql_open(c))) {
+    // the sampled loop on the library's own queue: forward + sampler launches of every token as packets
+    const int mode = c->samp_mode + (c->samp_amax ? 2 : 0);
+    bool ok = true;
+    std::vector<AqlProgram*> per(steps);
+    for (int s = 0; s < steps && ok; ++s) {
+      const int lvl = split_level(c, pos0 + s);
+      if (aql_record_level(c, lvl, enqueue_sample, &c->aql_sample[lvl][mode])) ok = false;
+      else per[s] = c->aql_sample[lvl][mode];
+    }
+    if (ok) {
+      if (aql_run(c->aql, steps, per.data(), c->aql_fence, nullptr)) return fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
+      HIPCHK(hipMemcpyAsync(rng_state, c->samp.rng, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(tokens_out, c->d_tokens, (size_t)steps * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      c->ran_forward = true;
+      return check_p2p(c);
+    }
+  }
   const bool graph = c->opt_graph && !c->loop;
   for (int s = 0; s < steps; ++s) {
     const int lvl = split_level(c, pos0 + s);

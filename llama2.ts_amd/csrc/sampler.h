@@ -47,6 +47,13 @@ struct Sampler {
 
 enum { MAX_VOCAB = 256 * 1024 };   // one chain thread per 1024-element tile
 
+// Launch recorder: while one is set (thread-local), every launch of enqueue() is handed to it -- host function, geometry, dynamic LDS,
+// the explicit arguments packed as the kernel-argument segment lays them out -- instead of to HIP: the library's own AQL queue
+// records the sampled step that way (aql_queue.h).  Returns false when the launch could not be recorded.
+typedef bool (*LaunchRecorder)(void* user, const void* host_fn, dim3 grid, dim3 block, size_t lds, hipStream_t st, const void* args, size_t arg_bytes);
+void set_recorder(LaunchRecorder r, void* user);
+bool recorder_failed();      // since the last set_recorder
+
 hipError_t create(Sampler* s, int V);
 void destroy(Sampler* s);
 // Enqueue one sampled step after the classifier: reads `logits` (V floats, left untouched), picks the next token

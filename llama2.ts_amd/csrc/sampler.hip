@@ -28,12 +28,40 @@
 // L2_SAMPLER_SERIAL=1 keeps the straightforward form for A/B: ONE lane adds in index order (~10 cycles per element,
 // ~130 us per pass over 32 000 values) inside a single 1024-thread workgroup (top-p: behind the same tile sort + rank merge).
 #include "sampler.h"
+#include <string.h>
 #include "exact_sum.h"
 #include "margin_rule.h"
 
 #include <stdlib.h>
 
 namespace l2s {
+
+static thread_local LaunchRecorder g_rec = nullptr;
+static thread_local void* g_rec_user = nullptr;
+static thread_local bool g_rec_failed = false;
+void set_recorder(LaunchRecorder r, void* user) { g_rec = r; g_rec_user = user; g_rec_failed = false; }
+bool recorder_failed() { return g_rec_failed; }
+
+template <class T>
+static void pack_arg(char* buf, size_t& off, const T& v) {
+  off = (off + alignof(T) - 1) & ~(alignof(T) - 1);
+  memcpy(buf + off, &v, sizeof(T));
+  off += sizeof(T);
+}
+// every launch of the sampled step: HIP, or the recorder (sampler.h)
+template <class... KA, class... A>
+static void s_launch(void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t st, const A&... a) {
+  static_assert(sizeof...(KA) == sizeof...(A), "argument count");
+  if (g_rec) {
+    char buf[1024];
+    size_t off = 0;
+    static_assert((sizeof(KA) + ... + 0) + 8 * sizeof...(KA) <= sizeof(buf), "kernel arguments exceed the packing buffer");
+    (pack_arg<KA>(buf, off, static_cast<KA>(a)), ...);
+    if (!g_rec(g_rec_user, reinterpret_cast<const void*>(kernel), grid, block, lds, st, buf, off)) g_rec_failed = true;
+    return;
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, st, a...);
+}
 
 #pragma clang fp contract(off)
 
@@ -75,9 +103,9 @@ static ChainArgs chain_args(const Sampler& s, const float* x, const double* part
 }
 
 static hipError_t launch_chain(const ChainArgs& a, int mode, hipStream_t st) {
-  if (mode == CHAIN_SAMPLE) hipLaunchKernelGGL(chain_kernel<CHAIN_SAMPLE>, dim3(1), dim3(TN), 0, st, a);
-  else if (mode == CHAIN_TOPP) hipLaunchKernelGGL(chain_kernel<CHAIN_TOPP>, dim3(1), dim3(TN), 0, st, a);
-  else hipLaunchKernelGGL(chain_kernel<CHAIN_DEBUG>, dim3(1), dim3(TN), 0, st, a);
+  if (mode == CHAIN_SAMPLE) s_launch(chain_kernel<CHAIN_SAMPLE>, dim3(1), dim3(TN), 0, st, a);
+  else if (mode == CHAIN_TOPP) s_launch(chain_kernel<CHAIN_TOPP>, dim3(1), dim3(TN), 0, st, a);
+  else s_launch(chain_kernel<CHAIN_DEBUG>, dim3(1), dim3(TN), 0, st, a);
   return hipGetLastError();
 }
 
@@ -85,11 +113,11 @@ hipError_t running_sums(const float* x_dev, int n, double* prefix_dev, hipStream
   Sampler s;
   hipError_t e = create(&s, n);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tile_sums_kernel, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part);
-  hipLaunchKernelGGL(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
+  s_launch(tile_sums_kernel, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part);
+  s_launch(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
   e = launch_chain(chain_args(s, x_dev, s.part, false), CHAIN_DEBUG, st);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(prefix_kernel, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part, s.off, s.runS, s.runBad, s.runEnd, prefix_dev);
+    s_launch(prefix_kernel, dim3(s.G), dim3(TN), 0, st, x_dev, n, s.part, s.off, s.runS, s.runBad, s.runEnd, prefix_dev);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -163,15 +191,15 @@ void destroy(Sampler* s) {
 // rank merge writes probs_sorted / idx_sorted and adds every value to the sum of the 1024-element tile it lands in (part_sorted).
 static hipError_t rank_merge(const Sampler& s, int gs, hipStream_t st) {
   const int n = gs * STILE;
-  hipLaunchKernelGGL(sort_rank_kernel, dim3((n + RT - 1) / RT, (gs + RANK_TQ - 1) / RANK_TQ), dim3(RT), 0, st, s.run_p, s.idx, gs, s.G, s.rank_acc,
+  s_launch(sort_rank_kernel, dim3((n + RT - 1) / RT, (gs + RANK_TQ - 1) / RANK_TQ), dim3(RT), 0, st, s.run_p, s.idx, gs, s.G, s.rank_acc,
                      s.probs_sorted, s.idx_sorted, s.part_sorted);
   return hipGetLastError();
 }
 
 static hipError_t sort_descending(const Sampler& s, const float* values, const ChainArgs& exps, bool fused, hipStream_t st) {
   const int gs = (s.V + STILE - 1) / STILE;
-  if (fused) hipLaunchKernelGGL(sort_tile_kernel<true>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
-  else hipLaunchKernelGGL(sort_tile_kernel<false>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
+  if (fused) s_launch(sort_tile_kernel<true>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
+  else s_launch(sort_tile_kernel<false>, dim3(gs), dim3(TN), 0, st, exps, values, s.V, s.run_p, s.idx);
   return rank_merge(s, gs, st);
 }
 
@@ -179,46 +207,46 @@ hipError_t enqueue(const Sampler& s, const float* logits, bool topp_mode, int* t
   hipError_t e;
   if (s.serial) {
     if (!topp_mode) {
-      hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.rng, tokpos, tokens_out);
+      s_launch(sample_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, s.rng, tokpos, tokens_out);
       return hipGetLastError();
     }
-    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, (int*)nullptr);
+    s_launch(softmax_kernel, dim3(1), dim3(NT), 0, st, logits, s.V, s.params, s.probs, (int*)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = sort_descending(s, s.probs, ChainArgs(), false, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(topp_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.rng, tokpos, tokens_out);
+    s_launch(topp_kernel, dim3(1), dim3(NT), 0, st, s.probs_sorted, s.idx_sorted, s.V, s.params, s.rng, tokpos, tokens_out);
     return hipGetLastError();
   }
   // temperature + exp (:481-483, :183-188), runs of the exps' running sum
-  if (!amax) hipLaunchKernelGGL(scaled_max_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey);
-  hipLaunchKernelGGL(exp_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey, amax, s.probs, s.part);
+  if (!amax) s_launch(scaled_max_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey);
+  s_launch(exp_kernel, dim3(s.G), dim3(TN), 0, st, logits, s.V, s.params, s.mxkey, amax, s.probs, s.part);
   if (!s.chain) {
     MarginArgs m = {};
     m.exps = s.probs; m.part = s.part; m.V = s.V; m.G = s.G; m.part2 = s.part2; m.amb = s.amb; m.ticket = s.ticket;
     m.sorted = s.probs_sorted; m.ids = s.idx_sorted; m.part_sorted = s.part_sorted; m.params = s.params; m.rng = s.rng;
     m.tokpos = tokpos; m.tokens_out = tokens_out; m.mxkey = s.mxkey; m.amax = amax; m.stats = s.stats; m.force_serial = s.force_serial ? 1 : 0;
     if (!topp_mode) {
-      hipLaunchKernelGGL(sample_margin_kernel, dim3(s.G), dim3(TN), 0, st, m);
+      s_launch(sample_margin_kernel, dim3(s.G), dim3(TN), 0, st, m);
       return hipGetLastError();
     }
     // the descending order needs the exact probabilities: runs of the exps, [exact total -> probabilities -> sorted tiles], rank merge
-    hipLaunchKernelGGL(runs_total_kernel, dim3(s.G), dim3(TN), 0, st, chain_args(s, s.probs, s.part, false), (Run*)s.recs, s.cnt, s.ticket, s.total);
+    s_launch(runs_total_kernel, dim3(s.G), dim3(TN), 0, st, chain_args(s, s.probs, s.part, false), (Run*)s.recs, s.cnt, s.ticket, s.total);
     const int gs = (s.V + STILE - 1) / STILE;
-    hipLaunchKernelGGL(sort_tile_wide_kernel, dim3(gs), dim3(WT), 0, st, s.probs, s.total, s.V, s.run_p, s.idx);
+    s_launch(sort_tile_wide_kernel, dim3(gs), dim3(WT), 0, st, s.probs, s.total, s.V, s.run_p, s.idx);
     if ((e = rank_merge(s, gs, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(topp_margin_kernel, dim3(1), dim3(TN), 0, st, m);
+    s_launch(topp_margin_kernel, dim3(1), dim3(TN), 0, st, m);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
+  s_launch(runs_kernel<false>, dim3(s.G), dim3(TN), 0, st, s.probs, s.V, s.part, (Run*)s.recs, s.cnt, s.cq, s.cm);
   const ChainArgs exps = chain_args(s, s.probs, s.part, false);
   ChainArgs pick;
   if (!topp_mode) {
     // exact total -> probabilities -> their runs, in one launch; then sample (:368-376)
-    hipLaunchKernelGGL(normalise_runs_kernel, dim3(s.G), dim3(TN), 0, st, exps, s.probs_n, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
+    s_launch(normalise_runs_kernel, dim3(s.G), dim3(TN), 0, st, exps, s.probs_n, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
     pick = chain_args(s, s.probs_n, s.part, true);
   } else {
     // sample_topp (:378-394): exact total -> probabilities -> sorted tiles in one launch, rank merge, runs of the sorted order
     if ((e = sort_descending(s, s.probs, exps, true, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(runs_kernel<true>, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part_sorted, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
+    s_launch(runs_kernel<true>, dim3(s.G), dim3(TN), 0, st, s.probs_sorted, s.V, s.part_sorted, (Run*)s.recs2, s.cnt2, s.cq, s.cm);
     pick = chain_args(s, s.probs_sorted, s.part_sorted, true);
     pick.part_sorted = s.part_sorted;
   }
