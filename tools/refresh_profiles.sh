@@ -45,4 +45,16 @@ for loop in ("host", "device"):
     r = subprocess.run(["node", "llama2.ts_amd/host/l2_run.mjs", "/tmp/s15.bin", "--steps", "256", "--loop", loop, "--metrics"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     print(loop, r.stderr.decode().strip())
 PY
+set +x
+# the library's own AQL queue (csrc/aql_queue.h): what a dependent kernel node costs by the fence scopes of its packet header, the decode
+# through the queue against replayed hipGraphs on this box, the launches of one token on the chip's shared clock under both
+timeout 120 tools/aql/microbench_aql > $out/microbench_aql_fence_scopes.txt 2>&1
+( source tools/ab_env.sh
+  for CFG in stories110M stories15M llama2_7b; do for V in "L2_AQL=0" "L2_AQL=1" "L2_AQL=1 L2_AQL_FENCE=1" "L2_AQL=0" "L2_AQL=1"; do echo -n "$CFG "; run $V; done; done ) > $out/aql_vs_graph_ab.txt 2>&1
+( export L2_TEST_HOOKS=1
+  for G in 8 4 2; do for A in 0 1; do echo -n "L2_AQL=$A "; L2_AQL=$A python3 tools/tp_solo_step.py $G llama2_7b 64; done; done ) > $out/tp_shard_step_aql_ab.txt 2>&1
+make -C llama2.ts_amd/csrc stamps > /dev/null 2>&1
+( export L2_TEST_HOOKS=1
+  echo "== replayed hipGraph (L2_AQL=0)"; L2_AQL=0 python tools/timeline_graph.py stories110M 100 | head -24
+  echo "== the library's own queue"; python tools/timeline_graph.py stories110M 100 | head -24 ) > $out/timeline_stories110M_graph_vs_aql.txt 2>&1
 cat $out/pytest_gpu.txt
