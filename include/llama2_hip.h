@@ -22,8 +22,9 @@ extern "C" {
 #endif
 
 /* 3 (round 5): l2_bench_tokens, option keys 5-7, L2_TP_SOLO_ID / l2_tp_mode 5 and the L2_TP_FENCED switch joined the surface after 2 -- a
- * binding built against 3 refuses an older library at open() (l2_abi_version), not at the first call that is missing */
-#define L2_ABI_VERSION 3
+ * binding built against it refuses an older library at open() (l2_abi_version), not at the first call that is missing.
+ * 4 (round 5): option key L2_OPT_AQL_QUEUE */
+#define L2_ABI_VERSION 4
 
 enum {
   L2_OK = 0,

@@ -170,7 +170,7 @@ AqlQueue* aql_create(int pci_domain, int pci_bus, int pci_device, int pci_functi
   if (s != HSA_STATUS_SUCCESS) return bail("hsa_queue_create", s);
   s = hsa_signal_create(1, 0, nullptr, &q->done);
   if (s != HSA_STATUS_SUCCESS) return bail("hsa_signal_create", s);
-  q->karg_cap = 4u << 20;
+  q->karg_cap = 8u << 20;      // (a 7B-shaped tensor-parallel step is ~230 launches x 512 bytes per level and loop)
   s = hsa_amd_memory_pool_allocate(q->dev_pool, q->karg_cap, 0, (void**)&q->karg_dev);
   if (s != HSA_STATUS_SUCCESS) return bail("hsa_amd_memory_pool_allocate (kernel arguments)", s);
   q->karg_host.reserve(q->karg_cap);
