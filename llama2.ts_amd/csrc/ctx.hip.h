@@ -209,6 +209,7 @@ struct l2_ctx {
   AqlQueue* aql = nullptr;
   AqlProgram* aql_greedy[NLEV] = {};
   AqlProgram* aql_sample[NLEV][4] = {};   // the sampled loop (same indices as g_sample)
+  AqlProgram* aql_last = nullptr;   // the greedy run's last pick (one launch, once per run)
   AqlProgram* aql_step[NLEV] = {};  // the blocking call: {token, pos} from pinned host memory, the step, logits straight into the host's buffer
   int* h_tokpos_dev = nullptr;      // device alias of h_tokpos
   AqlProgram* aql_rec = nullptr;    // non-null while enqueue_* records instead of launching

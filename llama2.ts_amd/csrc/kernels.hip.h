@@ -116,6 +116,10 @@ struct PhaseArgs {
   // from the attention workgroups of the SAME launch -- `gran` are those granules, tag = *gran_ep + 1 (the launch after this one advances
   // the counter), and a wait that gives up says so here
   int* gin_herr;
+  // greedy loop with the pick folded into the step (no launch of its own): non-null in the three launches that share the work -- layer 0's
+  // q / k / v launch takes the token from the classifier's argmax keys (`amax`) and records it here, layer 0's wo launch reads it back from
+  // here and re-arms the keys, the classifier launch advances {pos, step} (greedy_* below)
+  int* tok_out;
 #ifdef L2_STAMPS
   unsigned long long* dbg;  // diagnostic stamps (L2_STAMPS builds only: the argument block of the product build stays within four 64-byte
   unsigned long long* dbg_wg;  // lines -- a fifth cost every launch of the small models ~0.1 us, 2 % of a stories110M token)
@@ -412,6 +416,22 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// The greedy pick folded into the step (llama2.ts:477-479, 364-366, 496: next = argmax(logits); token = next; pos++).  The classifier's
+// workgroups fold their best (logit, index) into eight keys (below); instead of a one-wave launch that finishes the pick, the NEXT token's
+// first launch does: every workgroup of layer 0's q / k / v launch takes the maximum of the eight keys itself (eight loads past L1, one DPP
+// reduction -- requested beside the scalar load of {pos, step}, so the embedding row is asked for no later than before) and workgroup 0
+// records the token; layer 0's wo launch, which needs the token again for its residual (the embedding row), reads the record and re-arms
+// the keys (every reader of them is a launch back by then); the classifier launch, none of whose workgroups reads {pos, step} and behind
+// which nothing of this token runs, advances them.  step == 0: the run's first token comes from the host ({token, pos} as uploaded).  One
+// launch per token fewer; the run's last pick is finished by a launch of its own (argmax_last_kernel).
+__device__ __forceinline__ int greedy_token_from_keys(const PhaseArgs& a, int lane, int step) {
+  unsigned long long k = lane < 8 ? __hip_atomic_load(a.amax + (size_t)lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  k = wave_max_u64(k);
+  const int from_keys = (k == 0) ? 0 : (int)~(unsigned)k;       // nothing but NaN: reduce() keeps index 0
+  return step > 0 ? from_keys : a.tokpos[0];
+}
+
 // Epilogue operands that do not depend on the GEMV (RoPE table entries of the row pair, residual value of the row):
 // lane p's operands for pair / row p of row group g.  The latency kernel requests them with the weights; the
 // streaming kernel loads them in the epilogue (there the extra live registers cost more than the L2 round trip).
@@ -634,6 +654,12 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   // nothing) is already in flight.
   int token = 0, pos = 0;
   if (MODE == MODE_QKV || MODE == MODE_WO) { token = a.tokpos[0]; pos = a.tokpos[1]; }
+  // (the greedy pick folded into the step, greedy_token_from_keys: looked at in layer 0 only -- `emb` is the test every launch makes anyway)
+  if ((MODE == MODE_QKV || MODE == MODE_WO) && a.emb && a.tok_out) {
+    const int step = a.tokpos[2];
+    if (MODE == MODE_QKV) { token = greedy_token_from_keys(a, lane, step); if (vblock == 0 && tid == 0 && step > 0) a.tok_out[step - 1] = token; }
+    if (MODE == MODE_WO) { if (step > 0) token = a.tok_out[step - 1]; if (vblock == 0 && tid < 8) a.amax[(size_t)tid * 16] = 0ull; }
+  }
   const float* src = a.in;
   if (MODE == MODE_QKV) { if (a.emb) src = a.emb + (size_t)token * n; }
   const auto srs = L2_ACT_RSRC(src, n);      // (the input vector: past L1 -- the coherence rule above)
@@ -753,6 +779,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
     if (tid == 0) {
       for (int w = 1; w < nwaves; ++w) best = sk[w] > best ? sk[w] : best;
       __hip_atomic_fetch_max(a.amax + (size_t)(vblock & 7) * 16, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the greedy pick folded into the step: {pos, step} advance here -- no workgroup of this launch reads them, nothing of this token
+      // runs behind it, and the next token's first launch takes the token from the keys itself (greedy_token_from_keys)
+      if (vblock == 0 && a.tok_out) { int* tp = const_cast<int*>(a.tokpos); const int p1 = tp[1], step = tp[2]; tp[1] = p1 + 1; tp[2] = step + 1; }
     }
   }
 }
@@ -860,7 +889,14 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   f4 xr[XV], wr[XV];
   if (wave == 0) {
     const float* src = a.in;
-    if (MODE == MODE_QKV) { if (a.emb) src = a.emb + (size_t)a.tokpos[0] * n; }   // only layer 0 waits for the token
+    if (MODE == MODE_QKV) {      // only layer 0 waits for the token
+      if (a.emb) {
+        int tk;
+        if (a.tok_out) { const int step = a.tokpos[2]; tk = greedy_token_from_keys(a, lane, step); if (vblock == 0 && lane == 0 && step > 0) a.tok_out[step - 1] = tk; }
+        else tk = a.tokpos[0];
+        src = a.emb + (size_t)tk * n;
+      }
+    }
     if (GIN) {
       const unsigned gtag_in = __hip_atomic_load(a.gran_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
       granules_gather_f4<XV>(a.gran, n, lane, gtag_in, xr, a.gin_herr, 200000000ull, 1, const_cast<unsigned*>(a.gran_ep) + 1);      // bounded at 2 s; a short nap between sweeps (the wait is a whole attention long)
@@ -918,6 +954,11 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   STAMP(3);
   if (wave == 0 || gA0 >= groups) return;
   if (MODE == MODE_QKV || MODE == MODE_WO) { token = a.tokpos[0]; pos = a.tokpos[1]; }
+  if (MODE == MODE_WO && a.emb && a.tok_out) {      // the greedy pick folded into the step (greedy_token_from_keys): layer 0 only
+    const int step = a.tokpos[2];
+    if (step > 0) token = a.tok_out[step - 1];
+    if (vblock == 0 && wave == 1 && lane < 8) a.amax[(size_t)lane * 16] = 0ull;
+  }
   // (the tensor-parallel push pointer is looked at HERE, behind the weight requests: hipcc fetches a kernel argument where it is first
   // used, and a test of it in front of them put one more cold scalar-cache round -- 0.4 us -- before the first weight request of EVERY
   // wo launch, tensor parallel or not: stories110M 4 010 -> 3 930 tok/s until it was found by a same-box run of the round-4 library)
@@ -1073,6 +1114,21 @@ __global__ void __launch_bounds__(64) argmax_finish_kernel(unsigned long long* a
 __global__ void __launch_bounds__(64) set_tokpos_kernel(const int* host_tokpos, int* tokpos) {
   const int lane = threadIdx.x;
   if (lane < 4) tokpos[lane] = __hip_atomic_load(host_tokpos + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ... and with the pick folded into the step (greedy_token_from_keys): the run's LAST pick, once per run -- {pos, step} were advanced by
+// the last layer's w2 launch already
+__global__ void __launch_bounds__(64) argmax_last_kernel(unsigned long long* amax, int* tokpos, int* tokens_out) {
+  const int lane = threadIdx.x;
+  const int step = tokpos[2];
+  unsigned long long k = lane < 8 ? __hip_atomic_load(amax + (size_t)lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  if (lane < 8) amax[(size_t)lane * 16] = 0ull;
+  k = wave_max_u64(k);
+  if (lane == 0 && step > 0) {
+    const int bi = (k == 0) ? 0 : (int)~(unsigned)k;
+    tokens_out[step - 1] = bi;
+    tokpos[0] = bi;
+  }
 }
 
 __global__ void __launch_bounds__(1024) argmax_advance_kernel(const float* logits, int V, int* tokpos, int* tokens_out) {

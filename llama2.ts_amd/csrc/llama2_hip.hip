@@ -54,6 +54,7 @@ static void destroy_graphs(l2_ctx* c) {
   for (int i = 0; i < NLEV; ++i) {      // (their kernel arguments hold pointers and shapes of the step as it was)
     if (c->aql_greedy[i]) { aql_program_free(c->aql_greedy[i]); c->aql_greedy[i] = nullptr; }
     if (c->aql_step[i]) { aql_program_free(c->aql_step[i]); c->aql_step[i] = nullptr; }
+    if (i == 0 && c->aql_last) { aql_program_free(c->aql_last); c->aql_last = nullptr; }
     for (int m = 0; m < 4; ++m) if (c->aql_sample[i][m]) { aql_program_free(c->aql_sample[i][m]); c->aql_sample[i][m] = nullptr; }
   }
   if (c->aql) aql_reset(c->aql);
@@ -641,9 +642,14 @@ static int ensure_rowmajor(l2_ctx* c, bool unpack) {
   return L2_OK;
 }
 
-static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fold_argmax = false) {
+// fold: 0 logits only; 1 the classifier also folds its best logit into the argmax keys (the sampled loop's maximum); 2 the greedy pick
+// folded into the step (kernels.hip.h: greedy_token_from_keys) -- layer 0's q / k / v and wo launches and the classifier launch share it
+static bool greedy_folds(const l2_ctx* c) { return !c->tp_path && c->amax && c->d % 4 == 0 && c->h % 4 == 0; }      // (the scalar kernels of n % 4 != 0 shapes keep the pick's own launch)
+static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, int fold = 0) {
+  auto greedy = [&](PhaseArgs& a) { if (fold == 2) { a.amax = c->amax; a.tok_out = c->d_tokens; } };
   for (int l = 0; l < c->L; ++l) {
     PhaseArgs a = qkv_args(c, l);
+    if (l == 0) greedy(a);
     if (fused_qkv_attn_ok(c)) {
       LCHK(launch_qkv_attn(c, a, l, st));        // the head-local edge inside one launch (attention.hip.h: qkv_attn_small_kernel)
     } else {
@@ -653,11 +659,13 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
       } else {
         LCHK(launch_attn(c, l, st));
         a = wo_args(c, l);
+        if (l == 0) greedy(a);
         LCHK(launch_phase<MODE_WO>(c, a, st));
       }
     }
     if (fused_qkv_attn_ok(c)) {
       a = wo_args(c, l);
+      if (l == 0) greedy(a);
       LCHK(launch_phase<MODE_WO>(c, a, st));
     }
     if (c->p2p) {
@@ -682,7 +690,8 @@ static int enqueue_forward_impl(l2_ctx* c, hipStream_t st, bool to_host, bool fo
     }
   }
   PhaseArgs a = cls_args(c, to_host);
-  if (fold_argmax) a.amax = c->amax;
+  if (fold) a.amax = c->amax;
+  if (fold == 2) a.tok_out = c->d_tokens;
   LCHK(launch_phase<MODE_CLS>(c, a, st));
   if (c->p2p) {
     const dim3 grid(p2p_grid(c->V_loc));
@@ -730,17 +739,26 @@ static int ensure_ready(l2_ctx* c) {
 static int enqueue_greedy(l2_ctx* c, hipStream_t st) {  // device-resident step: forward, argmax, advance
   // the classifier's workgroups fold their logits into 8 argmax keys, one wave finishes; a tensor-parallel rank has
   // only its slice of the logits before the all-gather and takes the maximum over the gathered vector instead
+  // ... or, on one GPU with vector-form phases, the pick folded into the next token's first launch (no launch of its own; the run's last
+  // pick: enqueue_greedy_last)
   const bool fold = !c->tp_path;
-  int rc = enqueue_forward_impl(c, st, false, fold);
+  int rc = enqueue_forward_impl(c, st, false, greedy_folds(c) ? 2 : (fold ? 1 : 0));
   if (rc) return rc;
+  if (greedy_folds(c)) return L2_OK;
   if (fold) l2_launch(c, argmax_finish_kernel, dim3(1), dim3(64), 0, st, c->amax, c->tokpos, c->d_tokens);
   else l2_launch(c, argmax_advance_kernel, dim3(1), dim3(1024), 0, st, (const float*)c->logits, c->V, c->tokpos, c->d_tokens);
   LCHK(hipGetLastError());
   return L2_OK;
 }
+static int enqueue_greedy_last(l2_ctx* c, hipStream_t st) {      // once per run: the last token's pick (kernels.hip.h: argmax_last_kernel)
+  if (!greedy_folds(c)) return L2_OK;
+  l2_launch(c, argmax_last_kernel, dim3(1), dim3(64), 0, st, c->amax, c->tokpos, c->d_tokens);
+  LCHK(hipGetLastError());
+  return L2_OK;
+}
 
 static int enqueue_sample(l2_ctx* c, hipStream_t st) {  // device-resident sampled step: forward, temperature/softmax/sample(_topp), advance
-  int rc = enqueue_forward_impl(c, st, false, c->samp_amax);
+  int rc = enqueue_forward_impl(c, st, false, c->samp_amax ? 1 : 0);
   if (rc) return rc;
   if (c->aql_rec) {
     // the sampler's launches (their own translation unit) are handed over by its recorder; its kernels read logits, keys and
@@ -831,6 +849,7 @@ static int aql_open(l2_ctx* c) {
 }
 
 static int enqueue_greedy(l2_ctx* c, hipStream_t st);
+static int enqueue_greedy_last(l2_ctx* c, hipStream_t st);
 
 // Record the step of level `lvl` (once per level: destroy_graphs drops the recordings with the graphs) -- the same enqueue a hipGraph
 // captures, every launch turned into a packet by l2_launch.  L2_RUN_EAGER: the queue is given up (the note says why).
@@ -855,11 +874,13 @@ static int run_greedy_aql(l2_ctx* c, int pos0, int steps, bool timed, float* ms)
     const int lvl = split_level(c, pos0 + s);
     if (aql_record_level(c, lvl, enqueue_greedy, &c->aql_greedy[lvl])) return L2_RUN_EAGER;
   }
+  if (steps > 0 && greedy_folds(c) && aql_record_level(c, 0, enqueue_greedy_last, &c->aql_last)) return L2_RUN_EAGER;
   HIPCHK(hipStreamSynchronize(c->stream));      // {token, pos}, the argmax keys: the HIP stream's work is done before the queue starts
   std::vector<AqlProgram*> per(steps);
   for (int s = 0; s < steps; ++s) per[s] = c->aql_greedy[split_level(c, pos0 + s)];
+  if (steps > 0 && c->aql_last) per.push_back(c->aql_last);      // the run's last pick
   double us = 0.0;
-  if (aql_run(c->aql, steps, per.data(), c->aql_fence, &us)) return fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
+  if (aql_run(c->aql, (int)per.size(), per.data(), c->aql_fence, &us)) return fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
   if (timed && ms) *ms = (float)(us * 1e-3);
   c->ran_forward = true;
   return check_p2p(c);
@@ -943,6 +964,7 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
     // L2_PROFILE_SYNC=1 drains the stream after every token (kernel durations are unaffected)
     if (c->profile_sync) HIPCHK(hipStreamSynchronize(c->stream));
   }
+  if (steps > 0) { rc = enqueue_greedy_last(c, c->stream); if (rc) return rc; }
   if (timed) {
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
