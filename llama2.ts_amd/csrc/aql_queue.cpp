@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <string>
@@ -38,7 +39,8 @@ struct AqlQueue {
   std::vector<char> karg_host;                        //   from host memory every CU's scalar cache fetches them over PCIe -- 26 us a launch)
   size_t karg_cap = 0, karg_uploaded = 0;
   uint64_t widx = 0;                                  // next packet id (this queue has one producer)
-  bool inited = false, queue_error = false;
+  bool inited = false;
+  std::atomic<bool> queue_error{false};               // set by the runtime's error callback (its own thread)
   char err[512] = "";
 };
 
@@ -276,14 +278,21 @@ int aql_run(AqlQueue* q, int ntok, AqlProgram* const* per_token, int fence, doub
   size_t n = 0;
   std::chrono::steady_clock::time_point t0;
   bool started = false;
-  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300);
+  // a run that makes no progress for 300 s is given up (the read index is what moves)
+  auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300);
+  uint64_t seen = hsa_queue_load_read_index_relaxed(q->q);
+  auto progressed = [&]() {
+    const uint64_t r = hsa_queue_load_read_index_relaxed(q->q);
+    if (r != seen) { seen = r; deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300); }
+  };
   for (int t = 0; t < ntok; ++t) {
     const AqlProgram* p = per_token[t];
     if (!p || p->pk.empty()) continue;
     // room for the token's packets (the queue holds a few tens of tokens: the host runs ahead of the chip and then keeps pace)
     while (q->widx + p->pk.size() - hsa_queue_load_read_index_scacquire(q->q) > size) {
       if (q->queue_error) return -1;
-      if (std::chrono::steady_clock::now() > deadline) return qfail(q, "the queue did not drain within 300 s");
+      progressed();
+      if (std::chrono::steady_clock::now() > deadline) return qfail(q, "the queue made no progress for 300 s");
     }
     for (size_t i = 0; i < p->pk.size(); ++i, ++n) {
       hsa_kernel_dispatch_packet_t* dst = ring + ((q->widx + i) & (size - 1));
@@ -315,7 +324,8 @@ int aql_run(AqlQueue* q, int ntok, AqlProgram* const* per_token, int fence, doub
   hsa_signal_value_t v = hsa_signal_wait_scacquire(q->done, HSA_SIGNAL_CONDITION_LT, 1, 2000000ull, HSA_WAIT_STATE_ACTIVE);
   while (v >= 1) {
     if (q->queue_error) return -1;
-    if (std::chrono::steady_clock::now() > deadline) return qfail(q, "the run did not complete within 300 s");
+    progressed();
+    if (std::chrono::steady_clock::now() > deadline) return qfail(q, "the run made no progress for 300 s");
     v = hsa_signal_wait_scacquire(q->done, HSA_SIGNAL_CONDITION_LT, 1, 100000000ull, elapsed_us ? HSA_WAIT_STATE_ACTIVE : HSA_WAIT_STATE_BLOCKED);
   }
   if (elapsed_us) *elapsed_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
