@@ -33,9 +33,13 @@ def test_greedy_loop_on_the_queue_equals_graph_replay_and_the_reference(name, st
     assert again == a
     mid = steps // 3
     assert ctx.decode_greedy(a[mid - 1], mid, steps - mid).tolist() == a[mid:]
+    # the pick is folded into the next token's first launch, the run's last one has a launch of its own: runs of one and two tokens
+    assert ctx.decode_greedy(1, 0, 1).tolist() == a[:1] and ctx.decode_greedy(1, 0, 2).tolist() == a[:2]
+    assert ctx.decode_greedy(a[4], 5, 1).tolist() == a[5:6]
     ctx.set_option(runtime.OPT_AQL_QUEUE, 0)
     assert ctx.get_option(runtime.OPT_AQL_QUEUE) == 0
     assert ctx.decode_greedy(1, 0, steps).tolist() == a
+    assert ctx.decode_greedy(1, 0, 1).tolist() == a[:1] and ctx.decode_greedy(1, 0, 2).tolist() == a[:2]      # (the folded pick under graph replay)
     ctx.close()
 
 
