@@ -829,7 +829,7 @@ def main():
         "data": "synthetic (seeded hash generator, llama2.c-v0 layout)",
         "config": {"workload": "%s batch-1 greedy decode, %d tokens from BOS (-t 0 -s 1 -n %d)" % (args.config, K, K),
                    "header": list(hdr), "parallelism": ("tp%d" % world) if shards else ("replicas%d" % world if world > 1 else "single"),
-                   "loop": ("device-resident (forward + argmax on GPU); tensor-parallel step: %s" % ctx.tp_mode()
+                   "loop": ("device-resident (forward + argmax on GPU); tensor-parallel step: %s; dispatch: %s" % (ctx.tp_mode(), dispatch_note(ctx))
                             if shards else "device-resident (forward + argmax on GPU, %s)" % dispatch_note(ctx)),
                    "weights": "fp32, ONE copy on the device (%d MiB): the matrices of the streaming phases repacked in the order the chip consumes them "
                               "(%d MiB, DESIGN.md section 3), everything else row-major as the checkpoint stores it"
