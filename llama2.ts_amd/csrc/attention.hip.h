@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(64 * NW) pf_attn_tile_kernel(const AttnArgs a,
   attn_tile_dispatch<LR, NW, NT>(b, smem, blockIdx.x, 0, pos0 + p);
 }
 
+#ifndef L2_NO_PLAIN_KERNELS
 // Shapes whose head_size or dim is not a multiple of 4 (rows are not 16-byte aligned): one workgroup per head,
 // one thread per timestep, scalar loads.  Correctness only; keeps every rounding of the reference.
 __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int pos0) {
@@ -539,5 +540,7 @@ __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int 
     }
   }
 }
+
+#endif  // L2_NO_PLAIN_KERNELS
 
 }  // namespace l2k

@@ -1089,6 +1089,8 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
   }
 }
 
+// (plain, non-template kernels: defined in ONE translation unit -- attention_inst.hip includes this header for the templates only)
+#ifndef L2_NO_PLAIN_KERNELS
 // ------------------------------------------------------------------------------------------------
 // argmax (llama2.ts:364-366: first maximum, strict '>') + advance {token,pos,step}: keeps the greedy
 // loop (llama2.ts:465-508 at -t 0) on the device.  A logit and its index travel as ONE 64-bit key
@@ -1198,5 +1200,7 @@ __global__ void synth_fill_kernel(float* out, SynthSlice s, uint32_t seed, float
     out[i] = v;
   }
 }
+
+#endif  // L2_NO_PLAIN_KERNELS
 
 }  // namespace l2k

@@ -29,7 +29,7 @@
 #include <vector>
 
 #include "kernels.hip.h"
-#include "attention.hip.h"
+#include "attention_inst.hip.h"      // attention.hip.h + its instances as extern templates (compiled in attention_inst.hip)
 #include "prefill.hip.h"
 #include "sampler.h"
 #include "aql_queue.h"

@@ -154,8 +154,8 @@ def test_no_shipped_kernel_spills_registers(tmp_path):
 
 def test_aql_queue_finds_its_kernels_in_the_library_file(built):
     """The library's own AQL queue (csrc/aql_queue.h) loads the kernels through HSA from the gfx950 code objects inside
-    libllama2hip.so itself: the offload-bundle walk that finds them is plain file parsing and must see both translation units'
-    objects (decode kernels, sampler kernels) in the library as built here."""
+    libllama2hip.so itself: the offload-bundle walk that finds them is plain file parsing and must see all three translation units'
+    objects (decode kernels, the attention family, sampler kernels) in the library as built here."""
     import ctypes as C
     L = C.CDLL(runtime.LIB_PATH)
-    assert L.l2_debug_aql_code_objects() == 2
+    assert L.l2_debug_aql_code_objects() == 3
