@@ -107,3 +107,24 @@ def test_queue_follows_option_changes_and_uploads():
     other.upload(runtime.T_WO, 2, np.zeros(n, dtype=np.float32))
     assert other.decode_greedy(1, 0, 40).tolist() == b
     ctx.close(); other.close()
+
+
+@pytest.mark.parametrize("name", ["stories15M", "stories110M"])
+def test_sampled_loop_on_the_queue_equals_graph_replay(name):
+    """l2_decode_sample through the queue (the sampler's launches handed over by its recorder hook, each acquiring at agent scope:
+    its kernels are not under the coherence rule) against the same runs through replayed hipGraphs: tokens and RNG state, plain
+    sample and top-p, across a level change, twice over the same context."""
+    hdr = configs.header(name)
+    q, g = runtime.Context(hdr), runtime.Context(hdr)
+    for c in (q, g):
+        c.synth_fill(configs.DEFAULT_SEED)
+    g.set_option(runtime.OPT_AQL_QUEUE, 0)
+    n = min(hdr[6], 300)
+    for rep in range(2):
+        for (t, p, seed) in ((0.9, 1.0, 42), (1.0, 0.9, 7), (0.7, 0.5, 1234567 + rep)):
+            a, sa = q.decode_sample(1, 0, n, t, p, seed)
+            b, sb = g.decode_sample(1, 0, n, t, p, seed)
+            assert a.tolist() == b.tolist() and sa == sb, (name, t, p, rep)
+    assert q.get_option(runtime.OPT_AQL_QUEUE) == 1 and g.get_option(runtime.OPT_AQL_QUEUE) == 0
+    assert q.decode_greedy(1, 0, 50).tolist() == g.decode_greedy(1, 0, 50).tolist()      # (the greedy program beside the sampled ones)
+    q.close(); g.close()
