@@ -68,7 +68,8 @@ enum {
                                  llama2.ts:260-265 does (the reference's own rounding points in that loop; slower; > 99.9 % of logits
                                  come out bit-identical, the rest within 1 ulp: the tree-ordered fp64 sums elsewhere remain); 0 (default):
                                  fp64 partial sums, one rounding */
-  L2_OPT_USE_GRAPH = 2,       /* 1 (default): replay a captured hipGraph per token; 0: eager launches */
+  L2_OPT_USE_GRAPH = 2,       /* 1 (default): the step of a context length level is recorded once and replayed per token (as packets on the
+                                 library's own queue, L2_OPT_AQL_QUEUE, or as a captured hipGraph); 0: eager launches */
   L2_OPT_KEEP_STATE = 3,      /* 1: the RunState fields that only transformer() itself reads (llama2.ts:131-146: att, k, v, hb2, xb2,
                                  the xb of the FFN half, the final-normed x) are also written out for l2_read_state (parity
                                  tests); 0 (default): they stay on chip and reading them AFTER a forward returns L2_E_STATE -- q, hb, logits and
@@ -209,7 +210,8 @@ int l2_bench_gemv(l2_ctx* ctx, int tensor_kind, int layer, int iters, float* avg
  * to every dispatch of the rmsnorm + w1/w3 + SwiGLU kernel on the library's stream (hipExtLaunchKernelGGL: the events
  * bracket the kernel's execution, as a kernel trace does); mean duration in microseconds. */
 int l2_bench_dominant_in_situ(l2_ctx* ctx, int first_token, int pos0, int steps, float* avg_us, int* launches);
-/* `steps` forwards (greedy feed, device-resident) timed with events: total device ms. */
+/* `steps` forwards (greedy feed, device-resident), timed: total ms from the first submission to completion (the library's own queue: host
+ * clock, first doorbell -> completion signal, spinning; hipGraph replays: events on the library's stream). */
 int l2_bench_decode(l2_ctx* ctx, int first_token, int pos0, int steps, float* total_ms);
 /* The first `n` tokens the last device-resident run (l2_bench_decode, l2_decode_greedy, l2_decode_sample) chose: lets a benchmark
  * check the very run it timed against the reference's tokens (llama2.ts:476-478 picks them on the host). */
