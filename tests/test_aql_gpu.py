@@ -10,7 +10,11 @@ import pytest
 
 from llama2_ts_amd import configs, runtime
 
-pytestmark = pytest.mark.gpu
+# under a profiler's tool library the library stands down to replayed hipGraphs (the tool wraps every HSA queue and rocprofv3 crashes on
+# hand-written packets): nothing to test here then
+_TOOLS = [k for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIBRARY", "ROCPROFILER_REGISTER_FORCE_LOAD") if os.environ.get(k)]
+_TOOLS += [v for v in (os.environ.get("LD_PRELOAD", ""),) if "rocprof" in v or "roctracer" in v]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(bool(_TOOLS), reason="a profiler's tool library is loaded (%s): the AQL queue is not taken" % _TOOLS)]
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
