@@ -25,7 +25,7 @@ def test_bench_json_contract():
     assert "workload" in j["config"] and "model" not in j["config"]
     # the dispatch the timed run used (csrc/aql_queue.h): the library's own queue -- or replayed hipGraphs WITH the reason (e.g. under a profiler's tool library)
     loop = j["config"]["loop"]
-    assert "AQL packets on the library's own HSA queue" in loop or ("one hipGraph replay per token (" in loop and "AQL" in loop), loop
+    assert "AQL packets on the library's own HSA queue" in loop or ("one hipGraph replay per token (" in loop and "AQL" in loop) or "eager launches (" in loop, loop
     wm = j["config"]["weights_mib"]
     assert wm["repacked"] == 0 and abs(wm["on_device"] - wm["checkpoint"]) <= 2          # stories15M: latency-form phases, a one-batch classifier
     rf = j["roofline"]
