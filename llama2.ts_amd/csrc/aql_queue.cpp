@@ -5,6 +5,7 @@
 #include <hsa/hsa_ext_amd.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -40,7 +41,10 @@ struct AqlQueue {
   size_t karg_cap = 0, karg_uploaded = 0;
   uint64_t widx = 0;                                  // next packet id (this queue has one producer)
   bool inited = false;
-  std::atomic<bool> queue_error{false};               // set by the runtime's error callback (its own thread)
+  std::atomic<bool> queue_error{false};               // set by the runtime's error callback (its own thread), AFTER cb_err is written
+  char cb_err[256] = "";                              // ... which owns this text; err belongs to the calling thread
+  bool dead = false;                                  // a run was given up with packets still in the ring: never submit to this queue again
+  int wait_s = 300;                                   // L2_QUEUE_WAIT_S: a run that makes no progress for this long is given up
   char err[512] = "";
 };
 
@@ -85,8 +89,14 @@ static hsa_status_t on_pool(hsa_amd_memory_pool_t p, void* d) {
 
 static void on_queue_error(hsa_status_t s, hsa_queue_t*, void* d) {
   AqlQueue* q = (AqlQueue*)d;
-  q->queue_error = true;
-  snprintf(q->err, sizeof(q->err), "HSA queue error: %s", hsa_str(s));
+  snprintf(q->cb_err, sizeof(q->cb_err), "HSA queue error: %s", hsa_str(s));
+  q->queue_error.store(true, std::memory_order_release);
+}
+// the calling thread's view of it: the text is complete once the flag is seen
+static int queue_failed(AqlQueue* q) {
+  if (!q->queue_error.load(std::memory_order_acquire)) return 0;
+  q->dead = true;
+  return qfail(q, "%s", q->cb_err);
 }
 
 // gfx950 code objects inside the library: every clang offload bundle ("__CLANG_OFFLOAD_BUNDLE__", u64 entries, then per entry
@@ -177,6 +187,7 @@ AqlQueue* aql_create(int pci_domain, int pci_bus, int pci_device, int pci_functi
   if (s != HSA_STATUS_SUCCESS) return bail("hsa_amd_memory_pool_allocate (kernel arguments)", s);
   q->karg_host.reserve(q->karg_cap);
   q->widx = hsa_queue_load_write_index_relaxed(q->q);
+  { const char* w = getenv("L2_QUEUE_WAIT_S"); const int v = (w && *w) ? atoi(w) : 0; if (v > 0) q->wait_s = v; }
   return q;
 }
 
@@ -262,9 +273,12 @@ int aql_upload(AqlQueue* q) {
   return 0;
 }
 
+int aql_queue_dead(const AqlQueue* q) { return q ? (q->dead ? 1 : 0) : 1; }
+
 int aql_run(AqlQueue* q, int ntok, AqlProgram* const* per_token, int fence, double* elapsed_us) {
   if (!q || ntok < 0 || (ntok && !per_token)) return -1;
-  if (q->queue_error) return -1;
+  if (q->dead) return qfail(q, "the queue was given up by an earlier run (%s)", q->cb_err[0] ? q->cb_err : "no progress within L2_QUEUE_WAIT_S");
+  if (queue_failed(q)) return -1;
   if (q->karg_uploaded != q->karg_host.size()) return qfail(q, "kernel arguments recorded but not uploaded");
   size_t total = 0;
   for (int t = 0; t < ntok; ++t) total += per_token[t] ? per_token[t]->pk.size() : 0;
@@ -278,21 +292,24 @@ int aql_run(AqlQueue* q, int ntok, AqlProgram* const* per_token, int fence, doub
   size_t n = 0;
   std::chrono::steady_clock::time_point t0;
   bool started = false;
-  // a run that makes no progress for 300 s is given up (the read index is what moves)
-  auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300);
+  // a run that makes no progress for wait_s seconds (L2_QUEUE_WAIT_S, default 300) is given up (the read index is what moves) -- and the
+  // queue with it: its ring still holds this run's packets, `done` would be re-armed under them by the next run
+  const auto bound = std::chrono::seconds(q->wait_s);
+  auto deadline = std::chrono::steady_clock::now() + bound;
   uint64_t seen = hsa_queue_load_read_index_relaxed(q->q);
   auto progressed = [&]() {
     const uint64_t r = hsa_queue_load_read_index_relaxed(q->q);
-    if (r != seen) { seen = r; deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300); }
+    if (r != seen) { seen = r; deadline = std::chrono::steady_clock::now() + bound; }
   };
+  auto give_up = [&]() { q->dead = true; return qfail(q, "the run made no progress for %d s (L2_QUEUE_WAIT_S); the queue is given up", q->wait_s); };
   for (int t = 0; t < ntok; ++t) {
     const AqlProgram* p = per_token[t];
     if (!p || p->pk.empty()) continue;
     // room for the token's packets (the queue holds a few tens of tokens: the host runs ahead of the chip and then keeps pace)
     while (q->widx + p->pk.size() - hsa_queue_load_read_index_scacquire(q->q) > size) {
-      if (q->queue_error) return -1;
+      if (queue_failed(q)) return -1;
       progressed();
-      if (std::chrono::steady_clock::now() > deadline) return qfail(q, "the queue made no progress for 300 s");
+      if (std::chrono::steady_clock::now() > deadline) return give_up();
     }
     for (size_t i = 0; i < p->pk.size(); ++i, ++n) {
       hsa_kernel_dispatch_packet_t* dst = ring + ((q->widx + i) & (size - 1));
@@ -319,15 +336,15 @@ int aql_run(AqlQueue* q, int ntok, AqlProgram* const* per_token, int fence, doub
     if (!started) { t0 = std::chrono::steady_clock::now(); started = true; }
     hsa_signal_store_screlease(q->q->doorbell_signal, (hsa_signal_value_t)(q->widx - 1));
   }
-  // completion: spin briefly (a short run ends within microseconds), then sleep on the signal -- a TIMED run spins to its end (the
-  // wake-up from a sleep is tens of microseconds late)
+  // completion: spin briefly (a short run ends within microseconds), then sleep on the signal -- only a TIMED run (elapsed_us given) spins
+  // to its end (the wake-up from a sleep is tens of microseconds late); an untimed one leaves the host core alone
   hsa_signal_value_t v = hsa_signal_wait_scacquire(q->done, HSA_SIGNAL_CONDITION_LT, 1, 2000000ull, HSA_WAIT_STATE_ACTIVE);
   while (v >= 1) {
-    if (q->queue_error) return -1;
+    if (queue_failed(q)) return -1;
     progressed();
-    if (std::chrono::steady_clock::now() > deadline) return qfail(q, "the run made no progress for 300 s");
+    if (std::chrono::steady_clock::now() > deadline) return give_up();
     v = hsa_signal_wait_scacquire(q->done, HSA_SIGNAL_CONDITION_LT, 1, 100000000ull, elapsed_us ? HSA_WAIT_STATE_ACTIVE : HSA_WAIT_STATE_BLOCKED);
   }
   if (elapsed_us) *elapsed_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-  return q->queue_error ? -1 : 0;
+  return queue_failed(q) ? -1 : 0;
 }

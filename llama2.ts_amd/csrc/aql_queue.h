@@ -45,7 +45,12 @@ int aql_upload(AqlQueue* q);
 
 // Run `ntok` tokens: token t replays per_token[t].  Blocking.  fence = acquire scope + 4 * release scope of the fences BETWEEN
 // launches (AQL_FENCE_*; the run's first acquire and last release are always system scope).  elapsed_us (optional): first doorbell -> completion.
+// A run that makes no progress (the queue's read index stands still) for L2_QUEUE_WAIT_S seconds (environment, read at aql_create; default
+// 300) is given up: -1, and the queue is DEAD from then on (its ring still holds the run's packets) -- so is a queue whose error callback
+// fired.  The caller destroys it and goes back to HIP launches.  elapsed_us == nullptr: the host sleeps on the completion signal instead of
+// spinning (an untimed 2048-token 7B run is ~10 s).
 int aql_run(AqlQueue* q, int ntok, AqlProgram* const* per_token, int fence, double* elapsed_us);
+int aql_queue_dead(const AqlQueue* q);
 const char* aql_last_error(const AqlQueue* q);
 // How many gfx950 code objects the offload bundles of `so_path` hold (file parsing only: no GPU, no HSA); -1: the file cannot be read.
 int aql_count_code_objects(const char* so_path);

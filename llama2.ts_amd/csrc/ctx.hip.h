@@ -140,7 +140,7 @@ struct l2_ctx {
   // one-shot peer-to-peer exchange (tp_p2p_*): this rank's inbox + flags, the peers' mappings
   bool p2p = false;
   void* p2p_base = nullptr;          // uncached: [2][8][64] flag words, then [2][8][d] doubles
-  unsigned long long* p2p_epoch = nullptr;   // [P2P_FB] exchange counters, one per block (device)
+  unsigned long long* p2p_epoch = nullptr;   // [2][P2P_FB] exchange counters, one per block (device): the flag exchange's and the logits gather's, then the pushed exchange's own
   int* p2p_err = nullptr;            // pinned + mapped
   int* p2p_err_dev = nullptr;
   P2PPeers p2p_peers = {};

@@ -387,12 +387,14 @@ __device__ __forceinline__ void row_ptrs(const PhaseArgs& a, int g, int n, const
   }
 }
 
-// argmax (llama2.ts:364-366: first maximum, strict '>'): a logit and its index travel as ONE 64-bit key
-// (order-preserving bits of the value, then ~index), so "largest value, smallest index" is an unsigned maximum.
+// argmax (llama2.ts:364-366: `arr.reduce((maxIdx, val, idx, array) => (val > array[maxIdx] ? idx : maxIdx), 0)` -- first maximum, strict
+// '>'): a logit and its index travel as ONE 64-bit key (order-preserving bits of the value, then ~index), so "largest value, smallest
+// index" is an unsigned maximum.  NaN never wins a '>' (key bits 0: below -inf) -- EXCEPT at index 0, where the reduce() starts: no
+// `val > NaN` is ever true, so the pick stays 0 whatever the other logits are (the all-ones key: above +inf, and it decodes to 0).
 __device__ __forceinline__ unsigned long long argmax_key(float v, int i) {
   v = v + 0.0f;                                          // -0 -> +0: '>' does not tell them apart
   const unsigned u = __float_as_uint(v);
-  const unsigned o = (v != v) ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));   // NaN never wins a '>'
+  const unsigned o = (v != v) ? (i == 0 ? 0xffffffffu : 0u) : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
   return ((unsigned long long)o << 32) | (unsigned)(~i);
 }
 template <int CTRL, int ROW_MASK>
@@ -638,7 +640,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
   // the chip's requests of one moment sit a whole row (a power of two of bytes) apart and crowd the same HBM channels
   // (tools/microbench_rows.hip: 56.5 -> 54.2 us for the w1/w3 shape).  ci counts batches, col(gi, ci) is where batch ci lies.
   // (PK: no rotation -- the layout is what spreads the requests; `rg` then counts the wave's rounds instead)
-  auto rot_of = [&](int gi) { return (!PK && a.rot) ? (int)((unsigned)(gi * a.rot) % (unsigned)nchunks) : 0; };
+  // (never for a classifier: a rotated row adds its column batches in another order than its neighbour, and two rows with the SAME weights
+  //  -- an exact tie of the maximum, which the reference resolves to the smaller index, llama2.ts:364-366 -- must round to the same logit)
+  auto rot_of = [&](int gi) { return (!PK && MODE != MODE_CLS && a.rot) ? (int)((unsigned)(gi * a.rot) % (unsigned)nchunks) : 0; };
   auto col = [&](int ci, int rg) { if (PK) return ci; const int c = ci + rg; return c >= nchunks ? c - nchunks : c; };
   auto next = [&](int& gi, int& ci, bool& hv, int& rg) {
     if (++ci == nchunks) { ci = 0; gi += wstride; rg = PK ? rg + 1 : rot_of(gi); }

@@ -30,13 +30,17 @@ static Geo pick_geo_pure(const GeoKnobs& kb, int mode, int rows, int n) {
   int U = 2;
   if (n4 > 128 && n4 <= 256) U = 4;
   if (mode == MODE_CLS && n4 > 128 && n4 <= 192) U = 3;   // 768 columns (stories110M): three float4 per lane cover a row exactly; with U = 4 a quarter of the lanes re-read the last one (16.8 -> 16.5 us)
-  if (kb.tune_U == 2 || kb.tune_U == 4 || (kb.tune_U == 3 && mode == MODE_CLS)) U = kb.tune_U;
+  if (kb.tune_U == 2 || kb.tune_U == 4 || (kb.tune_U == 3 && mode == MODE_CLS && n4 > 128 && n4 <= 192)) U = kb.tune_U;      // (U = 3 exists for the widths it covers exactly)
   g.U = U;
   const int groups = (rows * pair + g.R - 1) / g.R;
   // 4 waves per workgroup from 512 row groups on (2 up to round 3: the q / k / v shard of an 8-rank group -- 768 groups -- runs
   // 9.0 -> 7.1 us with 4: fewer, fuller workgroups share the staged x; tools/tp_shard_sweep.py)
   g.nwaves = groups >= 512 ? 4 : (groups >= 256 ? 2 : 1);
   if (kb.tune_nwaves == 1 || kb.tune_nwaves == 2 || kb.tune_nwaves == 4) g.nwaves = kb.tune_nwaves;
+  // q / k / v of 513 .. 1024 columns (U = 4) exist with the one-per-thread staging round only, i.e. on four waves: with whole (d, d)
+  // matrices such a width always has the 512 row groups that select them, but a grouped-query or tensor-parallel phase has
+  // d_loc + 2 kv_dim_loc rows (d = 640 with 128-wide k / v: 448 groups), and L2_TUNE_NWAVES can ask for fewer
+  if (mode == MODE_QKV && U == 4) g.nwaves = 4;
   // staging: PRE float4 per thread per round, one round if it can cover the (padded) vector
   const int cpi = 64 * U, npad4 = ((n4 + cpi - 1) / cpi) * cpi, nth = 64 * g.nwaves;
   // one staging round whenever 12 float4 per thread cover the vector (w2 of Llama-2-7B: 11008 floats = 2752 float4 on 256
@@ -128,15 +132,30 @@ static bool use_small_pure(long long small_max, int mode, int rows, int n) {
 }
 static bool use_small(const l2_ctx* c, int mode, int rows, int n) { return use_small_pure((long long)c->small_max, mode, rows, n); }
 
+// Geometry of the latency form (pure): XV template point (float4 of x per lane: 1 .. 4, 6, 8), rows per wave and group (1 for a single
+// matrix while one row per wave still leaves waves idle, else 2 -- RoPE neighbours / a (w1, w3) row pair always travel together) and the
+// grid: one workgroup per CU as soon as there are that many row groups -- fewer busy waves per CU beat fewer CUs (the CU's 64 B / clock
+// address path is what a 7-wave workgroup queues on): stories15M 8 660 -> 8 945 tok/s, stories110M +0.7 % (profiles/r03/ab_small_kernel_grid.txt).
+// ONE function for the launcher and the debug hook below.
+struct SmallGeo { int xv, R, grid; };
+static SmallGeo small_geo_pure(int n_cus, int mode, int rows, int n) {
+  const int xv = (n / 4 + 63) / 64, xvt = xv <= 4 ? xv : (xv <= 6 ? 6 : 8);
+  const bool pair = (mode == MODE_QKV || mode == MODE_W13);
+  const bool r1 = !pair && rows <= n_cus * 7;      // seven compute waves per workgroup (kernels.hip.h)
+  const int rpg = (mode == MODE_W13) ? 1 : (r1 ? 1 : 2);
+  const int groups = (rows + rpg - 1) / rpg;
+  int grid = groups < n_cus ? groups : n_cus;
+  if (grid < 1) grid = 1;
+  return {xvt, r1 ? 1 : 2, grid};
+}
+
 // What launch_phase would launch for a phase of `rows` x `n` (pure: no context, no GPU): out = {form, U or XV, PRE or R, waves per workgroup,
 // grid, packed-capable}; form 0 = streaming vector kernel, 1 = latency form, 2 = scalar kernel (n % 4 != 0).
 extern "C" int l2_debug_pick_geo(int mode, int rows, int n, int n_cus, int small_max, int out[6]) {
   if (!out || mode < 0 || mode > MODE_CLS || rows <= 0 || n <= 0 || n_cus <= 0) return L2_E_ARG;
   if (use_small_pure(small_max, mode, rows, n)) {
-    const int xv = (n / 4 + 63) / 64, xvt = xv <= 4 ? xv : (xv <= 6 ? 6 : 8);
-    const bool pair = (mode == MODE_QKV || mode == MODE_W13), r1 = !pair && rows <= n_cus * 7;
-    const int rpg = (mode == MODE_W13) ? 1 : (r1 ? 1 : 2), groups = (rows + rpg - 1) / rpg;
-    out[0] = 1; out[1] = xvt; out[2] = (!pair && r1) ? 1 : 2; out[3] = 8; out[4] = groups < n_cus ? groups : n_cus; out[5] = 0;
+    const SmallGeo sg = small_geo_pure(n_cus, mode, rows, n);
+    out[0] = 1; out[1] = sg.xv; out[2] = sg.R; out[3] = 8; out[4] = sg.grid; out[5] = 0;
     return L2_OK;
   }
   const GeoKnobs kb = {n_cus, 0, 0, 0};
@@ -147,34 +166,24 @@ extern "C" int l2_debug_pick_geo(int mode, int rows, int n, int n_cus, int small
 }
 
 template <int MODE, int XV>
-static hipError_t launch_small_xv(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
+static hipError_t launch_small_xv(const l2_ctx* c, const PhaseArgs& a, const SmallGeo& sg, hipStream_t st) {
   constexpr bool pair = (MODE == MODE_QKV || MODE == MODE_W13);       // row pairs: RoPE neighbours / (w1, w3)
   const size_t lds = (size_t)XV * 64 * 16;
-  const int waves = c->n_cus * 7;     // seven compute waves per workgroup (kernels.hip.h)
-  // one row per wave while that still leaves waves idle, else two
-  const bool r1 = !pair && a.rows <= waves;
-  const int rpg = (MODE == MODE_W13) ? 1 : (r1 ? 1 : 2);
-  const int groups = (a.rows + rpg - 1) / rpg;
-  // one workgroup per CU as soon as there are that many row groups: fewer busy waves per CU beat fewer CUs (the CU's 64 B / clock
-  // address path is what a 7-wave workgroup queues on): stories15M 8 660 -> 8 945 tok/s, stories110M +0.7 % (profiles/r03/ab_small_kernel_grid.txt)
-  int grid = groups;
-  if (grid > c->n_cus) grid = c->n_cus;
-  if (grid < 1) grid = 1;
-  if (!pair && r1) launch_probed(c, phase_small_kernel<MODE, XV, pair ? 2 : 1>, dim3(grid), dim3(512), lds, st, a, MODE == MODE_W13);
-  else launch_probed(c, phase_small_kernel<MODE, XV, 2>, dim3(grid), dim3(512), lds, st, a, MODE == MODE_W13);
+  if (!pair && sg.R == 1) launch_probed(c, phase_small_kernel<MODE, XV, pair ? 2 : 1>, dim3(sg.grid), dim3(512), lds, st, a, MODE == MODE_W13);
+  else launch_probed(c, phase_small_kernel<MODE, XV, 2>, dim3(sg.grid), dim3(512), lds, st, a, MODE == MODE_W13);
   return hipGetLastError();
 }
 
 template <int MODE>
 static hipError_t launch_small(const l2_ctx* c, const PhaseArgs& a, hipStream_t st) {
-  const int xv = (a.n / 4 + 63) / 64;
-  switch (xv) {
-    case 1: return launch_small_xv<MODE, 1>(c, a, st);
-    case 2: return launch_small_xv<MODE, 2>(c, a, st);
-    case 3: return launch_small_xv<MODE, 3>(c, a, st);
-    case 4: return launch_small_xv<MODE, 4>(c, a, st);
-    case 5: case 6: return launch_small_xv<MODE, 6>(c, a, st);
-    default: if constexpr (MODE == MODE_W13) return hipErrorInvalidValue; else return launch_small_xv<MODE, 8>(c, a, st);   // use_small() keeps W13 out
+  const SmallGeo sg = small_geo_pure(c->n_cus, MODE, a.rows, a.n);
+  switch (sg.xv) {
+    case 1: return launch_small_xv<MODE, 1>(c, a, sg, st);
+    case 2: return launch_small_xv<MODE, 2>(c, a, sg, st);
+    case 3: return launch_small_xv<MODE, 3>(c, a, sg, st);
+    case 4: return launch_small_xv<MODE, 4>(c, a, sg, st);
+    case 6: return launch_small_xv<MODE, 6>(c, a, sg, st);
+    default: if constexpr (MODE == MODE_W13) return hipErrorInvalidValue; else return launch_small_xv<MODE, 8>(c, a, sg, st);   // use_small() keeps W13 out
   }
 }
 
@@ -220,7 +229,7 @@ static hipError_t launch_phase(const l2_ctx* c, const PhaseArgs& a_in, hipStream
   if (g.U == 3) { if constexpr (MODE == MODE_CLS) { if (g.pre == 1) L2_LAUNCH(3, 1); else L2_LAUNCH(3, 4); } }
   else if (g.U == 2) L2_LAUNCH_U(2);
   else if (g.pre == 1) L2_LAUNCH(4, 1);      // (a row of at most 256 float4 never needs more than four per thread ...
-  else if constexpr (MODE != MODE_QKV) L2_LAUNCH(4, 4);      //  ... and q / k / v of such a width have the 512 row groups that put four waves in a workgroup: one round)
+  else if constexpr (MODE != MODE_QKV) L2_LAUNCH(4, 4);      //  ... and q / k / v of such a width always run on four waves -- pick_geo_pure -- : one round)
   else return hipErrorInvalidValue;
 #undef L2_LAUNCH_U
 #undef L2_LAUNCH

@@ -868,6 +868,17 @@ static int aql_record_level(l2_ctx* c, int lvl, int (*enq)(l2_ctx*, hipStream_t)
   return L2_RUN_EAGER;
 }
 
+// A run on the queue failed (no progress within L2_QUEUE_WAIT_S, or the runtime reported a queue error): the ring may still hold its
+// packets, so the queue is never submitted to again -- it is destroyed with its recordings and the context goes on with HIP launches
+// (aql_tried stays set; the note says why).  The failed call itself reports the error.
+static int aql_give_up(l2_ctx* c) {
+  const int rc = fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
+  c->aql_note = std::string("given up after a failed run: ") + aql_last_error(c->aql);
+  destroy_graphs(c);
+  aql_destroy(c->aql); c->aql = nullptr;
+  return rc;
+}
+
 static int run_greedy_aql(l2_ctx* c, int pos0, int steps, bool timed, float* ms) {
   if (!c->aql && aql_open(c)) return L2_RUN_EAGER;
   for (int s = 0; s < steps; ++s) {
@@ -880,7 +891,7 @@ static int run_greedy_aql(l2_ctx* c, int pos0, int steps, bool timed, float* ms)
   for (int s = 0; s < steps; ++s) per[s] = c->aql_greedy[split_level(c, pos0 + s)];
   if (steps > 0 && c->aql_last) per.push_back(c->aql_last);      // the run's last pick
   double us = 0.0;
-  if (aql_run(c->aql, (int)per.size(), per.data(), c->aql_fence, &us)) return fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
+  if (aql_run(c->aql, (int)per.size(), per.data(), c->aql_fence, timed ? &us : nullptr)) return aql_give_up(c);      // (only a timed run spins on the completion signal)
   if (timed && ms) *ms = (float)(us * 1e-3);
   c->ran_forward = true;
   return check_p2p(c);
@@ -900,7 +911,7 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
     // the library's own queue: {token, pos} read from pinned host memory by the first launch, logits written straight into the
     // host's buffer by the classifier, one doorbell, one signal
     HIPCHK(hipStreamSynchronize(c->stream));      // (uploads, an earlier graph's work)
-    if (aql_run(c->aql, 1, &c->aql_step[lvl], c->aql_fence, nullptr)) return fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
+    if (aql_run(c->aql, 1, &c->aql_step[lvl], c->aql_fence, nullptr)) return aql_give_up(c);
     c->ran_forward = true;
     rc = check_p2p(c);
     if (rc) return rc;
@@ -1011,7 +1022,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
       else per[s] = c->aql_sample[lvl][mode];
     }
     if (ok) {
-      if (aql_run(c->aql, steps, per.data(), c->aql_fence, nullptr)) return fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
+      if (aql_run(c->aql, steps, per.data(), c->aql_fence, nullptr)) return aql_give_up(c);
       HIPCHK(hipMemcpyAsync(rng_state, c->samp.rng, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipMemcpyAsync(tokens_out, c->d_tokens, (size_t)steps * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));

@@ -201,7 +201,7 @@ static int p2p_publish_table(l2_ctx* c) {
   TpPush t;
   memset(&t, 0, sizeof(t));
   for (int r = 0; r < c->G && r < P2P_MAXG; ++r) t.gin[r] = c->p2p_peers.gin[r];
-  t.G = c->G; t.rank = c->rank; t.n = c->d; t.solo = c->solo ? 1 : 0; t.epoch = c->p2p_epoch;
+  t.G = c->G; t.rank = c->rank; t.n = c->d; t.solo = c->solo ? 1 : 0; t.epoch = c->p2p_epoch + P2P_FB;      // (the combine launches' own counters: p2p_combine_args)
   if (!c->tp_push) HIPCHK(hipMalloc(&c->tp_push, sizeof(TpPush)));
   HIPCHK(hipMemcpy(c->tp_push, &t, sizeof(t), hipMemcpyHostToDevice));
   return L2_OK;
@@ -213,6 +213,12 @@ static P2PArgs p2p_args(const l2_ctx* c, int n) {
   a.G = c->G; a.rank = c->rank; a.n = n; a.wait_ticks = c->p2p_wait_ticks; a.solo = c->solo ? 1 : 0; a.fenced = c->p2p_fenced;
   return a;
 }
+// The pushed exchange counts on words of ITS OWN (the second half of p2p_epoch): the pushing GEMV reads word 0 for every row, and the
+// combine launch's block b reads word b -- the two agree only if every block of every launch that advances these words advances all of
+// them.  The combine launches do (their grid is always p2p_grid(d)); the logits gather, whose grid is p2p_grid(V_loc), does not, so it
+// keeps the flag exchange's words to itself (a vocabulary shard of fewer 256-element blocks than d has would otherwise leave the
+// combine's upper blocks one exchange behind block 0: wrong-parity slots with matching stale tags, or waits that never end).
+static P2PArgs p2p_combine_args(const l2_ctx* c) { P2PArgs a = p2p_args(c, c->d); a.epoch = c->p2p_epoch + P2P_FB; return a; }
 static int p2p_grid(int n) { const int b = (n + 255) / 256; return b > P2P_FB ? P2P_FB : (b < 1 ? 1 : b); }
 
 // Own buffers (every tensor-parallel context): inbox + flags and the gathered-logits vector are UNCACHED device
@@ -223,8 +229,8 @@ static int p2p_alloc(l2_ctx* c) {
   if (mode && !strcmp(mode, "rccl")) return L2_OK;
   if (hipExtMallocWithFlags(&c->p2p_base, p2p_bytes(c), hipDeviceMallocUncached) != hipSuccess) { c->p2p_base = nullptr; (void)hipGetLastError(); return L2_OK; }
   HIPCHK(hipMemset(c->p2p_base, 0, p2p_bytes(c)));
-  HIPCHK(hipMalloc(&c->p2p_epoch, (size_t)P2P_FB * 8));
-  HIPCHK(hipMemset(c->p2p_epoch, 0, (size_t)P2P_FB * 8));
+  HIPCHK(hipMalloc(&c->p2p_epoch, (size_t)2 * P2P_FB * 8));      // [0, FB): flag exchange + logits gather; [FB, 2 FB): pushed exchange (p2p_combine_args)
+  HIPCHK(hipMemset(c->p2p_epoch, 0, (size_t)2 * P2P_FB * 8));
   HIPCHK(hipHostMalloc(&c->p2p_err, sizeof(int), hipHostMallocMapped));
   *c->p2p_err = 0;
   HIPCHK(hipHostGetDevicePointer((void**)&c->p2p_err_dev, c->p2p_err, 0));
@@ -346,7 +352,7 @@ static int p2p_connect_ipc(l2_ctx* c) {
     auto exchange = [&](int k) {
       if (p2p_pushing(c)) {
         hipLaunchKernelGGL(p2p_selftest_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->tp_push, c->xb2, c->rank, n, k);
-        hipLaunchKernelGGL(tp_p2p_combine_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->xb2, nullptr, nullptr, c->tokpos, (unsigned*)nullptr);
+        hipLaunchKernelGGL(tp_p2p_combine_kernel, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_combine_args(c), c->xb2, nullptr, nullptr, c->tokpos, (unsigned*)nullptr);
       } else {
         hipLaunchKernelGGL(p2p_selftest_fill, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->partial, c->xb2, c->rank, n, k);
         hipLaunchKernelGGL(tp_p2p_reduce_kernel<0>, dim3(p2p_grid(n)), dim3(256), 0, c->stream, p2p_args(c, n), c->partial, c->xb2, nullptr, nullptr, c->tokpos);
@@ -434,7 +440,7 @@ static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
 static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out, unsigned* bump) {
   const dim3 grid(p2p_grid(c->d));
   if (p2p_pushing(c)) {
-    l2_launch(c, tp_p2p_combine_kernel, grid, dim3(256), 0, st, p2p_args(c, c->d), c->x, res_emb, mv_out, (const int*)c->tokpos, bump);
+    l2_launch(c, tp_p2p_combine_kernel, grid, dim3(256), 0, st, p2p_combine_args(c), c->x, res_emb, mv_out, (const int*)c->tokpos, bump);
   } else if (!c->loop) {
     l2_launch(c, tp_p2p_reduce_kernel<0>, grid, dim3(256), 0, st, p2p_args(c, c->d), (const double*)c->partial, c->x, res_emb, mv_out, (const int*)c->tokpos);
   } else {

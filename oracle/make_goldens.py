@@ -59,6 +59,10 @@ PLAN = {
     # compute (what L2_F_GENERATE_ROPE generates, llama2.ts:125-126 reads them from the file) -- pins version-1 checkpoints.
     "wide_gqa_mha": (320, [0, 1, 2, 23, 143, 144, 145, 159, 160, 319], False, None),
     "tiny_gqa_rope_mha": (64, "all", False, None),
+    # the reference's argmax (llama2.ts:364-366) on logits that hit its edges: models with patched classifier rows (tests/argmax_cases.py:
+    # exact ties across the device's workgroups, -0 beside +0, +-inf, NaN, nothing but NaN, NaN at index 0) -- what is pinned is the
+    # token the reference FED next (its own pick), not numpy's argmax of the dumped logits
+    **{"argmax_%s_%s" % (c, sh): (16, [0, 3, 15], False, None) for sh in ("vec", "odd") for c in ("ties", "specials", "nan0", "allnan", "zeros")},
 }
 
 DUMP_STMT = (
@@ -126,7 +130,15 @@ def run_one(inst, name):
     synth_tok = plan[5] if len(plan) > 5 else False
     shape = "stories15M" if name.startswith("cli_") else name.replace("_prompt", "")
     gqa_hdr = None
-    if name.endswith("_mha"):      # grouped-query model, expanded to the multi-head checkpoint the reference can read
+    edge = None
+    if name.startswith("argmax_"):     # classifier rows patched so that the logits hit the edges of the reference's argmax
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import argmax_cases
+        _, edge, shape = name.split("_")
+        hdr, seed = argmax_cases.SHAPES[shape], argmax_cases.SEED
+        ckpt = os.path.join(WORK, name + ".bin")
+        argmax_cases.write_v0(ckpt, edge, shape)
+    elif name.endswith("_mha"):      # grouped-query model, expanded to the multi-head checkpoint the reference can read
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import gqa_cases
         shape = name[:-4]
@@ -181,6 +193,14 @@ def run_one(inst, name):
         "stdout_tail": r.stdout.decode("utf8", "replace")[-80:],
         "tokenizer": "synthetic (tests/synth_tokenizer.py)" if synth_tok else "reference tokenizer.bin",
     }
+    if edge is not None:
+        # the reference's OWN picks: the token it fed at step i + 1 is what its argmax returned at step i (llama2.ts:478, 504)
+        meta["picks"] = tokens.tolist()[1:]
+        meta["case"] = edge
+        meta["what"] = "tests/argmax_cases.py model (%s, %s): `picks` are the reference's own argmax results; `argmax` here is numpy's, which treats NaN differently" % (edge, shape)
+        with np.errstate(invalid="ignore"):
+            meta["logit_census"] = [{"nan": int(np.isnan(logits[i]).sum()), "inf": int(np.isinf(logits[i]).sum()),
+                                     "neg_zero": int((np.signbit(logits[i]) & (logits[i] == 0)).sum())} for i in range(n)]
     if gqa_hdr is not None:
         meta["gqa_header"] = list(gqa_hdr)
         meta["what"] = ("the reference ran the MULTI-HEAD expansion of the grouped-query model (gqa_header, seed): wk / wv rows of each cache "

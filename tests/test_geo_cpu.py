@@ -42,11 +42,14 @@ def kernels(tmp_path_factory):
     return {"stream": stream, "small": small, "n": len(names)}
 
 
-def phases(hdr, G=1):
+def phases(hdr, G=1, gqa=False):
+    """(mode, rows, columns) of the five phases as the library launches them: q / k / v has d_loc + 2 kv_dim_loc rows (llama2_hip.hip:
+    qkv_args) -- 3 d_loc unless the context honours n_kv_heads < n_heads (L2_F_GQA)."""
     d, h, _L, H, KVH, V, _S = hdr
     V = abs(V)
     dl, hl, Vl = d // G, h // G, V // G
-    return [(MODE_QKV, 3 * dl, d), (MODE_WO, d, dl), (MODE_W13, hl, d), (MODE_W2, d, hl), (MODE_CLS, Vl, d)]
+    kvl = (KVH * (d // H) if gqa else d) // G
+    return [(MODE_QKV, dl + 2 * kvl, d), (MODE_WO, d, dl), (MODE_W13, hl, d), (MODE_W2, d, hl), (MODE_CLS, Vl, d)]
 
 
 def pick(mode, rows, n, small_max=SMALL_MAX):
@@ -65,6 +68,10 @@ def shapes():
     out += [((1280, 2560, 2, 10, 10, -1000, 48), 1), ((1280, 2572, 2, 10, 10, 1000, 48), 1), ((2048, 5632, 1, 16, 16, -777, 32), 1), ((1280, 1280, 1, 10, 10, -140001, 16), 1)]
     # narrow hidden sizes and wide-but-short matrices: the streaming kernel's short-row points (U = 4 with two waves, U = 2 / 4 with one staging round in w2)
     out += [((768, 300, 1, 12, 12, 300, 32), 1), ((512, 300, 1, 8, 8, -300, 32), 1), ((1024, 768, 1, 8, 8, 300, 32), 1), ((1024, 8192, 1, 8, 8, -300, 32), 1), ((640, 200, 1, 10, 10, 120, 32), 1)]
+    # grouped-query shapes (the third entry: honoured, L2_F_GQA): q / k / v phases with fewer rows than 3 d -- the round-5 advisor's
+    # d = 640 with 128-wide k / v, multi-query 7B width, the GQA fixtures of tests/gqa_cases.py
+    out += [((640, 1728, 1, 10, 2, -300, 32), 1, True), ((4096, 11008, 1, 32, 1, -320, 16), 1, True), ((4096, 11008, 1, 32, 8, -320, 16), 8, True),
+            ((1024, 2816, 1, 16, 2, 300, 32), 1, True), ((768, 2048, 1, 12, 4, 300, 32), 1, True), ((64, 176, 2, 4, 2, 512, 64), 1, True), ((256, 704, 2, 4, 1, -512, 320), 1, True)]
     rng = np.random.default_rng(5)
     for _ in range(300):      # odd widths, tiny and huge row counts
         H = int(rng.choice([1, 2, 4, 8, 16, 32]))
@@ -80,8 +87,8 @@ def test_every_selected_template_point_is_instantiated_and_no_streaming_point_is
     used = set()
     # (small_max 0: the development configuration L2_SMALL_MAX=0 the GPU tests use to run the streaming form on shapes that default to
     # the latency form -- a narrow qkv / wo phase reaches the streaming kernel's short-row points only that way)
-    for hdr, G, small_max in [(hdr, G, sm) for hdr, G in shapes() for sm in (SMALL_MAX, 0)]:
-        for mode, rows, n in phases(hdr, G):
+    for hdr, G, gqa, small_max in [(sh[0], sh[1], len(sh) > 2 and sh[2], sm) for sh in shapes() for sm in (SMALL_MAX, 0)]:
+        for mode, rows, n in phases(hdr, G, gqa):
             if rows <= 0 or n <= 0:
                 continue
             form, a, b, nw, grid, packable = pick(mode, rows, n, small_max)

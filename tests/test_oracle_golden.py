@@ -186,3 +186,51 @@ def test_js_in_process_generator_equals_the_checkpoint_file(name, steps, tmp_pat
     j = json.loads(r.stdout.decode())
     assert j["tensor_sha256"] == want
     assert j["sha256"] == meta["logits_sha256"][:steps] and j["tokens"] == meta["argmax"][:steps]
+
+
+def _same_floats(a, b):
+    """Bit equality with every NaN counted as the same value (V8 stores a canonical NaN; the C oracle's inf - inf carries a sign bit)."""
+    a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    na, nb = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(na, nb) and np.array_equal(bits(a)[~na], bits(b)[~nb]))
+
+
+@pytest.mark.parametrize("shape", ["vec", "odd"])
+@pytest.mark.parametrize("case", ["ties", "specials", "nan0", "allnan", "zeros"])
+def test_oracle_argmax_edges_match_the_reference(case, shape):
+    """llama2.ts:364-366 on logits that hit its edges (tests/argmax_cases.py), RUN BY THE REAL REFERENCE: the oracle's logits are
+    the reference's (NaN = NaN) and orc_argmax picks what the reference fed next -- first of tied maxima, -0 == +0, NaN never wins
+    except at index 0, where the reduce() never leaves it."""
+    import argmax_cases as A
+    meta, g = load("argmax_%s_%s" % (case, shape))
+    assert meta["header"] == list(A.SHAPES[shape]) and meta["seed"] == A.SEED
+    o, _ = A.patched_oracle(case, shape)
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    hit = {"nan": 0, "inf": 0, "neg_zero": 0}
+    for pos, tok in enumerate(meta["tokens_fed"]):
+        lg = o.forward(tok, pos)
+        if pos in keep:
+            assert _same_floats(lg, g["logits"][keep[pos]]), (case, shape, pos)
+        with np.errstate(invalid="ignore"):
+            census = {"nan": int(np.isnan(lg).sum()), "inf": int(np.isinf(lg).sum()), "neg_zero": int((np.signbit(lg) & (lg == 0)).sum())}
+        assert census == meta["logit_census"][pos], (case, shape, pos)
+        for k in hit:
+            hit[k] += census[k]
+        if pos + 1 < len(meta["tokens_fed"]):
+            assert O.argmax(lg) == meta["picks"][pos] == meta["tokens_fed"][pos + 1], (case, shape, pos)
+    o.close()
+    # every case really produces what it is named for
+    V = abs(A.SHAPES[shape][5])
+    if case == "ties":
+        dup = set(A._spread(V)) | {5, (3 * V) // 5 + 2}
+        assert sum(p in dup for p in meta["picks"]) >= 8
+    if case == "specials":
+        assert hit["nan"] and hit["inf"] and set(meta["picks"]) <= {4, 6}
+    if case in ("nan0", "allnan", "zeros"):
+        assert set(meta["picks"]) == {0}
+    if case == "nan0":
+        assert hit["nan"] == len(meta["tokens_fed"])          # one NaN per step, at index 0, and finite logits above every other
+    if case == "allnan":
+        assert hit["nan"] == V * len(meta["tokens_fed"])
+    if case == "zeros":
+        assert hit["neg_zero"] >= len(meta["tokens_fed"])

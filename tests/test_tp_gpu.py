@@ -84,6 +84,47 @@ def test_one_rank_communicator(collective):
         del os.environ["L2_TP_ALLREDUCE"]
 
 
+# a vocabulary (shard) of FEWER 256-element blocks than dim has: the logits gather then runs fewer workgroups than the combine launch of
+# the pushed all-reduce, and the two must not share exchange counters (round-5 advisor finding: the combine's upper blocks fell one
+# exchange behind the pushing GEMV, which reads block 0's counter -- the creation soak then sent the group back to RCCL, or a wait ran
+# into its bound).  Llama-2-7B never showed it: 4000 / 256 and 4096 / 256 both round up to 16 blocks.
+NARROW_VOCAB = (1024, 1536, 2, 8, 8, -512, 40)
+
+
+def test_pushed_exchange_with_fewer_vocabulary_blocks_than_dim():
+    orc = O.Oracle(NARROW_VOCAB, 7)
+    want, tok = [], 1
+    for pos in range(12):
+        lg = orc.forward(tok, pos)
+        want.append(lg)
+        tok = O.argmax(lg)
+    picks = [O.argmax(lg) for lg in want]
+    os.environ["L2_TP_FORCE_COMM"] = "1"
+    os.environ["L2_TP_ALLREDUCE"] = "p2p"
+    os.environ["L2_TP_WAIT_S"] = "3"
+    try:
+        ctx = runtime.Context(NARROW_VOCAB)
+        assert ctx.tp_mode_id() == 3, ctx.tp_mode()          # the creation soak (96 all-reduces, 32 gathers in between) kept the peer-to-peer path
+        ctx.synth_fill(7)
+        tok = 1
+        for pos in range(12):
+            got = np.array(ctx.forward(tok, pos), copy=True)
+            assert np.abs(got - want[pos]).max() <= 1e-4, pos
+            tok = picks[pos]
+        assert ctx.decode_greedy(1, 0, 12).tolist() == picks
+        ctx.close()
+        # ... and a shard-timing context of an 8-rank group of the shape the finding names (d = 5120, V = 32000: 16 gather blocks, 20 combine
+        # blocks): no soak runs there, a lagging block would sit out L2_TP_WAIT_S on every exchange and break the context
+        solo = runtime.Context((5120, 13824, 1, 40, 40, -32000, 16), tp_rank=0, tp_size=8, nccl_id=runtime.TP_SOLO_ID)
+        solo.synth_fill(1)
+        solo.decode_greedy(1, 0, 12)
+        solo.decode_greedy(1, 0, 12)
+        solo.close()
+    finally:
+        for k in ("L2_TP_FORCE_COMM", "L2_TP_ALLREDUCE", "L2_TP_WAIT_S"):
+            del os.environ[k]
+
+
 def _run_group(name, G, n_forward, n_greedy, exact=False, collective="p2p"):
     """G ranks of one tensor-parallel group as G host threads on one device (L2_TP_LOOPBACK test hook in
     llama2_hip.hip: the collectives become device sums/copies between thread barriers; everything else is the

@@ -5,7 +5,7 @@ workgroups by XCD, by shader engine and by position in the grid.
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["L2_LIB_PATH"] = os.path.join(ROOT, "llama2.ts_amd", "lib", "libllama2hip_stamps.so")
+sys.path.insert(0, os.path.join(ROOT, "tools")); import diag_lib; diag_lib.use()    # builds gpurun_out/diag/libllama2hip_stamps.so on demand
 os.environ["L2_USE_GRAPH"] = "0"
 os.environ.setdefault("L2_TEST_HOOKS", "1")
 import numpy as np

@@ -6,7 +6,7 @@ previous phase launch's last end (= boundaries + whatever launch without stamps 
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["L2_LIB_PATH"] = os.path.join(ROOT, "llama2.ts_amd", "lib", "libllama2hip_stamps.so")
+sys.path.insert(0, os.path.join(ROOT, "tools")); import diag_lib; diag_lib.use()    # builds gpurun_out/diag/libllama2hip_stamps.so on demand
 os.environ["L2_USE_GRAPH"] = "1"
 os.environ.setdefault("L2_TEST_HOOKS", "1")
 import numpy as np
