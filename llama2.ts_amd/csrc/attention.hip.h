@@ -24,13 +24,13 @@
 namespace l2k {
 
 struct AttnArgs {
-  const float* q;        // (dim) rotated q of this position
-  const float* kc;       // key_cache   + l*S*d   (row `pos` was written by the QKV launch before this one)
-  const float* vc;       // value_cache + l*S*d
-  float* att;            // (H, S) probabilities (RunState.att, parity reads)
-  float* xb;             // (dim) out
+  Mut<const float> q;    // (dim) rotated q of this position      (Mut: bytes an earlier launch of the run wrote -- no plain load compiles, kernels.hip.h)
+  Mut<const float> kc;   // key_cache   + l*S*d   (row `pos` was written by the QKV launch before this one)
+  Mut<const float> vc;   // value_cache + l*S*d
+  Mut<float> att;        // (H, S) probabilities (RunState.att, parity reads)
+  Mut<float> xb;         // (dim) out
   const int* tokpos;
-  double* part;          // split form: [H][nsplit][rec] doubles, rec = round_up(hs + 2, 16)
+  Mut<double> part;      // split form: [H][nsplit][rec] doubles, rec = round_up(hs + 2, 16)
   unsigned* counter;     // split form: [H] merge tickets (one per 128-byte line), zero between launches
   int dim, head_size, seq_len, n_heads, nsplit;
   int kv_dim, kv_mul;    // floats of a cache row; query heads per cache head (1 unless the context honours n_kv_heads < n_heads)
@@ -54,7 +54,7 @@ struct AttnArgs {
 // the attention output, element i of head h: RunState.xb, and the hand-off granule when a workgroup of this launch waits for it
 __device__ __forceinline__ void attn_out(const AttnArgs& a, size_t idx, float v, unsigned otag) {
   if (a.gout) granule_store(a.gout + idx, v, otag);      // first: a workgroup of this launch waits for it
-  a.xb[idx] = v;
+  a.xb.st(idx, v);
 }
 
 // A wave's wait for its hand-off granules (fused launch): every lane has up to N words to collect; all L1-bypassing loads of a pass
@@ -152,18 +152,18 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   const bool own_pos = FUSED && t1 == T && n > 0;      // this split ends with the row of this position
   const int n_tile = own_pos ? n - 1 : n;               // rows that come through the cache tiles
   const unsigned slab = (unsigned)max(FUSED ? min(t1, pos) : t1, 0) * (unsigned)dim * 4u;
-  const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.kc), 0, slab, 0x00020000);
-  const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.vc), 0, slab, 0x00020000);
+  const auto krs = a.kc.rsrc_bytes(slab);
+  const auto vrs = a.vc.rsrc_bytes(slab);
   const unsigned voff = (unsigned)(((size_t)(t0 + wave * RPT + r) * dim + (size_t)hk * hs + cc4) * 4);
   const unsigned tstride = (unsigned)(NW * RPT) * (unsigned)dim * 4u;                            // bytes between a wave's tiles
   auto issue = [&](f4 (&buf)[NT], bool values, int rd) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      buf[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(values ? vrs : krs, voff, (unsigned)(rd * NT + j) * tstride, 16));      // aux 16 = sc1: cache rows are written by launches of this run (coherence rule, kernels.hip.h)
+      buf[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(values ? vrs : krs, voff, (unsigned)(rd * NT + j) * tstride, L2_SC1_AUX));      // sc1: cache rows are written by launches of this run (coherence rule, kernels.hip.h)
   };
   issue(ra, false, 0);
   f4 q4;
-  if (!FUSED) { const auto qrs = L2_ACT_RSRC(a.q, a.dim); q4 = L2_ACT_LD4(qrs, ((size_t)h * hs + cc4) >> 2); }
+  if (!FUSED) { const auto qrs = a.q.rsrc(a.dim); q4 = L2_ACT_LD4(qrs, ((size_t)h * hs + cc4) >> 2); }
   if (!MULTI || rounds <= 1) issue(rb, true, 0);
   // FUSED: the cache tiles are in flight; now ONE wait for everything of this position the lane will need: its four q values,
   // and -- the wave that scores row pos -- q[i] and k[i], and -- the threads that fold the output -- v[i] (hs <= 64: one each)
@@ -262,10 +262,10 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
     for (int t = tid; t < n; t += NTH) {
       const float pr = (float)((double)(n > NTH ? sc[t] : e_own) * rs);
       sc[t] = pr;
-      if (a.att) a.att[(size_t)h * S + t] = pr;
+      if (a.att) a.att.st((size_t)h * S + t, pr);
     }
   } else if (a.att) {
-    for (int t = tid; t < n; t += NTH) st_sc1(a.att + (size_t)h * S + t0 + t, sc[t]);   // rescaled by the merging workgroup
+    for (int t = tid; t < n; t += NTH) a.att.st_sc1((size_t)h * S + t0 + t, sc[t]);   // rescaled by the merging workgroup
   }
   __syncthreads();
   STAMP(3);
@@ -274,9 +274,9 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
   if (a.exact && NS == 1) {
     // the reference's own rounding points: the accumulator is a Float32Array element, rounded at every timestep, t ascending
     for (int i = tid; i < hs; i += NTH) {
-      const float* vp = a.vc + (size_t)hk * hs + i;
+      const Mut<const float> vp = a.vc + ((size_t)hk * hs + i);
       float o = 0.0f;
-      for (int t = 0; t < n; ++t) o = (float)((double)o + (double)sc[t] * (double)ld_sc1(vp + (size_t)t * dim));
+      for (int t = 0; t < n; ++t) o = (float)((double)o + (double)sc[t] * (double)vp.ld((size_t)t * dim));
       attn_out(a, (size_t)h * hs + i, o, otag);
     }
     return;
@@ -321,7 +321,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       }
       double own = 0.0;
       if (FUSED) { if (own_pos) own = (double)sc[n - 1] * (double)gv; }      // hs <= 64 <= NTH: i == tid
-      if (FUSED) a.xb[(size_t)h * hs + i] = (float)(((c0 + c1) + (c2 + c3)) + own);   // ONE rounding of the fp64 sum
+      if (FUSED) a.xb.st((size_t)h * hs + i, (float)(((c0 + c1) + (c2 + c3)) + own));   // ONE rounding of the fp64 sum
       else attn_out(a, (size_t)h * hs + i, (float)((c0 + c1) + (c2 + c3)), otag);
     }
     STAMP(5);
@@ -331,7 +331,7 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
 
   // ---- split form: publish {acc, l, m}, last arriver of the head merges
   const int rec = attn_rec(hs);
-  double* mypart = a.part + ((size_t)h * NS + sp) * rec;
+  const Mut<double> mypart = a.part + ((size_t)h * NS + sp) * rec;
   for (int i = tid; i < hs; i += NTH) {
     double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
 #pragma unroll
@@ -341,17 +341,17 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
     }
     double own = 0.0;
     if (FUSED) { if (own_pos) own = (double)sc[n - 1] * (double)gv; }
-    if (FUSED) st_sc1(mypart + i, ((c0 + c1) + (c2 + c3)) + own);
-    else st_sc1(mypart + i, (c0 + c1) + (c2 + c3));
+    if (FUSED) mypart.st_sc1(i, ((c0 + c1) + (c2 + c3)) + own);
+    else mypart.st_sc1(i, (c0 + c1) + (c2 + c3));
   }
-  if (tid == 0) { st_sc1(mypart + hs, sum); st_sc1(mypart + hs + 1, (double)mx); }
+  if (tid == 0) { mypart.st_sc1(hs, sum); mypart.st_sc1(hs + 1, (double)mx); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
   __syncthreads();
   if (tid == 0) *ticket = __hip_atomic_fetch_add(a.counter + (size_t)h * CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (*ticket != (unsigned)(NS - 1)) return;
 
-  const double* hp = a.part + (size_t)h * NS * rec;     // sc1 loads: they bypass this CU's L1
+  const Mut<double> hp = a.part + (size_t)h * NS * rec;     // (ld: past this CU's L1)
   if (NS <= 8) {
     // ONE round of loads: every thread requests {m, l} of all splits and its element of every partial at once
     // (three dependent rounds of L1-bypassing loads were 3 us of the merge)
@@ -359,8 +359,8 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
       double mm[8], ll[8], aa[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const double* rp = hp + (size_t)min(k, NS - 1) * rec;
-        mm[k] = ld_sc1(rp + hs + 1); ll[k] = ld_sc1(rp + hs); aa[k] = ld_sc1(rp + i);
+        const Mut<double> rp = hp + (size_t)min(k, NS - 1) * rec;
+        mm[k] = rp.ld(hs + 1); ll[k] = rp.ld(hs); aa[k] = rp.ld(i);
       }
       double M = mm[0];
 #pragma unroll
@@ -375,23 +375,23 @@ __device__ __forceinline__ void attn_tile_body(const AttnArgs& a, char* smem, co
     }
   } else {
     double M = -INFINITY;
-    for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, ld_sc1(hp + (size_t)s2 * rec + hs + 1));
+    for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, hp.ld((size_t)s2 * rec + hs + 1));
     double Lsum = 0.0;
-    for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + hs);
+    for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(hp.ld((size_t)s2 * rec + hs + 1) - M) * hp.ld((size_t)s2 * rec + hs);
     for (int i = tid; i < hs; i += NTH) {
       double num = 0.0;
-      for (int s2 = 0; s2 < NS; ++s2) num += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + i);
+      for (int s2 = 0; s2 < NS; ++s2) num += exp(hp.ld((size_t)s2 * rec + hs + 1) - M) * hp.ld((size_t)s2 * rec + i);
       attn_out(a, (size_t)h * hs + i, (float)(num / Lsum), otag);
     }
   }
   if (a.att) {                                          // probabilities for parity reads of RunState.att (L2_OPT_KEEP_ATT)
     double M = -INFINITY;
-    for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, ld_sc1(hp + (size_t)s2 * rec + hs + 1));
+    for (int s2 = 0; s2 < NS; ++s2) M = fmax(M, hp.ld((size_t)s2 * rec + hs + 1));
     double Lsum = 0.0;
-    for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(ld_sc1(hp + (size_t)s2 * rec + hs + 1) - M) * ld_sc1(hp + (size_t)s2 * rec + hs);
+    for (int s2 = 0; s2 < NS; ++s2) Lsum += exp(hp.ld((size_t)s2 * rec + hs + 1) - M) * hp.ld((size_t)s2 * rec + hs);
     for (int t = tid; t < T; t += NTH) {
-      const double ws = exp(ld_sc1(hp + (size_t)(t / chunk) * rec + hs + 1) - M);
-      a.att[(size_t)h * S + t] = (float)((double)ld_sc1(a.att + (size_t)h * S + t) * ws / Lsum);
+      const double ws = exp(hp.ld((size_t)(t / chunk) * rec + hs + 1) - M);
+      a.att.st((size_t)h * S + t, (float)((double)a.att.ld((size_t)h * S + t) * ws / Lsum));
     }
   }
   if (tid == 0) __hip_atomic_store(a.counter + (size_t)h * CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every split has its ticket: re-arm
@@ -428,9 +428,9 @@ __global__ void __launch_bounds__(512) qkv_attn_small_kernel(const PhaseArgs a, 
   // round, ~1 us before the first weight request -- seen with tools/stamps_fused.py).  An empty asm statement that names the
   // values as scalar inputs makes them due before the branch.
 #define L2_PIN4(x0, x1, x2, x3) asm volatile("" ::"s"(x0), "s"(x1), "s"(x2), "s"(x3))
-  L2_PIN4(a.w0, a.w1, a.w2, a.in); L2_PIN4(a.emb, a.rmsw, a.out, a.out_k); L2_PIN4(a.out_v, a.fr, a.fi, a.tokpos);
-  L2_PIN4(a.n, a.rows, a.dim, a.kv_dim); L2_PIN4(a.head_size, a.gran, a.gran_ep, a.inv_n); asm volatile("" ::"s"(a.gran_hmagic)); asm volatile("" ::"s"(a.aux), "s"(a.aux2));
-  L2_PIN4(at.kc, at.vc, at.att, at.xb); L2_PIN4(at.tokpos, at.part, at.counter, at.dim); L2_PIN4(at.head_size, at.seq_len, at.n_heads, at.nsplit);
+  L2_PIN4(a.w0, a.w1, a.w2, a.in.addr()); L2_PIN4(a.emb, a.rmsw, a.out.addr(), a.out_k.addr()); L2_PIN4(a.out_v.addr(), a.fr, a.fi, a.tokpos);
+  L2_PIN4(a.n, a.rows, a.dim, a.kv_dim); L2_PIN4(a.head_size, a.gran, a.gran_ep, a.inv_n); asm volatile("" ::"s"(a.gran_hmagic)); asm volatile("" ::"s"(a.aux.addr()), "s"(a.aux2.addr()));
+  L2_PIN4(at.kc.addr(), at.vc.addr(), at.att.addr(), at.xb.addr()); L2_PIN4(at.tokpos, at.part.addr(), at.counter, at.dim); L2_PIN4(at.head_size, at.seq_len, at.n_heads, at.nsplit);
   asm volatile("" ::"s"(at.kv_dim), "s"(at.kv_mul)); L2_PIN4(at.inv_sqrt_hs, at.gran, at.gran_ep, at.herr); L2_PIN4(at.wait_ticks, at.exact, nattn, at.dbg);
 #undef L2_PIN4
   const int nq = (int)gridDim.x - nattn;
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // every argument in ONE fetch round, and the position (device memory: one captured graph serves every position) requested right
   // behind it -- left alone, hipcc fetches the arguments in two dependent rounds before it even asks for pos (see qkv_attn_small_kernel)
-  asm volatile("" ::"s"(a.q), "s"(a.kc), "s"(a.vc), "s"(a.att), "s"(a.xb), "s"(a.tokpos), "s"(a.part), "s"(a.counter));
+  asm volatile("" ::"s"(a.q.addr()), "s"(a.kc.addr()), "s"(a.vc.addr()), "s"(a.att.addr()), "s"(a.xb.addr()), "s"(a.tokpos), "s"(a.part.addr()), "s"(a.counter));
   const int pos = a.tokpos[1];
   asm volatile("" ::"s"(a.dim), "s"(a.head_size), "s"(a.seq_len), "s"(a.n_heads), "s"(a.nsplit), "s"(a.kv_dim), "s"(a.kv_mul), "s"(a.inv_sqrt_hs), "s"(a.gout), "s"(a.gout_ep));
   attn_tile_dispatch<LR, NW, NT>(a, smem, blockIdx.x, blockIdx.y, pos);
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(64 * NW) pf_attn_tile_kernel(const AttnArgs a,
   const int p = blockIdx.y;
   b.q = a.q + (size_t)p * a.dim;
   b.xb = a.xb + (size_t)p * a.dim;
-  b.att = nullptr;
+  b.att = Mut<float>(nullptr);
   b.nsplit = 1;
   attn_tile_dispatch<LR, NW, NT>(b, smem, blockIdx.x, 0, pos0 + p);
 }
@@ -500,13 +500,13 @@ __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int 
   float* att = reinterpret_cast<float*>(smem);                    // S floats
   double* red = reinterpret_cast<double*>(att + ((S + 3) & ~3));  // 8 doubles
   const int pos = a.pos_plus1 ? pos0 + (int)blockIdx.y : a.tokpos[1];
-  const float* q = a.q + (a.pos_plus1 ? (size_t)blockIdx.y * dim : 0) + (size_t)h * hs;
-  float* xb = a.xb + (a.pos_plus1 ? (size_t)blockIdx.y * dim : 0) + (size_t)h * hs;
+  const Mut<const float> q = a.q + ((a.pos_plus1 ? (size_t)blockIdx.y * dim : 0) + (size_t)h * hs);
+  const Mut<float> xb = a.xb + ((a.pos_plus1 ? (size_t)blockIdx.y * dim : 0) + (size_t)h * hs);
   const double rsq = sqrt((double)hs);
   for (int t = tid; t <= pos; t += 256) {
-    const float* kp = a.kc + (size_t)t * kvd + (size_t)hk * hs;
+    const Mut<const float> kp = a.kc + ((size_t)t * kvd + (size_t)hk * hs);
     double s = 0.0;
-    for (int i = 0; i < hs; ++i) s += (double)ld_sc1(q + i) * (double)ld_sc1(kp + i);
+    for (int i = 0; i < hs; ++i) s += (double)q.ld(i) * (double)kp.ld(i);
     att[t] = (float)(s / rsq);
   }
   __syncthreads();
@@ -524,19 +524,19 @@ __global__ void __launch_bounds__(256) attn_scalar_kernel(const AttnArgs a, int 
   for (int t = tid; t <= pos; t += 256) {
     const float pr = (float)((double)att[t] / sum);
     att[t] = pr;
-    if (a.att && !a.pos_plus1) a.att[(size_t)h * S + t] = pr;
+    if (a.att && !a.pos_plus1) a.att.st((size_t)h * S + t, pr);
   }
   __syncthreads();
   for (int i = tid; i < hs; i += 256) {
-    const float* vp = a.vc + (size_t)hk * hs + i;
+    const Mut<const float> vp = a.vc + ((size_t)hk * hs + i);
     if (a.exact) {
       float o = 0.0f;
-      for (int t = 0; t <= pos; ++t) o = (float)((double)o + (double)att[t] * (double)ld_sc1(vp + (size_t)t * kvd));
-      xb[i] = o;
+      for (int t = 0; t <= pos; ++t) o = (float)((double)o + (double)att[t] * (double)vp.ld((size_t)t * kvd));
+      xb.st(i, o);
     } else {
       double o = 0.0;
-      for (int t = 0; t <= pos; ++t) o += (double)att[t] * (double)ld_sc1(vp + (size_t)t * kvd);
-      xb[i] = (float)o;
+      for (int t = 0; t <= pos; ++t) o += (double)att[t] * (double)vp.ld((size_t)t * kvd);
+      xb.st(i, (float)o);
     }
   }
 }

@@ -219,6 +219,9 @@ struct l2_ctx {
   int aql_fence = 20;               // acquire scope + 4 * release scope + 16 * (agent acquire on a token's first launch): aql_queue.h, create_impl
   std::string aql_note;             // why the queue is not in use, if it is not
   int opt_exact = 0, opt_graph = 1, opt_keep_state = 0;
+  int opt_pollute = 0;              // L2_DEBUG_POLLUTE=1 (test hook): l1_pollute_kernel behind every launch of the step (kernels.hip.h)
+  float* pollute_sink = nullptr;
+  int opt_pos_check = 0;            // L2_CHECK_POS=1: l2_forward refuses a position that does not continue the sequence (llama2.ts:464, 496)
   int next_pos = 0;
   bool ran_forward = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

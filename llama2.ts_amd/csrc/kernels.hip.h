@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace l2k {
 
@@ -79,19 +80,76 @@ struct Stamps {
 #define STAMP(k) do { } while (0)
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// write-through (sc1) stores / L1-bypassing loads: relaxed agent-scope atomics (split-attention hand-off)
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Diagnostic build ONLY (-DL2_COHERENCE_BREAK, `make coherence_break`: never shipped): every load the coherence rule sends past L1 -- the
+// element loads below, the 16-byte buffer loads of activations (L2_ACT_LD4) and of cache rows (attention.hip.h) -- becomes a PLAIN cached
+// load.  It exists to prove that tests/test_coherence_gpu.py fails when the rule is broken (L2_TEST_COHERENCE_BREAK=1).
+#ifdef L2_COHERENCE_BREAK
+#define L2_SC1_AUX 0
+#else
+#define L2_SC1_AUX 16      // the sc1 bit of a buffer load's cache-policy field
+#endif
+__device__ __forceinline__ double ld_sc1(const double* p) {
+#ifdef L2_COHERENCE_BREAK
+  return *(const volatile double*)p;
+#else
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#endif
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+#ifdef L2_COHERENCE_BREAK
+  return *(const volatile float*)p;
+#else
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#endif
+}
+
+// The coherence rule (stated in full below, "COHERENCE RULE of the decode step's kernels") as a TYPE.  A pointer to bytes that a launch of
+// the run may have written -- activations, cache rows, split-attention partials, probabilities kept for parity reads -- travels in the
+// kernel-argument structs as Mut<T>: it has NO operator* and NO operator[], so a plain (L1-cached) load of such a byte does not compile
+// in a kernel.  What it hands out instead: ld(i) = one element past L1 (a relaxed agent-scope atomic load), rsrc(n) = the buffer
+// descriptor the 16-byte sc1 loads go through (L2_ACT_LD4, the attention tiles), st(i, v) = a PLAIN store (stores stay plain under the
+// rule), st4 = 16 bytes of them, st_sc1(i, v) = a write-through store (hand-offs inside one launch), addr() = the raw address -- for the
+// host, and in device code only to NAME the value in an `asm volatile("" :: "s"(...))` pin (tests/test_abi_cpu.py fails on any other use).
+// Same size and layout as the pointer it replaces (the kernel-argument blocks did not move).
+template <class T>
+struct Mut {
+  T* p;
+  Mut() = default;
+  __host__ __device__ Mut(T* q) : p(q) {}
+  __host__ __device__ explicit operator bool() const { return p != nullptr; }
+  __host__ __device__ Mut operator+(size_t i) const { return Mut(p + i); }
+  __host__ __device__ T* addr() const { return p; }
+  __device__ __forceinline__ auto ld(size_t i = 0) const { return ld_sc1(p + i); }
+  __device__ __forceinline__ void st(size_t i, T v) const { p[i] = v; }
+  __device__ __forceinline__ void st_sc1(size_t i, T v) const { l2k::st_sc1(p + i, v); }
+  __device__ __forceinline__ void st4(size_t i4, f4 v) const { reinterpret_cast<f4*>(p)[i4] = v; }      // 16 bytes, plain (T = float, 16-byte aligned base)
+  // buffer descriptor over `bytes` bytes from here (loads past its end read as zeros)
+  __device__ __forceinline__ auto rsrc_bytes(unsigned bytes) const { return __builtin_amdgcn_make_buffer_rsrc(const_cast<typename std::remove_const<T>::type*>(p), 0, bytes, 0x00020000); }
+  __device__ __forceinline__ auto rsrc(unsigned n_elems) const { return rsrc_bytes(n_elems * (unsigned)sizeof(T)); }
+};
+static_assert(sizeof(Mut<float>) == sizeof(float*), "Mut<T> is the pointer it wraps");
+
 struct PhaseArgs {
   const float* w0;    // QKV: wq[l]   W13: w1[l]   else: the matrix
   const float* w1;    // QKV: wk[l]   W13: w3[l]
   const float* w2;    // QKV: wv[l]
-  const float* in;    // input vector: x (QKV, W13, CLS), xb (WO), hb (W2)
+  Mut<const float> in; // input vector: x (QKV, W13, CLS), xb (WO), hb (W2) -- written by the launch before (Mut: no plain load)
   const float* emb;   // token_embedding_table when the input/residual is the embedding row (layer 0), else null
   const float* rmsw;  // rmsnorm weight (QKV, W13, CLS) or null
-  float* out;         // QKV: q   WO/W2: x   W13: hb   CLS: logits
-  float* out_k;       // QKV: key_cache   + l*S*d
-  float* out_v;       // QKV: value_cache + l*S*d
-  float* aux;         // CLS: final-normed x (llama2.ts:299)  QKV: k  W13: hb2  WO: xb2  W2: xb (parity reads; may be null)
-  float* aux2;        // QKV: v (parity reads; may be null)   CLS: host-mapped pinned logits (zero-copy hand-off) or null
-  const float* res;   // WO/W2: residual source x
+  Mut<float> out;      // QKV: q   WO/W2: x   W13: hb   CLS: logits
+  Mut<float> out_k;    // QKV: key_cache   + l*S*d
+  Mut<float> out_v;    // QKV: value_cache + l*S*d
+  Mut<float> aux;      // CLS: final-normed x (llama2.ts:299)  QKV: k  W13: hb2  WO: xb2  W2: xb (parity reads; may be null)
+  Mut<float> aux2;     // QKV: v (parity reads; may be null)   CLS: host-mapped pinned logits (zero-copy hand-off) or null
+  Mut<const float> res; // WO/W2: residual source x
   const float* fr;    // freq_cis_real
   const float* fi;    // freq_cis_imag
   const int* tokpos;  // {token, pos, step, _}
@@ -323,20 +381,6 @@ __device__ __forceinline__ f4 ldg_nt(const float* p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// write-through (sc1) stores / L1-bypassing loads: relaxed agent-scope atomics (split-attention hand-off)
-__device__ __forceinline__ void st_sc1(double* p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_sc1(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_sc1(float* p, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_sc1(const float* p) {
-  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-// ------------------------------------------------------------------------------------------------
 // COHERENCE RULE of the decode step's kernels.  On the library's own queue (aql_queue.h) the launches of a token carry a RELEASE
 // fence only (the command processor writes the L2s' dirty lines back when a launch ends; the chip then keeps its eight L2s
 // coherent by itself) and NO acquire: nothing invalidates a CU's vector L1 between two launches.  So every VECTOR load of a byte
@@ -347,6 +391,13 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
 // their plain / non-temporal loads.  (Measured on the way, tools/aql/microbench_aql.cpp + profiles/r05/aql_*: write-through stores
 // instead of the release fence cost every launch 0.3 - 0.9 us -- a 4-byte sc1 store is a fabric write of its own; {token, pos} as
 // vector loads queue behind the weight requests of the latency form and delay its epilogue operands.)
+// Round 6, measured: this chip does not NEED the load half of the rule.  With every load below turned into a plain cached one
+// (-DL2_COHERENCE_BREAK) and a kernel behind every launch that fills every CU's L1 with the step's mutable lines (l1_pollute_kernel), the
+// step is still bit-identical (profiles/r06/coherence_adversary.txt); directly: 2.8e9 plain loads of lines the same CUs had pulled two
+// dispatches earlier, no acquire: 0 stale (profiles/r06/l1_across_dispatches.txt) -- on gfx950 / ROCm 7.2 a dispatch does not see
+// vector-L1 lines of an earlier dispatch.  The rule stays: it is what the HSA memory model requires of packets without an acquire fence,
+// it costs nothing (the sc1 form is 1 - 2 % FASTER at the small models, equal at 7B: profiles/r06/plain_vs_sc1_loads_ab.txt), the Mut<T>
+// type below enforces it at compile time and tests/test_coherence_gpu.py would catch a chip or firmware that does carry lines over.
 //
 // a launch counter of the fused launch (it changes from launch to launch): ONE vector load past L1, broadcast through a scalar register
 __device__ __forceinline__ unsigned ld_word(const unsigned* p) {
@@ -355,7 +406,7 @@ __device__ __forceinline__ unsigned ld_word(const unsigned* p) {
 // 16 bytes of an activation vector past L1: a buffer load with the sc1 bit (aux 16), tracked by the compiler's wait counts like any
 // other load; the descriptor ends at the vector's end (elements past it read as zeros)
 #define L2_ACT_RSRC(ptr, n_floats) __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (unsigned)(n_floats) * 4u, 0x00020000)
-#define L2_ACT_LD4(rs, idx4) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(idx4) * 16u, 0, 16))
+#define L2_ACT_LD4(rs, idx4) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(idx4) * 16u, 0, L2_SC1_AUX))
 
 // QKV row groups: all q rows (dim), then k, then v (kv_dim each).
 __device__ __forceinline__ void qkv_group(const PhaseArgs& a, int g, int R, int& m, int& i0) {
@@ -452,7 +503,7 @@ __device__ __forceinline__ EpiPre epi_prefetch(const PhaseArgs& a, int g, int la
   } else if (MODE == MODE_WO || MODE == MODE_W2) {
     if (!a.partial && !a.push) {
       const int i = min(g * R + min(lane, R - 1), a.rows - 1);
-      e.e0 = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : ld_sc1(a.res + i);
+      e.e0 = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : a.res.ld(i);
     }
 
   }
@@ -474,9 +525,9 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         const float s0 = (float)acc[2 * p], s1 = (float)acc[(2 * p + 1) % R];  // matmul store, llama2.ts:201
         if (m == 2) {  // v: straight into the cache row (llama2.ts:240)
           if (a.gran) { unsigned long long* gp = a.gran + a.dim + a.kv_dim + i; granule_store(gp, s0, pre.tag); granule_store(gp + 1, s1, pre.tag); }      // first: a workgroup of this launch waits for them
-          float* vc = a.out_v + (size_t)pos * a.kv_dim;
-          vc[i] = s0; vc[i + 1] = s1;
-          if (a.aux2) { a.aux2[i] = s0; a.aux2[i + 1] = s1; }
+          const Mut<float> vc = a.out_v + (size_t)pos * a.kv_dim;
+          vc.st(i, s0); vc.st(i + 1, s1);
+          if (a.aux2) { a.aux2.st(i, s0); a.aux2.st(i + 1, s1); }
         } else {       // RoPE on the adjacent pair (llama2.ts:224-235)
           double fcr, fci;
           if (PREF) { fcr = pre.e0; fci = pre.e1; }
@@ -484,11 +535,11 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
           const float o0 = (float)((double)s0 * fcr - (double)s1 * fci);
           const float o1 = (float)((double)s0 * fci + (double)s1 * fcr);
           if (a.gran) { unsigned long long* gp = a.gran + (m == 0 ? 0 : a.dim) + i; granule_store(gp, o0, pre.tag); granule_store(gp + 1, o1, pre.tag); }      // first: a workgroup of this launch waits for them
-          if (m == 0) { a.out[i] = o0; a.out[i + 1] = o1; }
+          if (m == 0) { a.out.st(i, o0); a.out.st(i + 1, o1); }
           else {        // k: cache row (llama2.ts:239)
-            float* kc = a.out_k + (size_t)pos * a.kv_dim;
-            kc[i] = o0; kc[i + 1] = o1;
-            if (a.aux) { a.aux[i] = o0; a.aux[i + 1] = o1; }
+            const Mut<float> kc = a.out_k + (size_t)pos * a.kv_dim;
+            kc.st(i, o0); kc.st(i + 1, o1);
+            if (a.aux) { a.aux.st(i, o0); a.aux.st(i + 1, o1); }
           }
         }
       }
@@ -502,8 +553,8 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         const double v = h1;
         const float sl = (float)(v * rcp_fast(1.0 + exp_fast(-v)));       // llama2.ts:285 (store #1)
         const float hv = (float)((double)sl * (double)h3);                  // llama2.ts:289 (store #2)
-        a.out[row0 + p] = hv;
-        if (a.aux) a.aux[row0 + p] = h3;
+        a.out.st(row0 + p, hv);
+        if (a.aux) a.aux.st(row0 + p, h3);
       }
     }
   } else if (MODE == MODE_CLS) {
@@ -512,8 +563,8 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
     for (int r = 0; r < R; ++r) {
       if (lane == r && row0 + r < a.rows) {
         const float lg = (float)acc[r];                                     // llama2.ts:302
-        a.out[row0 + r] = lg;
-        if (a.aux2) a.aux2[row0 + r] = lg;   // straight into the host's RunState.logits (pinned, mapped)
+        a.out.st(row0 + r, lg);
+        if (a.aux2) a.aux2.st(row0 + r, lg);   // straight into the host's RunState.logits (pinned, mapped)
         const unsigned long long key = argmax_key(lg, row0 + r);
         best = key > best ? key : best;
       }
@@ -534,10 +585,10 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
         if (a.partial) {
           a.partial[i] = acc[r];
         } else {
-          const float xr = PREF ? pre.e0 : ((MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : ld_sc1(a.res + i));
+          const float xr = PREF ? pre.e0 : ((MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + i] : a.res.ld(i));
           const float mv = (float)acc[r];   // xb2 (WO) / xb (W2) as the reference stores it
-          a.out[i] = xr + mv;
-          if (a.aux) a.aux[i] = mv;
+          a.out.st(i, xr + mv);
+          if (a.aux) a.aux.st(i, mv);
         }
       }
     }
@@ -664,9 +715,9 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
     if (MODE == MODE_QKV) { token = greedy_token_from_keys(a, lane, step); if (vblock == 0 && tid == 0 && step > 0) a.tok_out[step - 1] = token; }
     if (MODE == MODE_WO) { if (step > 0) token = a.tok_out[step - 1]; if (vblock == 0 && tid < 8) a.amax[(size_t)tid * 16] = 0ull; }
   }
-  const float* src = a.in;
-  if (MODE == MODE_QKV) { if (a.emb) src = a.emb + (size_t)token * n; }
-  const auto srs = L2_ACT_RSRC(src, n);      // (the input vector: past L1 -- the coherence rule above)
+  Mut<const float> src = a.in;      // (the embedding row of layer 0 is immutable, but takes the same way)
+  if (MODE == MODE_QKV) { if (a.emb) src = Mut<const float>(a.emb + (size_t)token * n); }
+  const auto srs = src.rsrc(n);      // (the input vector: past L1 -- the coherence rule above)
   const f4* rw4 = reinterpret_cast<const f4*>(a.rmsw);
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   double ss = 0.0, ss1 = 0.0, ss2 = 0.0, ss3 = 0.0;   // four chains: fp64 FMA latency is not on the path
@@ -718,7 +769,7 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
       o.z = (float)((double)wv.z * (ss * (double)xv.z));
       o.w = (float)((double)wv.w * (ss * (double)xv.w));
       xs4[c] = o;
-      if (MODE == MODE_CLS && vblock == 0 && a.aux) reinterpret_cast<f4*>(a.aux)[c] = o;  // rmsnorm(x, x, ...) in place, llama2.ts:299
+      if (MODE == MODE_CLS && vblock == 0 && a.aux) a.aux.st4(c, o);  // rmsnorm(x, x, ...) in place, llama2.ts:299
     }
   }
   __syncthreads();
@@ -892,20 +943,20 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   // what bounds the big phases) and need {token, pos} only for the epilogue operands, requested after the x barrier
   f4 xr[XV], wr[XV];
   if (wave == 0) {
-    const float* src = a.in;
+    Mut<const float> src = a.in;
     if (MODE == MODE_QKV) {      // only layer 0 waits for the token
       if (a.emb) {
         int tk;
         if (a.tok_out) { const int step = a.tokpos[2]; tk = greedy_token_from_keys(a, lane, step); if (vblock == 0 && lane == 0 && step > 0) a.tok_out[step - 1] = tk; }
         else tk = a.tokpos[0];
-        src = a.emb + (size_t)tk * n;
+        src = Mut<const float>(a.emb + (size_t)tk * n);
       }
     }
     if (GIN) {
       const unsigned gtag_in = __hip_atomic_load(a.gran_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
       granules_gather_f4<XV>(a.gran, n, lane, gtag_in, xr, a.gin_herr, 200000000ull, 1, const_cast<unsigned*>(a.gran_ep) + 1);      // bounded at 2 s; a short nap between sweeps (the wait is a whole attention long)
     } else {
-      const auto srs = L2_ACT_RSRC(src, n);
+      const auto srs = src.rsrc(n);
 #pragma unroll
       for (int u = 0; u < XV; ++u) xr[u] = L2_ACT_LD4(srs, min(u * 64 + lane, n4 - 1));
     }
@@ -939,7 +990,7 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
         o.z = (float)((double)wr[u].z * (ss * (double)xr[u].z));
         o.w = (float)((double)wr[u].w * (ss * (double)xr[u].w));
         xs4[u * 64 + lane] = o;
-        if (MODE == MODE_CLS && vblock == 0 && a.aux && u * 64 + lane < n4) reinterpret_cast<f4*>(a.aux)[u * 64 + lane] = o;   // llama2.ts:299
+        if (MODE == MODE_CLS && vblock == 0 && a.aux && u * 64 + lane < n4) a.aux.st4(u * 64 + lane, o);   // llama2.ts:299
         if (u == 0) STAMP(8);
       }
       STAMP(9);
@@ -1041,20 +1092,20 @@ __global__ void __launch_bounds__(256) phase_kernel_scalar(const PhaseArgs a) {
   const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   const int n = a.n;
   const int token = a.tokpos[0], pos = a.tokpos[1];
-  const float* src = a.in;
-  if ((MODE == MODE_QKV) && a.emb) src = a.emb + (size_t)token * n;
+  Mut<const float> src = a.in;
+  if ((MODE == MODE_QKV) && a.emb) src = Mut<const float>(a.emb + (size_t)token * n);
   if (mode_has_norm<MODE>()) {
     double ss = 0.0;
-    for (int j = tid; j < n; j += nthreads) { const double v = ld_sc1(src + j); ss += v * v; }
+    for (int j = tid; j < n; j += nthreads) { const double v = src.ld(j); ss += v * v; }
     ss = block_sum(ss, red, tid, nthreads);
     ss = rms_scale(ss, a.inv_n);
     for (int j = tid; j < n; j += nthreads) {
-      const float o = (float)((double)a.rmsw[j] * (ss * (double)ld_sc1(src + j)));
+      const float o = (float)((double)a.rmsw[j] * (ss * (double)src.ld(j)));
       xs[j] = o;
-      if (MODE == MODE_CLS && blockIdx.x == 0 && a.aux) a.aux[j] = o;
+      if (MODE == MODE_CLS && blockIdx.x == 0 && a.aux) a.aux.st(j, o);
     }
   } else {
-    for (int j = tid; j < n; j += nthreads) xs[j] = ld_sc1(src + j);
+    for (int j = tid; j < n; j += nthreads) xs[j] = src.ld(j);
   }
   __syncthreads();
   const int rows_per_group = (MODE == MODE_W13) ? R / 2 : R;
@@ -1113,6 +1164,36 @@ __global__ void __launch_bounds__(64) argmax_finish_kernel(unsigned long long* a
     tokens_out[step] = bi;
     tokpos[0] = bi; tokpos[1] = p1 + 1; tokpos[2] = step + 1;
   }
+}
+
+// TEST HOOK (L2_DEBUG_POLLUTE=1 behind L2_TEST_HOOKS; tests/test_coherence_gpu.py): the adversary of the coherence rule.  Launched behind
+// EVERY launch of a recorded step, it makes every CU pull every mutable line of the step -- activations, logits, argmax keys, launch
+// counters, hand-off granules, split-attention partials, {token, pos, step}, the token record and the cache rows of the current and the
+// next position in every layer -- into ITS vector L1 with PLAIN loads.  Nothing invalidates those lines before a later launch of the token
+// rewrites the bytes (on the library's queue no launch but a token's first acquires), so any load of them that does not go past L1 returns
+// what the polluter saw.  With the rule kept, tokens and logits are bit for bit those of a run without the polluter.
+struct PolluteArgs { const float* buf[20]; unsigned bytes[20]; const float* kc; const float* vc; const int* tokpos; float* sink; int nb, L, S, kvd; };
+__global__ void __launch_bounds__(256) l1_pollute_kernel(const PolluteArgs a) {
+  const int tid = threadIdx.x;
+  float acc = 0.0f;
+  auto pull = [&](const float* base, unsigned bytes) {      // one plain dword load per 64-byte half line
+    for (unsigned o = (unsigned)tid * 64u; o < bytes; o += 256u * 64u) {
+      float v;
+      asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(reinterpret_cast<const char*>(base) + o) : "memory");
+      acc += v;
+    }
+  };
+  for (int b = 0; b < a.nb; ++b) pull(a.buf[b], a.bytes[b]);
+  int pos;
+  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(pos) : "v"(a.tokpos + 1) : "memory");
+  pos = pos < 0 ? 0 : (pos >= a.S ? a.S - 1 : pos);
+  const int p1 = pos + 1 < a.S ? pos + 1 : pos;
+  for (int l = 0; l < a.L; ++l) {      // row pos (written by this token's q / k / v launch of layer l) and row pos + 1 (by the next token's)
+    const size_t slab = (size_t)l * a.S * a.kvd;
+    pull(a.kc + slab + (size_t)pos * a.kvd, (unsigned)a.kvd * 4u); pull(a.vc + slab + (size_t)pos * a.kvd, (unsigned)a.kvd * 4u);
+    pull(a.kc + slab + (size_t)p1 * a.kvd, (unsigned)a.kvd * 4u); pull(a.vc + slab + (size_t)p1 * a.kvd, (unsigned)a.kvd * 4u);
+  }
+  if (acc == 1.2345e-38f) a.sink[0] = acc;      // (keeps the loads alive; never true in practice)
 }
 
 // The blocking call (llama2.ts:468) on the library's own queue: {token, pos} of the call come from pinned host memory -- one load over

@@ -91,8 +91,16 @@ static void aql_pack(char* buf, size_t& off, const T& v) {
   memcpy(buf + off, &v, sizeof(T));
   off += sizeof(T);
 }
+static void pollute_behind(const l2_ctx* c, hipStream_t st);
+template <class... KA, class... A>
+static void l2_launch_one(const l2_ctx* c, void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t st, const A&... a);
 template <class... KA, class... A>
 static void l2_launch(const l2_ctx* c, void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t st, const A&... a) {
+  l2_launch_one(c, kernel, grid, block, lds, st, a...);
+  if (c->opt_pollute) pollute_behind(c, st);      // test hook: the coherence rule's adversary behind every launch (kernels.hip.h: l1_pollute_kernel)
+}
+template <class... KA, class... A>
+static void l2_launch_one(const l2_ctx* c, void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t st, const A&... a) {
   static_assert(sizeof...(KA) == sizeof...(A), "argument count");
   if (c->aql_rec) {
     l2_ctx* m = const_cast<l2_ctx*>(c);
@@ -106,6 +114,20 @@ static void l2_launch(const l2_ctx* c, void (*kernel)(KA...), dim3 grid, dim3 bl
     return;
   }
   hipLaunchKernelGGL(kernel, grid, block, lds, st, a...);
+}
+
+static void pollute_behind(const l2_ctx* c, hipStream_t st) {
+  PolluteArgs p;
+  memset(&p, 0, sizeof(p));
+  int nb = 0;
+  auto add = [&](const void* b, size_t bytes) { if (b && bytes && nb < 20) { p.buf[nb] = (const float*)b; p.bytes[nb] = (unsigned)(bytes > 16384 ? 16384 : bytes); ++nb; } };
+  add(c->x, (size_t)c->d * 4); add(c->xn, (size_t)c->d * 4); add(c->xb, (size_t)c->d_loc * 4); add(c->xb2, (size_t)c->d * 4);
+  add(c->hb, (size_t)c->h_loc * 4); add(c->hb2, (size_t)c->h_loc * 4); add(c->q, (size_t)c->d_loc * 4); add(c->k, (size_t)c->kvd_loc * 4); add(c->v, (size_t)c->kvd_loc * 4);
+  add(c->logits_loc, (size_t)c->V_loc * 4); add(c->amax, 8 * 16 * 8); add(c->attn_counter, (size_t)c->H_loc * CTR_STRIDE * 4);
+  add(c->attn_part, (size_t)c->H_loc * 8 * (((size_t)c->hs + 2 + 15) & ~(size_t)15) * 8); add(c->gran, ((size_t)c->d_loc + 2 * (size_t)c->kvd_loc) * 8);
+  add(c->gran_ep, (size_t)c->H_loc * 4 + 16); add(c->tokpos, 16); add(c->d_tokens, (size_t)c->S * 4); add(c->att, (size_t)c->H_loc * c->S * 4);
+  p.nb = nb; p.kc = c->kc; p.vc = c->vc; p.tokpos = c->tokpos; p.sink = c->pollute_sink; p.L = c->L; p.S = c->S; p.kvd = c->kvd_loc;
+  l2_launch_one(c, l1_pollute_kernel, dim3(c->n_cus * 4), dim3(256), 0, st, p);      // four workgroups per CU: every CU gets some
 }
 
 // Launch with optional start / stop events on THE DISPATCH (hipExtLaunchKernelGGL): their elapsed time is the kernel's

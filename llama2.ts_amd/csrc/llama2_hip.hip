@@ -124,6 +124,7 @@ extern "C" void l2_destroy(l2_ctx* c) {
   if (c->h_herr) hipHostFree(c->h_herr);
   for (hipEvent_t e : c->probe) hipEventDestroy(e);
   { float* pb[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_xb, c->pf_hb}; for (float* b : pb) if (b) hipFree(b); if (c->pf_tok) hipFree(c->pf_tok); }
+  if (c->pollute_sink) hipFree(c->pollute_sink);
   if (c->tokpos) hipFree(c->tokpos);
   if (c->d_tokens) hipFree(c->d_tokens);
   if (c->h_tokpos) hipHostFree(c->h_tokpos);
@@ -188,6 +189,8 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->opt_graph = env_int("L2_USE_GRAPH", (G == 1 && !hook_int("L2_TP_FORCE_COMM")) ? 1 : 0);
   c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
   c->opt_aql = env_int("L2_AQL", 1);
+  c->opt_pollute = hook_int("L2_DEBUG_POLLUTE");
+  c->opt_pos_check = env_int("L2_CHECK_POS", 0);
   // fences between the launches of a run on the library's own queue: no acquire, an agent-scope release, and an agent-scope acquire
   // on the first launch of every token (kernels.hip.h: the coherence rule).  L2_AQL_FENCE=<scope> sets both (1 = what a hipGraph
   // node carries); L2_AQL_ACQ / L2_AQL_REL / L2_AQL_TOKACQ one at a time (A/B, development switches)
@@ -268,6 +271,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
     c->opt_fuse_four_waves = dev_int("L2_FUSE_FOUR_WAVES", 1);
     c->fuse_min_rows = dev_int("L2_FUSE_MIN_ROWS", c->d >= 512 ? 128 : 0);
   }
+  if (c->opt_pollute) CK(hipMalloc(&c->pollute_sink, 64));
   CK(hipMalloc(&c->tokpos, 4 * sizeof(int)));
   CK(hipMemsetAsync(c->tokpos, 0, 4 * sizeof(int), c->stream));
   CK(hipMalloc(&c->d_tokens, (size_t)S * sizeof(int)));
@@ -901,9 +905,15 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
   if (!c) return fail(L2_E_ARG, "null context");
   if (pos < 0 || pos >= c->S) return fail(L2_E_ARG, "pos %d outside [0, seq_len=%d)", pos, c->S);
   if (token < 0 || token >= c->V) return fail(L2_E_ARG, "token %d outside [0, vocab_size=%d)", token, c->V);
+  // L2_CHECK_POS=1 (a debugging host): the reference's loop feeds pos = 0, 1, 2, ... (llama2.ts:464, 496) and attention reads whatever rows
+  // 0 .. pos - 1 the cache holds -- a position that neither restarts at 0 nor continues where the last call (or device loop) left off
+  // would read rows no call of this sequence wrote
+  if (c->opt_pos_check && pos != 0 && pos > c->next_pos)
+    return fail(L2_E_STATE, "L2_CHECK_POS: pos %d skips ahead of the sequence (cache rows 0 .. %d have been written)", pos, c->next_pos - 1);
   int rc = ensure_ready(c);
   if (rc) return rc;
   HIPCHK(hipSetDevice(c->device));
+  c->next_pos = pos + 1;
   c->h_tokpos[0] = token; c->h_tokpos[1] = pos; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   const int lvl = split_level(c, pos);
   set_level(c, lvl);
@@ -952,6 +962,7 @@ static int run_greedy(l2_ctx* c, int first_token, int pos0, int steps, bool time
   int rc = ensure_ready(c);
   if (rc) return rc;
   HIPCHK(hipSetDevice(c->device));
+  if (pos0 + steps > c->next_pos || pos0 == 0) c->next_pos = pos0 + steps;      // (L2_CHECK_POS: rows 0 .. pos0 + steps - 1 are written when this returns)
   c->h_tokpos[0] = first_token; c->h_tokpos[1] = pos0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
   HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(c->amax, 0, 8 * 16 * 8, c->stream));   // argmax keys: zero at the start of every run (an aborted sampled step may have left some)

@@ -144,6 +144,9 @@ extern "C" int l2_prefill(l2_ctx* c, const int32_t* tokens, int n_tokens, int po
     return L2_OK;
   }
   HIPCHK(hipSetDevice(c->device));
+  if (c->opt_pos_check && pos0 != 0 && pos0 > c->next_pos)
+    return fail(L2_E_STATE, "L2_CHECK_POS: pos %d skips ahead of the sequence (cache rows 0 .. %d have been written)", pos0, c->next_pos - 1);
+  if (pos0 + n_tokens > c->next_pos || pos0 == 0) c->next_pos = pos0 + n_tokens;
   const int step = pf3_ok(c) ? PF_S * PF_T : PF_T;      // positions per launch sequence: several 64-token chunks where the register-blocked GEMMs apply
   int done = 0;
   while (done < n_tokens) {

@@ -3,6 +3,7 @@ and fails loudly (no CPU fallback) when there is no GPU.  No compute calls here.
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -159,3 +160,38 @@ def test_aql_queue_finds_its_kernels_in_the_library_file(built):
     import ctypes as C
     L = C.CDLL(runtime.LIB_PATH)
     assert L.l2_debug_aql_code_objects() == 3
+
+
+def test_mutable_device_bytes_travel_as_Mut_and_a_plain_load_of_them_does_not_compile(tmp_path):
+    """The coherence rule (csrc/kernels.hip.h) as a type: the kernel-argument fields that point at bytes a launch of the run writes are
+    Mut<T>, Mut<T> has no operator* / operator[] / implicit conversion to a pointer, its raw address is only ever named in the
+    `asm volatile("" :: "s"(...))` argument pins -- and hipcc refuses a kernel that dereferences one."""
+    import re
+    import shutil
+    csrc = os.path.join(ROOT, "llama2.ts_amd", "csrc")
+    k = open(os.path.join(csrc, "kernels.hip.h")).read()
+    at = open(os.path.join(csrc, "attention.hip.h")).read()
+    body = k[k.index("struct Mut {"):k.index("static_assert(sizeof(Mut<float>)")]
+    assert "operator*" not in body and "operator[]" not in body and "operator T*" not in body and "operator const" not in body
+    pa = k[k.index("struct PhaseArgs {"):k.index("static_assert(sizeof(void*) != 8 || sizeof(PhaseArgs)")]
+    for f in ("in", "res", "out", "out_k", "out_v", "aux", "aux2"):
+        assert re.search(r"Mut<(const )?float> %s;" % f, pa), f
+    aa = at[at.index("struct AttnArgs {"):at.index("// the attention output, element i of head h")]
+    for f, t in (("q", "const float"), ("kc", "const float"), ("vc", "const float"), ("att", "float"), ("xb", "float"), ("part", "double")):
+        assert "Mut<%s> %s;" % (t, f) in aa, f
+    for name, text in (("kernels.hip.h", k), ("attention.hip.h", at), ("tp_exchange.hip.h", open(os.path.join(csrc, "tp_exchange.hip.h")).read())):
+        for ln in text.splitlines():
+            if ".addr()" in ln and not ln.lstrip().startswith("//"):
+                assert "asm volatile(\"\"" in ln or "L2_PIN4(" in ln, (name, ln.strip()[:120])
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    src = """#define L2_NO_PLAIN_KERNELS
+#include "%s/kernels.hip.h"
+__global__ void probe(const l2k::PhaseArgs a, float* o) { o[0] = %%s; }
+""" % csrc
+    for expr, ok in (("a.in.ld(0)", True), ("a.in[0]", False), ("*a.in", False), ("a.res[3]", False), ("a.out[1]", False), ("((const float*)a.in)[0]", False)):
+        f = tmp_path / "probe.hip"
+        f.write_text(src % expr)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-std=c++17", "-fsyntax-only", str(f)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert (r.returncode == 0) == ok, (expr, r.stderr.decode()[-600:])

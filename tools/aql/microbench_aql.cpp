@@ -143,6 +143,44 @@ int main(int argc, char** argv) {
     { char lab[96]; snprintf(lab, sizeof lab, "load+store (sc1), acquire none / release agent"); run_chain(kS, grid, 256, 0, 1, true, lab);
       snprintf(lab, sizeof lab, "load+store (sc1), acquire agent / release none"); run_chain(kS, grid, 256, 1, 0, true, lab); }
   }
+  // ---- does a CU's vector L1 carry a line from one dispatch into a later one?  chain: set(v), pull(v), pull(v), set(v + 1), pull(v + 1), ...
+  {
+    const Kern kPull = get_kernel(ex, "k_pull_all"), kSet = get_kernel(ex, "k_set_all"), kSetS = get_kernel(ex, "k_set_all_sc1");
+    const int n = 4096;      // 16 KB: every CU's L1 (32 KB) can hold the whole buffer
+    const int M = 999;       // 333 x {set, pull, pull}
+    for (int variant = 0; variant < 6; ++variant) {
+      const bool sc1_store = variant & 1;
+      const int acq = 0, rel = (variant >> 1) == 0 ? 0 : ((variant >> 1) == 1 ? 1 : 2);      // release none / agent / system; NO acquire
+      if (!sc1_store && rel == 0) continue;      // plain stores without a release never reach the other XCDs' L2s: not what is asked here
+      memset(host, 0, (size_t)n * 4);
+      CK(hsa_memory_copy(a, host, (size_t)n * 4)); CK(hsa_memory_copy(sink, host, 64));
+      for (int i = 0; i < M; ++i) { ka[i].in = a; ka[i].out = a; ka[i].n = n; ka[i].pad = i / 3 + 1; ka[i].sink = sink; }
+      CK(hsa_memory_copy(ka_dev, ka, (size_t)M * sizeof(RotArgs)));
+      hsa_signal_store_relaxed(done, 1);
+      const uint64_t base = hsa_queue_add_write_index_relaxed(q, M);
+      while (base + M - hsa_queue_load_read_index_scacquire(q) > (uint64_t)QSZ) {}
+      for (int i = 0; i < M; ++i) {
+        hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + i) & (QSZ - 1));
+        const bool first = i == 0, last = i == M - 1, is_set = (i % 3) == 0;
+        const Kern& k = is_set ? (sc1_store ? kSetS : kSet) : kPull;
+        const int wgs = is_set ? n / 256 : 1024;      // pull: four workgroups per CU, every one reads everything
+        p->workgroup_size_x = 256; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
+        p->grid_size_x = wgs * 256; p->grid_size_y = 1; p->grid_size_z = 1;
+        p->private_segment_size = k.priv; p->group_segment_size = k.group;
+        p->kernel_object = k.object; p->kernarg_address = &ka_dev[i]; p->reserved2 = 0;
+        p->completion_signal.handle = last ? done.handle : 0;
+        const int A = first ? HSA_FENCE_SCOPE_SYSTEM : acq, R = last ? HSA_FENCE_SCOPE_SYSTEM : rel;
+        const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                (A << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (R << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+        __atomic_store_n((uint32_t*)p, (uint32_t)header | ((uint32_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16), __ATOMIC_RELEASE);
+      }
+      hsa_signal_store_screlease(q->doorbell_signal, base + M - 1);
+      if (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 5000000000ull, HSA_WAIT_STATE_ACTIVE) != 0) { printf("L1 carry-over: TIMEOUT\n"); exit(2); }
+      CK(hsa_memory_copy(host, sink, 64));
+      printf("L1 across dispatches: %s stores, NO acquire, release %-6s: 666 pulls x 1024 workgroups x %d plain loads: %.0f stale\n",
+             sc1_store ? "sc1  " : "plain", sn[rel], n, host[0]);
+    }
+  }
   hsa_queue_destroy(q);
   hsa_shut_down();
   return 0;

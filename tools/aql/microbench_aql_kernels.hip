@@ -46,3 +46,26 @@ extern "C" __global__ void k_rot_sst_pld(const float* in, float* out, int n) {
   const float v = in[j];
   __hip_atomic_store(reinterpret_cast<unsigned*>(out + i), __float_as_uint(v + 1.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// ---- does a CU's vector L1 carry a line from one dispatch into a later one?  (round 6: tests/test_coherence_gpu.py's adversary found no
+// stale read even in a build whose activation loads are plain.)  k_pull_all: EVERY workgroup reads the WHOLE small buffer with plain
+// loads and counts the elements that are not `expect`; k_set_all: one launch rewrites the buffer (plain or sc1 stores).  The chain
+// alternates set(v) / pull(v) / pull(v): a pull that finds the value of the set BEFORE the last one read a line its CU kept from the
+// pull two dispatches earlier.
+extern "C" __global__ void k_pull_all(const float* buf, float* unused, int n, int expect, float* stale_count) {
+  int bad = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(buf + i) : "memory");
+    bad += (v != (float)expect);
+  }
+  if (bad) atomicAdd(stale_count, (float)bad);
+}
+extern "C" __global__ void k_set_all(const float* unused, float* buf, int n, int value, float* sink) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) buf[i] = (float)value;
+}
+extern "C" __global__ void k_set_all_sc1(const float* unused, float* buf, int n, int value, float* sink) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) __hip_atomic_store(reinterpret_cast<unsigned*>(buf + i), __float_as_uint((float)value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
