@@ -1,6 +1,4 @@
 """cpu_baseline of bench.py: the C oracle (one thread, like the single-threaded reference) and its JavaScript restatement under this box's Node, next to the figure the reference itself printed in the build container.  The oracle is imported HERE and nowhere else in the benchmark: it is the thing timed in this leg, never part of the GPU path."""
-import csv
-import glob
 import json
 import os
 import shutil
@@ -9,7 +7,6 @@ import sys
 import tempfile
 import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")

@@ -1,15 +1,8 @@
 """Shared pieces of bench.py: the peak it prices against, child-process environments, the parity check of a timed run."""
-import csv
-import glob
 import json
 import os
-import shutil
-import subprocess
 import sys
-import tempfile
-import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")

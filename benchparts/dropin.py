@@ -1,6 +1,4 @@
 """The drop-in boundary timed: the blocking call per token through ctypes, through the real N-API addon under Node, and under AMD_DIRECT_DISPATCH=0."""
-import csv
-import glob
 import json
 import os
 import shutil

@@ -1,15 +1,12 @@
 """rocprofv3 legs of bench.py: HBM traffic of the dominant kernel (two --pmc passes) and its duration by kernel trace, each over a child of bench.py that is started BEFORE this process touches the GPU."""
 import csv
 import glob
-import json
 import os
 import shutil
 import subprocess
 import sys
 import tempfile
-import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")

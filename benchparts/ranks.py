@@ -237,7 +237,7 @@ def supervise(args, argv):
                 break
             rc = 1
             continue
-        notes.append("%s: %s" % (label, first["why"]))
+        notes.append("%s: rank %d: %s" % (label, first["rank"], first["why"]))
     else:
         rc = 1
     if rank == 0 and not printed:

@@ -1,12 +1,7 @@
 """One configuration on one GPU: the device-resident loop, the drop-in loops, the roofline of the dominant kernel, the shard-step prediction."""
-import csv
-import glob
 import json
 import os
-import shutil
-import subprocess
 import sys
-import tempfile
 import time
 
 import numpy as np
@@ -21,6 +16,19 @@ from llama2_ts_amd import configs, runtime  # noqa: E402
 from .baselines import cpu_baseline  # noqa: E402
 from .common import DOMINANT, HBM_PEAK_GBS, avg_bytes_per_token, dominant_kernel_bytes, parity_block  # noqa: E402
 from .dropin import dropin_direct_dispatch_off, dropin_loop, napi_dropin  # noqa: E402
+
+
+def contract_keys(out, bpt):
+    """`value` times the device-resident loop -- a SURVEY.md 8(f1) extra.  The contract's own call is one blocking transformer() per
+    token with the logits handed to the host (llama2.ts:468 -> 478): through the N-API addon under Node where a checkpoint file can be
+    written, else through ctypes.  Both are in the line already; these keys put the contract's figure next to `value`."""
+    napi = (out.get("napi_dropin_tok_s") or {}).get("value")
+    rate = napi or out.get("dropin_tok_s")
+    if rate:
+        out["contract_tok_s"] = rate
+        out["contract_hbm_frac"] = round(bpt * rate / 1e9 / HBM_PEAK_GBS, 4)
+        out["contract_how"] = ("one blocking l2_forward per token through the N-API addon under Node (host/l2_run.mjs --loop host), logits to the host, first maximum there"
+                               if napi else "one blocking l2_forward per token through ctypes, logits to the host, argmax there (no checkpoint file of this size is written for the N-API run)")
 
 
 def dispatch_note(ctx):
@@ -89,7 +97,7 @@ def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None):
            "algorithmic_bytes_per_token": int(bpt),
            "hbm_gbs_end_to_end": round(bpt * K / wall / 1e9, 2),
            "hbm_frac_end_to_end": round(bpt * K / wall / 1e9 / HBM_PEAK_GBS, 4),
-           "loop": "device-resident (forward + argmax on GPU, %s)" % dispatch_note(ctx),
+           "loop": "device-resident (forward + argmax on GPU, %s) -- `value` times THIS loop (a SURVEY.md 8(f1) extra); the contract's own call is `contract_tok_s`" % dispatch_note(ctx),
            "parity": parity}
     # the same K steps through the blocking drop-in boundary (llama2.ts:468 -> 478: logits to the host every token, argmax there)
     rate, dropin_tokens = dropin_loop(ctx, K)
@@ -97,6 +105,7 @@ def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None):
     out["parity"]["dropin_equal_to_reference_golden"] = parity_block(name, seed, dropin_tokens)["equal_to_reference_golden"]
     out["napi_dropin_tok_s"] = napi_dropin(ctx, name, seed, K)               # ... and through the N-API addon under Node (the contract's binding)
     out["dropin_tok_s_direct_dispatch_off"] = dropin_direct_dispatch_off(name, seed)
+    contract_keys(out, bpt)
     out["roofline"] = roofline_block(ctx, cfg, K, traffic[0], traffic[1], trace_us)
     out["per_kernel"] = per_kernel_block(ctx, cfg)      # back-to-back launches of each GEMV phase: us and GB/s of its matrix bytes
     S = hdr[6]

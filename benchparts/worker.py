@@ -64,8 +64,9 @@ def worker(args):
     stage = args.worker_stage
     rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
     port = os.environ["L2_BENCH_WORKER_PORT"]
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world,
-                            timeout=datetime.timedelta(seconds=dl["create"] + dl["prove"]))
+    # (a store of the workers' own, hosted by rank 0's worker: the launcher's agent store -- TORCHELASTIC_USE_AGENT_STORE -- belongs to the supervisors)
+    store = dist.TCPStore("127.0.0.1", int(port), world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=dl["start"]))
+    dist.init_process_group("gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=dl["create"] + dl["prove"]))
     mark("started")
     if under_profiler():
         os.environ.setdefault("L2_USE_GRAPH", "0")

@@ -42,6 +42,13 @@ def test_bench_json_contract():
     assert pr["steps_checked"] == 32 and pr["equal_to_reference_golden"] is True and pr["dropin_equal_to_reference_golden"] is True
     assert rf["kernel_trace_us"] is None or 0 < rf["kernel_trace_us"] <= rf["avg_launch_us"] * 1.2
     assert "duration_used" in rf
+    # `value` is the device-resident loop (a SURVEY.md 8(f1) extra) and says so; the contract's own call -- one blocking transformer() per
+    # token, logits to the host -- stands next to it: through the N-API addon where Node is here, else through ctypes
+    assert "`value` times THIS loop" in loop and "contract_tok_s" in loop
+    assert 0 < j["contract_tok_s"] <= j["value"] * 1.02 and 0 < j["contract_hbm_frac"] < 1 and "contract_how" in j
+    napi = (j.get("napi_dropin_tok_s") or {}).get("value")
+    assert j["contract_tok_s"] == (napi or j["dropin_tok_s"])
+    assert abs(j["contract_hbm_frac"] - j["algorithmic_bytes_per_token"] * j["contract_tok_s"] / 8e12) < 2e-4
 
 
 def test_bench_exits_nonzero_when_the_timed_tokens_are_not_the_references(tmp_path):
@@ -73,6 +80,10 @@ def test_bench_two_ranks_replicas_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["parallelism"] == "replicas2"
     assert j["value"] > 0
+    # every rank was a CPU-only supervisor with one fresh worker: one stage (a shape that does not shard), proved before it was timed
+    assert [f["stage"] for f in j["tp"]["formation"]] == ["replicas"] and j["tp"]["formation"][0]["ok"] and j["tp"]["ranks"] == 2
+    assert j["tp"]["proved_before_timing"]["same_on_every_rank"] and j["tp"]["proved_before_timing"]["equals_reference_golden"] is True
+    assert j["roofline"]["bound"] == "hbm" and j["roofline"]["frac"] > 0 and "cpu_baseline" in j
 
 
 CO_RESIDENCY = ("never raised its flag", "did not arrive", "failed its self-test", "exchange timed out")
@@ -155,6 +166,12 @@ def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
         assert j["config"]["weights_mib"]["repacked"] > 0     # 7B width: the streaming kernels read their matrices in consumption order
         assert "note" in j and "no RCCL" in j["note"]
         assert j["tp"]["ranks"] == 2 and j["tp"]["sharded"] and j["tp"]["l2_tp_mode"] == [3] and j["tp"]["devices"] == [0, 0]
+        # the stages that failed were given up and the next one started from FRESH worker processes; the line carries the rank's shard roofline
+        f = j["tp"]["formation"]
+        assert [x["stage"] for x in f] == ["p2p", "rccl", "file"] and [x["ok"] for x in f] == [False, False, True]
+        rf = j["roofline"]
+        assert rf["bound"] == "hbm" and rf["bytes_per_launch"] == 4 * (2 * (11008 // 2) * 4096 + 2 * 4096 + 11008 // 2) and 0 < rf["frac"] < 1
+        assert "cpu_baseline" in j
     _retry_once(attempt)
 
 
