@@ -33,16 +33,13 @@ def contract_keys(out, bpt):
 
 def dispatch_note(ctx):
     """How the device-resident loop's launches reached the chip in the run just made (L2_OPT_AQL_QUEUE, include/llama2_hip.h)."""
-    try:
-        if ctx.get_option(runtime.OPT_AQL_QUEUE):
-            return ("a token's launches written as AQL packets on the library's own HSA queue: barrier bit, agent-scope release, "
-                    "no acquire fence between the launches of a token (csrc/aql_queue.h)")
-        why = runtime.lib().l2_last_error().decode("utf8", "replace")
-        if not ctx.get_option(runtime.OPT_USE_GRAPH):
-            return "eager launches (L2_USE_GRAPH=0: the step is not recorded, so neither the library's AQL queue nor a hipGraph replays it)"
-        return "one hipGraph replay per token (%s)" % (why if "AQL" in why else "the library's AQL queue was not taken: L2_AQL=0, or a step with collectives of the runtime's")
-    except Exception as e:      # an older library
-        return "one hipGraph replay per token (%s)" % type(e).__name__
+    if ctx.get_option(runtime.OPT_AQL_QUEUE):
+        return ("a token's launches written as AQL packets on the library's own HSA queue: barrier bit, agent-scope release, "
+                "no acquire fence between the launches of a token (csrc/aql_queue.h)")
+    why = ctx.dispatch_reason()
+    if not ctx.get_option(runtime.OPT_USE_GRAPH):
+        return "eager launches (%s)" % (why or "L2_USE_GRAPH=0: the step is not recorded")
+    return "one hipGraph replay per token (the library's AQL queue is not in use: %s)" % (why or "not taken")
 
 
 def roofline_block(ctx, cfg, K, traffic, traffic_how, trace_us=None):

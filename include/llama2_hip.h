@@ -23,8 +23,9 @@ extern "C" {
 
 /* 3 (round 5): l2_bench_tokens, option keys 5-7, L2_TP_SOLO_ID / l2_tp_mode 5 and the L2_TP_FENCED switch joined the surface after 2 -- a
  * binding built against it refuses an older library at open() (l2_abi_version), not at the first call that is missing.
- * 4 (round 5): option key L2_OPT_AQL_QUEUE */
-#define L2_ABI_VERSION 4
+ * 4 (round 5): option key L2_OPT_AQL_QUEUE
+ * 5 (round 6): option keys L2_OPT_PREFILL_F32_MFMA, L2_OPT_CHECK_POS; l2_dispatch_reason */
+#define L2_ABI_VERSION 5
 
 enum {
   L2_OK = 0,
@@ -82,10 +83,18 @@ enum {
   L2_OPT_SAMPLED_SERIAL = 7,  /* read-only: of those, the tokens whose running sums came within the proven margin of the threshold and were
                                  therefore picked by the reference's loop run as written (csrc/sampler_margin.hip.h); the others by the
                                  margin rule */
-  L2_OPT_AQL_QUEUE = 8        /* 1 (default): l2_decode_greedy submits a token's launches as hand-written AQL packets on a queue of the
-                                 library's own (csrc/aql_queue.h: barrier bit, no cache fences between the launches of a run); 0: a replayed
-                                 hipGraph per token.  Reading it AFTER a greedy run tells what that run used: 1 the queue, 0 hipGraphs
-                                 (switched off, a tensor-parallel context, or the queue could not be had: l2_last_error() then holds the reason) */
+  L2_OPT_AQL_QUEUE = 8,       /* 1 (default): the recorded step of l2_decode_greedy, l2_decode_sample AND of the blocking l2_forward is submitted as
+                                 hand-written AQL packets on a queue of the library's own (csrc/aql_queue.h: barrier bit, agent-scope release, no
+                                 acquire between the launches of a token); 0: a replayed hipGraph per token.  Reading it tells what the context
+                                 uses now: 1 the queue, 0 hipGraphs / eager launches (switched off, L2_USE_GRAPH=0, RCCL collectives in the step,
+                                 a profiler's tool library in the process, or the queue was given up: l2_dispatch_reason() says which) */
+  L2_OPT_PREFILL_F32_MFMA = 9, /* 1: l2_prefill's register-blocked GEMMs accumulate in fp32 on v_mfma_f32_16x16x4_f32 -- a k-ordered fmaf chain per
+                                 element instead of the reference's fp64 accumulate (llama2.ts:196-203): faster prompt ingestion, logits within
+                                 1e-4 on the fixtures, NOT bit-level parity with the reference (measured exactness);
+                                 0 (default): fp64 MFMA, the reference's arithmetic.  Decode is never affected */
+  L2_OPT_CHECK_POS = 10       /* 1 (or L2_CHECK_POS=1 in the environment at creation): l2_forward / l2_prefill refuse (L2_E_STATE) a position that
+                                 neither restarts at 0 nor continues the sequence -- the reference's loop feeds pos = 0, 1, 2, ... (llama2.ts:464,
+                                 496) and attention reads whatever rows 0 .. pos - 1 the cache holds; 0 (default): any position is accepted */
 };
 
 typedef struct l2_ctx l2_ctx;
@@ -139,8 +148,9 @@ int l2_upload(l2_ctx* ctx, int tensor_kind, int layer, const float* host, size_t
  * returns the file bytes consumed.  Equivalent to l2_create + one l2_upload per Float32Array. */
 int l2_load_checkpoint(const char* path, int device, int tp_rank, int tp_size, const void* nccl_id, l2_ctx** out,
                        uint64_t* bytes_read);
-/* The same for a llama2.c "version 1" file (magic "ak42", 256-byte header, norms first, no freq_cis; fp32): detected by
- * its magic and loaded with L2_F_GQA | L2_F_GENERATE_ROPE.  A file without the magic is the v0 layout above. */
+/* (l2_load_checkpoint also reads a llama2.c "version 1" file -- magic "ak42", 256-byte header, norms first, no freq_cis; fp32:
+ * detected by its magic and loaded with L2_F_GQA | L2_F_GENERATE_ROPE.  A file without the magic is the v0 layout above.) */
+
 /* The 7 header ints of a context (what readConfig parsed). */
 int l2_get_header(l2_ctx* ctx, int32_t cfg_out[7]);
 
@@ -153,8 +163,8 @@ int l2_read_tensor(l2_ctx* ctx, int tensor_kind, int layer, size_t offset, float
 /* Replaces transformer(token, pos, p, s, w) (llama2.ts:205-303, call site :468).  Blocking: when it
  * returns, logits_out[0..V) holds state.logits for this position and the device KV cache holds rows
  * 0..pos.  pos must be 0 <= pos < seq_len; token in [0, V).  The reference's loop feeds pos = 0, 1, 2, ... (llama2.ts:464,
- * 496); any pos is accepted here -- attention then reads whatever rows 0..pos-1 the cache holds from earlier calls.
- * logits_out may be NULL (logits stay readable through l2_logits_host / l2_read_state). */
+ * 496); any pos is accepted here -- attention then reads whatever rows 0..pos-1 the cache holds from earlier calls
+ * (L2_OPT_CHECK_POS makes a position that skips ahead an error).  logits_out may be NULL (logits stay readable through l2_logits_host / l2_read_state). */
 int l2_forward(l2_ctx* ctx, int token, int pos, float* logits_out);
 /* Pinned host buffer (V floats) that l2_forward fills; a binding may wrap it as RunState.logits to
  * skip the copy into logits_out. */
@@ -198,6 +208,9 @@ int l2_read_state(l2_ctx* ctx, int which, int layer, float* out, size_t n_floats
 
 int l2_set_option(l2_ctx* ctx, int key, int value);
 int l2_get_option(l2_ctx* ctx, int key, int* value);
+/* Why the library's own queue (L2_OPT_AQL_QUEUE) is not in use on this context, or "" when it is / has not been tried yet.  The text
+ * lives in the context and is valid until the next call on it (l2_last_error is for failures only and is left alone). */
+const char* l2_dispatch_reason(l2_ctx* ctx);
 
 /* Measurement hooks (bench.py): HIP events on the context's own stream. */
 int l2_timer_start(l2_ctx* ctx);

@@ -215,10 +215,11 @@ struct l2_ctx {
   AqlProgram* aql_rec = nullptr;    // non-null while enqueue_* records instead of launching
   bool aql_rec_failed = false;
   bool aql_tried = false;
-  int opt_aql = 1;                  // L2_AQL=0: replayed hipGraphs for the greedy loop (the blocking call and the sampled loop always use them)
+  int opt_aql = 1;                  // L2_AQL=0: replayed hipGraphs instead of the library's own queue (greedy loop, sampled loop and the blocking call alike)
   int aql_fence = 20;               // acquire scope + 4 * release scope + 16 * (agent acquire on a token's first launch): aql_queue.h, create_impl
   std::string aql_note;             // why the queue is not in use, if it is not
   int opt_exact = 0, opt_graph = 1, opt_keep_state = 0;
+  int opt_pf_f32 = 0;               // L2_OPT_PREFILL_F32_MFMA: the register-blocked prompt GEMMs accumulate in fp32 on v_mfma_f32_16x16x4_f32 (opt-in; prefill.hip.h)
   int opt_pollute = 0;              // L2_DEBUG_POLLUTE=1 (test hook): l1_pollute_kernel behind every launch of the step (kernels.hip.h)
   float* pollute_sink = nullptr;
   int opt_pos_check = 0;            // L2_CHECK_POS=1: l2_forward refuses a position that does not continue the sequence (llama2.ts:464, 496)

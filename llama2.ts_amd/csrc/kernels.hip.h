@@ -1204,7 +1204,7 @@ __global__ void __launch_bounds__(64) set_tokpos_kernel(const int* host_tokpos, 
 }
 
 // ... and with the pick folded into the step (greedy_token_from_keys): the run's LAST pick, once per run -- {pos, step} were advanced by
-// the last layer's w2 launch already
+// the classifier launch already
 __global__ void __launch_bounds__(64) argmax_last_kernel(unsigned long long* amax, int* tokpos, int* tokens_out) {
   const int lane = threadIdx.x;
   const int step = tokpos[2];

@@ -1134,6 +1134,8 @@ extern "C" int l2_set_option(l2_ctx* c, int key, int value) {
     case L2_OPT_USE_GRAPH: c->opt_graph = !!value; return L2_OK;
     case L2_OPT_KEEP_STATE: if (c->opt_keep_state != !!value) { c->opt_keep_state = !!value; destroy_graphs(c); } return L2_OK;
     case L2_OPT_AQL_QUEUE: c->opt_aql = !!value; if (value) c->aql_tried = false; return L2_OK;
+    case L2_OPT_PREFILL_F32_MFMA: c->opt_pf_f32 = !!value; return L2_OK;
+    case L2_OPT_CHECK_POS: c->opt_pos_check = !!value; return L2_OK;
     case L2_OPT_PACKED_MIB: case L2_OPT_WEIGHT_MIB: case L2_OPT_SAMPLED_TOKENS: case L2_OPT_SAMPLED_SERIAL:
       return fail(L2_E_ARG, "option %d is read-only", key);
     default: return fail(L2_E_ARG, "unknown option %d", key);
@@ -1146,10 +1148,9 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
     case L2_OPT_EXACT_ATTENTION: *value = c->opt_exact; return L2_OK;
     case L2_OPT_USE_GRAPH: *value = c->opt_graph; return L2_OK;
     case L2_OPT_KEEP_STATE: *value = c->opt_keep_state; return L2_OK;
-    case L2_OPT_AQL_QUEUE:
-      *value = aql_usable(c) ? 1 : 0;
-      if (!*value && !c->aql_note.empty()) fail(L2_OK, "AQL queue not in use: %s", c->aql_note.c_str());
-      return L2_OK;
+    case L2_OPT_AQL_QUEUE: *value = aql_usable(c) ? 1 : 0; return L2_OK;      // (why not: l2_dispatch_reason -- l2_last_error is for failures)
+    case L2_OPT_PREFILL_F32_MFMA: *value = c->opt_pf_f32; return L2_OK;
+    case L2_OPT_CHECK_POS: *value = c->opt_pos_check; return L2_OK;
     case L2_OPT_PACKED_MIB: {
       size_t floats = 0;
       if (c->packed_valid) for (int m = 0; m < 5; ++m) if (c->packed[m].buf) floats += c->packed[m].layer_elems * (size_t)(m == MODE_CLS ? 1 : c->L);
@@ -1172,6 +1173,17 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
     }
     default: return fail(L2_E_ARG, "unknown option %d", key);
   }
+}
+
+extern "C" const char* l2_dispatch_reason(l2_ctx* c) {
+  if (!c || aql_usable(c)) return "";
+  if (c->aql_note.empty()) {
+    if (!c->opt_aql) c->aql_note = "switched off (L2_AQL=0 / L2_OPT_AQL_QUEUE)";
+    else if (!c->opt_graph) c->aql_note = "the step is not recorded (L2_USE_GRAPH=0): eager launches";
+    else if (c->tp_path) c->aql_note = "a tensor-parallel step whose exchanges are not kernels of the library (RCCL collectives, or the loopback test group)";
+    else if (c->profile_sync) c->aql_note = "L2_PROFILE_SYNC=1";
+  }
+  return c->aql_note.c_str();
 }
 
 #include "bench_hooks.hip.h"

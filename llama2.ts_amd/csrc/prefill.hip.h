@@ -98,12 +98,13 @@ __global__ void __launch_bounds__(256) pf_norm_kernel(float* xn, const float* x,
   for (int j = tid + 256 * MAXE; j < dim; j += 256) xn[(size_t)t * dim + j] = (float)((double)w[j] * (ss * (double)xr[j]));
 }
 
-// Epilogue of one 16-row x 16-token tile: the lane holds tokens t = toff + kq + 4r (r = 0..3) of output index i.
-template <int MODE>
-__device__ __forceinline__ void pf_emit(const PfArgs& a, const d4& av, const d4& acc3, int m, int i, int j, int kq, int toff) {
+// Epilogue of one 16-row x 16-token tile: the lane holds four tokens of output index i -- t = toff + kq + 4r (r = 0..3) in the f64 MFMA's
+// result layout, t = toff + 4 kq + r in the f32 MFMA's (F32: the opt-in fp32-accumulate GEMMs, pf_gemm3_kernel<.., true>).
+template <int MODE, bool F32 = false, class V = d4>
+__device__ __forceinline__ void pf_emit(const PfArgs& a, const V& av, const V& acc3, int m, int i, int j, int kq, int toff) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int t = toff + kq + 4 * r;
+    const int t = F32 ? toff + 4 * kq + r : toff + kq + 4 * r;
     const float sv = (float)av[r];                                  // matmul store (llama2.ts:201)
     if (MODE == MODE_QKV) {
       const int pos = a.pos0 + t;
@@ -325,17 +326,51 @@ __device__ __forceinline__ void mfma_group(d4 (&c)[4][4], double x0, double x1, 
                : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
 }
 #undef L2_MF
+// The same k-step on v_mfma_f32_16x16x4_f32 (L2_OPT_PREFILL_F32_MFMA, opt-in): fp32 operands as loaded, fp32 accumulate -- bit for bit a
+// k-ordered fmaf chain per element (MI355X guide), NOT the reference's fp64 accumulate; 32 cycles per instruction against 64, no
+// widening conversions on the vector pipe.  Same A / B operand lanes as the f64 form; results: row = 4 (lane >> 4) + register.
+#define L2_MF "v_mfma_f32_16x16x4_f32 "
+__device__ __forceinline__ void mfma_group(f4 (&c)[1][4], float x0, float x1, float x2, float x3, const float (&w)[1]) {
+  asm volatile("s_nop 1\n\t" L2_MF "%0, %4, %8, %0\n\t" L2_MF "%1, %5, %8, %1\n\t" L2_MF "%2, %6, %8, %2\n\t" L2_MF "%3, %7, %8, %3"
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]));
+}
+__device__ __forceinline__ void mfma_group(f4 (&c)[2][4], float x0, float x1, float x2, float x3, const float (&w)[2]) {
+  asm volatile("s_nop 1\n\t" L2_MF "%0, %8, %12, %0\n\t" L2_MF "%1, %9, %12, %1\n\t" L2_MF "%2, %10, %12, %2\n\t" L2_MF "%3, %11, %12, %3\n\t"
+               L2_MF "%4, %8, %13, %4\n\t" L2_MF "%5, %9, %13, %5\n\t" L2_MF "%6, %10, %13, %6\n\t" L2_MF "%7, %11, %13, %7"
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]), "+a"(c[1][0]), "+a"(c[1][1]), "+a"(c[1][2]), "+a"(c[1][3])
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]), "v"(w[1]));
+}
+__device__ __forceinline__ void mfma_group(f4 (&c)[3][4], float x0, float x1, float x2, float x3, const float (&w)[3]) {
+  asm volatile("s_nop 1\n\t" L2_MF "%0, %12, %16, %0\n\t" L2_MF "%1, %13, %16, %1\n\t" L2_MF "%2, %14, %16, %2\n\t" L2_MF "%3, %15, %16, %3\n\t"
+               L2_MF "%4, %12, %17, %4\n\t" L2_MF "%5, %13, %17, %5\n\t" L2_MF "%6, %14, %17, %6\n\t" L2_MF "%7, %15, %17, %7\n\t"
+               L2_MF "%8, %12, %18, %8\n\t" L2_MF "%9, %13, %18, %9\n\t" L2_MF "%10, %14, %18, %10\n\t" L2_MF "%11, %15, %18, %11"
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]), "+a"(c[1][0]), "+a"(c[1][1]), "+a"(c[1][2]), "+a"(c[1][3]),
+                 "+a"(c[2][0]), "+a"(c[2][1]), "+a"(c[2][2]), "+a"(c[2][3])
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]), "v"(w[1]), "v"(w[2]));
+}
+__device__ __forceinline__ void mfma_group(f4 (&c)[4][4], float x0, float x1, float x2, float x3, const float (&w)[4]) {
+  asm volatile("s_nop 1\n\t" L2_MF "%0, %16, %20, %0\n\t" L2_MF "%1, %17, %20, %1\n\t" L2_MF "%2, %18, %20, %2\n\t" L2_MF "%3, %19, %20, %3\n\t"
+               L2_MF "%4, %16, %21, %4\n\t" L2_MF "%5, %17, %21, %5\n\t" L2_MF "%6, %18, %21, %6\n\t" L2_MF "%7, %19, %21, %7\n\t"
+               L2_MF "%8, %16, %22, %8\n\t" L2_MF "%9, %17, %22, %9\n\t" L2_MF "%10, %18, %22, %10\n\t" L2_MF "%11, %19, %22, %11\n\t"
+               L2_MF "%12, %16, %23, %12\n\t" L2_MF "%13, %17, %23, %13\n\t" L2_MF "%14, %18, %23, %14\n\t" L2_MF "%15, %19, %23, %15"
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]), "+a"(c[1][0]), "+a"(c[1][1]), "+a"(c[1][2]), "+a"(c[1][3]),
+                 "+a"(c[2][0]), "+a"(c[2][1]), "+a"(c[2][2]), "+a"(c[2][3]), "+a"(c[3][0]), "+a"(c[3][1]), "+a"(c[3][2]), "+a"(c[3][3])
+               : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+}
+#undef L2_MF
 // after the last MFMA: its result is read by ordinary vector instructions (v_accvgpr_read) that hipcc pads for its own MFMAs only
-template <int NS>
-__device__ __forceinline__ void mfma_drain(d4 (&c)[NS][4]) {
+template <class V, int NS>
+__device__ __forceinline__ void mfma_drain(V (&c)[NS][4]) {
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_)
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(c[s_][0]), "+a"(c[s_][1]), "+a"(c[s_][2]), "+a"(c[s_][3]));
 }
 
-template <int MODE, int NW, int RT, int TT>
+template <int MODE, int NW, int RT, int TT, bool F32 = false>
 __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   static_assert(TT == 4, "mfma_group is written for four token tiles (a 64-token chunk)");
+  using V = typename std::conditional<F32, f4, d4>::type;      // one result tile per lane: four fp64 (reference arithmetic) or four fp32 (opt-in)
+  using E = typename std::conditional<F32, float, double>::type;
   // blockIdx.y: which 64-token chunk of the launch (up to PF_S): the same weight tile against the next 64 activation rows.  More
   // chunks per launch = more workgroups per launch, which is what lets wo / w2 (256 row tiles) take 2 or 4 row tiles per wave
   // and still fill 256 CUs, and what evens out w1 / w3's 688 tiles (2.7 per CU in one chunk, 10.75 in four).
@@ -351,7 +386,8 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   constexpr bool DUAL = (MODE == MODE_W13);
   constexpr int NS = DUAL ? 2 * RT : RT;             // weight streams of the wave: row tiles (w1 tile r, w3 tile r, ... when DUAL)
   constexpr int UN = 2;                              // 16-column blocks per batch, two batches in flight (4 blocks: occupancy 2 -> 1 for w1 / w3, 215 -> 232 us)
-  extern __shared__ __attribute__((aligned(16))) double part3[];     // [TT][NW][4][64]
+  extern __shared__ __attribute__((aligned(16))) char part3_raw[];
+  E* part3 = reinterpret_cast<E*>(part3_raw);                        // [TT][NW][4][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.n, npair = (n >> 4) / UN;
   const int j = lane & 15, kq = lane >> 4;
@@ -393,9 +429,9 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   const int pk_lastci = (((n >> 2) + 127) >> 7) - 1;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xin), 0, (unsigned)(16 * TT) * (unsigned)n * 4u, 0x00020000);
   const unsigned tstride = 16u * (unsigned)n * 4u;                    // bytes between token tiles
-  d4 acc[NS][TT];
+  V acc[NS][TT];
   {
-    const d4 z = {0.0, 0.0, 0.0, 0.0};
+    const V z = {0, 0, 0, 0};
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_)
 #pragma unroll
@@ -433,14 +469,14 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   auto mma = [&](const Batch& b) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      double wd[NS][4], xd[TT][4];
+      E wd[NS][4], xd[TT][4];      // (fp64: widened here, on the pipe the MFMAs need; fp32: the loaded registers themselves)
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_) { wd[s_][0] = b.wv[u][s_].x; wd[s_][1] = b.wv[u][s_].y; wd[s_][2] = b.wv[u][s_].z; wd[s_][3] = b.wv[u][s_].w; }
 #pragma unroll
       for (int t = 0; t < TT; ++t) { xd[t][0] = b.xv[u][t].x; xd[t][1] = b.xv[u][t].y; xd[t][2] = b.xv[u][t].z; xd[t][3] = b.xv[u][t].w; }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        double wk[NS];
+        E wk[NS];
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) wk[s_] = wd[s_][k];
         mfma_group(acc, xd[0][k], xd[1][k], xd[2][k], xd[3][k], wk);
@@ -455,7 +491,7 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
     load(A, i + 2);
     mma(B);
   }
-  mfma_drain<NS>(acc);
+  mfma_drain<V, NS>(acc);
   // ---- split-K combine, one weight stream at a time: every wave parks its TT partial tiles, wave t (t < TT) adds token tile t
   // over the waves IN WAVE ORDER (the same sum on every run) and finishes it
   auto park = [&](int s_) {
@@ -465,10 +501,10 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
       for (int r = 0; r < 4; ++r) part3[((size_t)(t * NW + wave) * 4 + r) * 64 + lane] = acc[s_][t][r];
   };
   auto gather = [&](int t) {
-    d4 v = {0.0, 0.0, 0.0, 0.0};
+    V v = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      double sacc = part3[((size_t)(t * NW + 0) * 4 + r) * 64 + lane];
+      E sacc = part3[((size_t)(t * NW + 0) * 4 + r) * 64 + lane];
 #pragma unroll
       for (int w = 1; w < NW; ++w) sacc += part3[((size_t)(t * NW + w) * 4 + r) * 64 + lane];
       v[r] = sacc;
@@ -478,7 +514,7 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
   static_assert(NW >= TT, "one finishing wave per token tile");
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
-    d4 first = {0.0, 0.0, 0.0, 0.0}, second = {0.0, 0.0, 0.0, 0.0};
+    V first = {0, 0, 0, 0}, second = {0, 0, 0, 0};
     __syncthreads();                                   // the previous stream's partials have been read
     park(DUAL ? 2 * r : r);
     __syncthreads();
@@ -489,7 +525,7 @@ __global__ void __launch_bounds__(64 * NW) pf_gemm3_kernel(const PfArgs a_in) {
       __syncthreads();
       if (wave < TT) second = gather(wave);
     }
-    if (wave < TT) pf_emit<MODE>(a, first, second, tm[r], ti0[r] + j, j, kq, 16 * wave);
+    if (wave < TT) pf_emit<MODE, F32, V>(a, first, second, tm[r], ti0[r] + j, j, kq, 16 * wave);
   }
 }
 

@@ -25,7 +25,7 @@ TENSOR_NAMES = ["token_embedding_table", "rms_att_weight", "wq", "wk", "wv", "wo
 S_X, S_XB, S_XB2, S_HB, S_HB2, S_Q, S_K, S_V, S_ATT, S_LOGITS, S_KEY_CACHE, S_VALUE_CACHE = range(12)
 STATE_IDS = dict(x=S_X, xb=S_XB, xb2=S_XB2, hb=S_HB, hb2=S_HB2, q=S_Q, k=S_K, v=S_V, att=S_ATT, logits=S_LOGITS,
                  key_cache=S_KEY_CACHE, value_cache=S_VALUE_CACHE)
-OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_KEEP_STATE, OPT_PACKED_MIB, OPT_WEIGHT_MIB, OPT_SAMPLED_TOKENS, OPT_SAMPLED_SERIAL, OPT_AQL_QUEUE = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_EXACT_ATTENTION, OPT_USE_GRAPH, OPT_KEEP_STATE, OPT_PACKED_MIB, OPT_WEIGHT_MIB, OPT_SAMPLED_TOKENS, OPT_SAMPLED_SERIAL, OPT_AQL_QUEUE, OPT_PREFILL_F32_MFMA, OPT_CHECK_POS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 F_GQA, F_GENERATE_ROPE = 1, 2     # l2_create_ex flags
 TP_SOLO_ID = b"L2-SOLO-SHARD-TIMING"   # l2_create_tp id of a shard-timing context (include/llama2_hip.h: L2_TP_SOLO_ID)
 
@@ -33,7 +33,7 @@ TP_SOLO_ID = b"L2-SOLO-SHARD-TIMING"   # l2_create_tp id of a shard-timing conte
 ABI_SYMBOLS = ["l2_abi_version", "l2_device_count", "l2_last_error", "l2_create", "l2_destroy", "l2_tp_unique_id",
                "l2_create_tp", "l2_upload", "l2_synth_fill", "l2_read_tensor", "l2_forward", "l2_logits_host",
                "l2_decode_greedy", "l2_decode_sample", "l2_debug_running_sums", "l2_read_state", "l2_set_option", "l2_get_option", "l2_timer_start",
-               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ", "l2_tp_mode", "l2_create_ex", "l2_bench_tokens"]
+               "l2_timer_stop", "l2_bench_gemv", "l2_bench_decode", "l2_load_checkpoint", "l2_get_header", "l2_prefill", "l2_bench_dominant_in_situ", "l2_tp_mode", "l2_create_ex", "l2_bench_tokens", "l2_dispatch_reason"]
 
 
 class L2Error(RuntimeError):
@@ -86,6 +86,8 @@ def lib():
     L.l2_create_ex.argtypes = [vp, i32, u32, C.POINTER(vp)]
     L.l2_tp_mode.restype = i32
     L.l2_bench_tokens.argtypes = [vp, vp, i32]
+    L.l2_dispatch_reason.argtypes = [vp]
+    L.l2_dispatch_reason.restype = C.c_char_p
     for name in ABI_SYMBOLS:   # fail at load time, not at first use, if the .so is stale
         getattr(L, name)
     _lib = L
@@ -245,6 +247,10 @@ class Context:
         v = C.c_int()
         _check(lib().l2_get_option(self._h, key, C.byref(v)))
         return v.value
+
+    def dispatch_reason(self):
+        """Why the library's own queue is not in use on this context ("" when it is): l2_dispatch_reason."""
+        return lib().l2_dispatch_reason(self._h).decode("utf8", "replace")
 
     # -- measurement
     def timer_start(self):

@@ -27,7 +27,7 @@ def test_header_symbols_exported(built):
     raw = C.CDLL(runtime.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert built.l2_abi_version() == 4
+    assert built.l2_abi_version() == 5
 
 
 def test_header_cites_reference_lines():

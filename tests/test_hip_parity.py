@@ -442,6 +442,35 @@ def test_prefill_at_the_widths_the_bench_times(built, name, n, form, monkeypatch
     b.close()
 
 
+@pytest.mark.parametrize("name,n", [("stories110M", 128), ("stories110M", 256), ("llama2_7b_L2", 64), ("llama2_7b_L2", 128), ("llama2_7b_L2", 256)])
+def test_prefill_fp32_accumulate_is_an_opt_in_within_the_logit_bar(built, name, n):
+    """L2_OPT_PREFILL_F32_MFMA (build both, choose by evidence: SURVEY.md section 7): the register-blocked prompt GEMMs on
+    v_mfma_f32_16x16x4_f32 -- fp32 accumulate, NOT the reference's arithmetic (llama2.ts:196-203 accumulates in a double), so NOT the
+    default.  What it must still do: the reference's logits within 1e-4 at the kept positions, the reference's argmax there, a KV
+    cache within fp32 accumulation error of the default form's -- and leave the default alone (option off: bit for bit the fp64 form)."""
+    meta, g = load_gold(name)
+    keep = {p: i for i, p in enumerate(meta["logit_positions"])}
+    toks = meta["tokens_fed"][:n]
+    a = runtime.Context(meta["header"]); a.synth_fill(meta["seed"])
+    assert a.get_option(runtime.OPT_PREFILL_F32_MFMA) == 0
+    la = np.array(a.prefill(toks, 0), copy=True)
+    b = runtime.Context(meta["header"]); b.synth_fill(meta["seed"])
+    b.set_option(runtime.OPT_PREFILL_F32_MFMA, 1)
+    lb = np.array(b.prefill(toks, 0), copy=True)
+    err = float(np.abs(lb - g["logits"][keep[n - 1]]).max())
+    assert err <= TOL and runtime.argmax(lb) == meta["argmax"][n - 1], (name, n, err)
+    assert not np.array_equal(bits(la), bits(lb)), "the fp32 form produced the fp64 form's bits: the option did nothing"
+    d, S, L = b.cfg.dim, b.cfg.seq_len, b.cfg.n_layers
+    for nm in ("key_cache", "value_cache"):
+        ca = a.read_state(nm).reshape(L, S, d)[:, :n]
+        cb = b.read_state(nm).reshape(L, S, d)[:, :n]
+        assert np.abs(ca - cb).max() <= 2e-5, nm
+    b.set_option(runtime.OPT_PREFILL_F32_MFMA, 0)
+    assert np.array_equal(bits(np.array(b.prefill(toks, 0), copy=True)), bits(la))
+    print("\n[prefill fp32 accumulate %s n=%d] max|dlogit| vs reference %.3g (fp64 form %.3g)" % (name, n, err, float(np.abs(la - g["logits"][keep[n - 1]]).max())))
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("n,first", [(65, 0), (70, 0), (129, 0), (200, 0), (160, 100), (300, 37)])
 def test_prefill_ragged_chunk_counts_at_110m_width(built, n, first):
     """The register-blocked GEMMs take up to four 64-token chunks per launch: prompts that end inside a chunk (65, 70, 129,
