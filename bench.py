@@ -36,14 +36,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 from llama2_ts_amd import configs, runtime  # noqa: E402
 from benchparts import profiler  # noqa: E402
 from benchparts.baselines import cpu_baseline, reference_js_figure  # noqa: E402,F401  (reference_js_figure: tests/test_bench_cpu.py)
 from benchparts.common import HBM_PEAK_GBS, avg_bytes_per_token, parity_block, under_profiler  # noqa: E402
 from benchparts.dropin import dropin_child, dropin_direct_dispatch_off, dropin_loop, napi_dropin  # noqa: E402
-from benchparts.single import contract_keys, dispatch_note, per_kernel_block, roofline_block, secondary_config, tp_prediction  # noqa: E402
+from benchparts.single import contract_keys, dispatch_note, per_kernel_block, prefill_rates, roofline_block, secondary_config, tp_prediction  # noqa: E402
 
 
 def main():
@@ -196,12 +194,7 @@ def main():
             samp[nm] = round(n_s / (time.perf_counter() - t0), 3)
         out["sampled_decode_tok_s"] = samp
         # prompt ingestion (l2_prefill: 64-token chunks on the fp64 MFMA path, up to four chunks per launch) next to the token-by-token loop it replaces
-        for key, n_p in (("prefill_tok_s", min(128, S)), ("prefill_256_tok_s", min(256, S))):
-            ptoks = (np.arange(n_p, dtype=np.int32) * 7919 + 2) % cfg.vocab_size
-            ctx.prefill(ptoks, 0)
-            t0 = time.perf_counter()
-            ctx.prefill(ptoks, 0)
-            out[key] = round(n_p / (time.perf_counter() - t0), 1)
+        out.update(prefill_rates(ctx, cfg, S))
     ctx.close()
 
     if not args.no_extra and args.config.startswith("llama2_7b"):

@@ -108,15 +108,33 @@ def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None):
     S = hdr[6]
     ms = ctx.bench_decode(1, 0, S)
     out["whole_context_tok_s"] = round(S / (ms * 1e-3), 2)
-    for key, n_p in (("prefill_tok_s", min(128, S)), ("prefill_256_tok_s", min(256, S))):     # prompt ingestion, as in the main block
-        ptoks = (np.arange(n_p, dtype=np.int32) * 7919 + 2) % cfg.vocab_size
-        ctx.prefill(ptoks, 0)
-        t0 = time.perf_counter()
-        ctx.prefill(ptoks, 0)
-        out[key] = round(n_p / (time.perf_counter() - t0), 1)
+    out.update(prefill_rates(ctx, cfg, S))     # prompt ingestion, as in the main block
     ctx.close()
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(name, hdr, seed)
+    return out
+
+
+def prefill_rates(ctx, cfg, S):
+    """Prompt ingestion (l2_prefill; llama2.ts:471-473 feeds a prompt one transformer() call per token): 128 and 256 tokens
+    in one call, in the reference's arithmetic (fp64 MFMA: the default) and -- reported beside it, never instead of it -- with the opt-in
+    fp32-accumulate GEMMs (L2_OPT_PREFILL_F32_MFMA; DESIGN.md section 6 has their measured exactness)."""
+    out, f32 = {}, {}
+    for key, n_p in (("prefill_tok_s", min(128, S)), ("prefill_256_tok_s", min(256, S))):
+        ptoks = (np.arange(n_p, dtype=np.int32) * 7919 + 2) % cfg.vocab_size
+        for opt in (0, 1):
+            ctx.set_option(runtime.OPT_PREFILL_F32_MFMA, opt)
+            ctx.prefill(ptoks, 0)
+            t0 = time.perf_counter()
+            ctx.prefill(ptoks, 0)
+            r = round(n_p / (time.perf_counter() - t0), 1)
+            if opt:
+                f32[str(n_p)] = r
+            else:
+                out[key] = r
+        ctx.set_option(runtime.OPT_PREFILL_F32_MFMA, 0)
+    out["prefill_f32_mfma_tok_s"] = dict(f32, what="opt-in (L2_OPT_PREFILL_F32_MFMA): the same GEMMs on v_mfma_f32_16x16x4_f32, fp32 accumulate -- not the reference's arithmetic; "
+                                                     "prefill_tok_s / prefill_256_tok_s are the default fp64 form")
     return out
 
 

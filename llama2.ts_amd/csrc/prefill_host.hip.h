@@ -10,13 +10,11 @@ static bool can_prefill(const l2_ctx* c) {
 // One prefill GEMM.  `tt` = tiles of 16 tokens in the chunk (1, 2 or 4).  (The 16-row-tile kernel's LDS-tile variant -- short chunks over
 // row-major tensors only -- went in round 5: 8 instances, one of them at 256 VGPRs + 134 AGPRs, for chunks of at most 32 tokens.)
 // register-blocked form (prefill.hip.h: pf_gemm3_kernel): RT row tiles per wave, 4 waves split K, `chunks` 64-token chunks per launch
-template <int MODE, int RT>
-static void launch_pf3(const PfArgs& a, int chunks, bool f32, hipStream_t st) {
+template <int MODE, int RT, bool F32 = false>
+static void launch_pf3(const PfArgs& a, int chunks, hipStream_t st) {
   constexpr int NW = 4;
-  const size_t lds = (size_t)4 * NW * 4 * 64 * 8;
-  // f32: L2_OPT_PREFILL_F32_MFMA -- the same blocking on v_mfma_f32_16x16x4_f32 (fp32 accumulate: NOT the reference's arithmetic; opt-in)
-  if (f32) hipLaunchKernelGGL((pf_gemm3_kernel<MODE, NW, RT, 4, true>), dim3(a.rows / (16 * RT), chunks), dim3(64 * NW), lds / 2, st, a);
-  else hipLaunchKernelGGL((pf_gemm3_kernel<MODE, NW, RT, 4>), dim3(a.rows / (16 * RT), chunks), dim3(64 * NW), lds, st, a);
+  const size_t lds = (size_t)4 * NW * 4 * 64 * (F32 ? 4 : 8);
+  hipLaunchKernelGGL((pf_gemm3_kernel<MODE, NW, RT, 4, F32>), dim3(a.rows / (16 * RT), chunks), dim3(64 * NW), lds, st, a);
 }
 
 // Shapes the register-blocked GEMMs cover: whole batches of two 16-column blocks (n % 32) of both input widths (qkv's 3 d / 16 row
@@ -25,16 +23,32 @@ static bool pf3_ok(const l2_ctx* c) { return c->pf3 && c->d % 32 == 0 && c->h % 
 
 template <int MODE>
 static void launch_pf_gemm(const l2_ctx* c, const PfArgs& a, int nw, int tt, int chunks, hipStream_t st) {
+  if (pf3_ok(c) && tt == 4 && c->opt_pf_f32) {
+    // L2_OPT_PREFILL_F32_MFMA (opt-in): the same blocking on v_mfma_f32_16x16x4_f32 -- fp32 accumulate, NOT the reference's arithmetic.  A
+    // result tile is four registers, not eight, and an MFMA takes 32 cycles, not 64: with the fp64 form's row tiles per wave the operand
+    // fragments (re-read from L2 by every wave) would need ~24 B / clock / CU, so with FOUR chunks in the launch (enough workgroups either
+    // way) a wave takes more row tiles: q / k / v four, w1 / w3 two pairs (7B, 256 tokens: 6 510 -> 6 940 tok/s); with fewer chunks the
+    // fp64 form's counts (more tiles per wave at 128 tokens left CUs idle: 5 520 -> 4 910)
+    const int tiles = a.rows / 16;
+    if constexpr (MODE == MODE_QKV) { if (chunks == 4 && tiles % 4 == 0) launch_pf3<MODE, 4, true>(a, chunks, st); else launch_pf3<MODE, 3, true>(a, chunks, st); return; }
+    else if constexpr (MODE == MODE_W13) { if (chunks == 4 && tiles % 2 == 0) launch_pf3<MODE, 2, true>(a, chunks, st); else launch_pf3<MODE, 1, true>(a, chunks, st); return; }
+    else {
+      if (chunks == 4 && tiles % 4 == 0) launch_pf3<MODE, 4, true>(a, chunks, st);
+      else if (chunks == 2 && tiles % 2 == 0) launch_pf3<MODE, 2, true>(a, chunks, st);
+      else launch_pf3<MODE, 1, true>(a, chunks, st);
+      return;
+    }
+  }
   if (pf3_ok(c) && tt == 4) {
     // row tiles per wave: conversions per MFMA are 16 (R + 64) / (64 R) for R rows per workgroup, so as many as still leave >= 256
     // workgroups: qkv 3 (3 d / 16 tiles), w1 / w3 one pair (688 pairs at 7B), wo / w2 (d / 16 tiles) 1, 2 or 4 with the chunk count
-    if constexpr (MODE == MODE_QKV) { launch_pf3<MODE, 3>(a, chunks, c->opt_pf_f32 != 0, st); return; }
-    else if constexpr (MODE == MODE_W13) { launch_pf3<MODE, 1>(a, chunks, c->opt_pf_f32 != 0, st); return; }
+    if constexpr (MODE == MODE_QKV) { launch_pf3<MODE, 3>(a, chunks, st); return; }
+    else if constexpr (MODE == MODE_W13) { launch_pf3<MODE, 1>(a, chunks, st); return; }
     else {
       const int tiles = a.rows / 16;
-      if (chunks == 4 && tiles % 4 == 0) launch_pf3<MODE, 4>(a, chunks, c->opt_pf_f32 != 0, st);
-      else if (chunks == 2 && tiles % 2 == 0) launch_pf3<MODE, 2>(a, chunks, c->opt_pf_f32 != 0, st);
-      else launch_pf3<MODE, 1>(a, chunks, c->opt_pf_f32 != 0, st);
+      if (chunks == 4 && tiles % 4 == 0) launch_pf3<MODE, 4>(a, chunks, st);
+      else if (chunks == 2 && tiles % 2 == 0) launch_pf3<MODE, 2>(a, chunks, st);
+      else launch_pf3<MODE, 1>(a, chunks, st);
       return;
     }
   }

@@ -23,6 +23,7 @@ for cfg in llama2_7b stories110M stories15M; do
 done
 # the decode path's MFMA counters (north_star: "evidenced by rocprof HBM GB/s and MFMA utilisation"): one counter per pass
 for cfg in llama2_7b stories110M; do python3 tools/decode_mfma_pmc.py $cfg $out/decode_mfma_pmc_$cfg.json > $out/decode_mfma_pmc_$cfg.txt 2>&1; done
+python tools/prefill_f32_eval.py > $out/prefill_f32_eval.txt 2>&1; cp gpurun_out/r06/prefill_f32_eval.json $out/ 2>/dev/null
 python tools/prefill_bench.py llama2_7b > $out/prefill_bench_llama2_7b.txt 2>&1
 python tools/prefill_bench.py stories110M > $out/prefill_bench_stories110M.txt 2>&1
 for c in stories110M stories15M llama2_7b_L2; do python tools/sampler_bench.py $c; done > $out/sampler_bench_run.txt 2>&1
