@@ -151,6 +151,8 @@ struct l2_ctx {
   unsigned* awo_ep = nullptr;               // its launch counter (advanced by the combine launch that follows)
   int opt_awo = 1;                          // L2_TP_ATTN_WO=0: attention and wo as two launches (A/B, development switch)
   TpPush* tp_push = nullptr;         // device table of the peers' granule inboxes for the GEMV epilogues (kernels.hip.h: tp_push_row)
+  int opt_fused_combine = 1;         // L2_TP_FUSED_COMBINE=0: the combine launch behind wo / w2 (round-5 form; A/B, development switch)
+  bool tp_fused = false;             // the pushing GEMVs' own waves combine (tp_exchange.hip.h: p2p_publish_table)
   int opt_push = 1;                  // L2_TP_PUSH=0: partials through c->partial and the flag exchange (round-4 form; A/B, development switch)
   bool rccl_graph = false;           // the RCCL collectives of the step are captured into the per-token hipGraph (cleared if capture is refused)
   unsigned long long p2p_wait_ticks = 3000000000ull;   // L2_TP_WAIT_S (default 30 s) on the 100 MHz clock
@@ -266,14 +268,15 @@ static void mark_dirty(l2_ctx* c, int kind, int layer) {
 // full tensor (row0/col0) so l2_upload can cut it out of the caller's full array.
 struct Slice { size_t rows, cols, full_rows, full_cols, row0, col0; };
 
-static Slice tensor_slice(const l2_ctx* c, int kind) {
-  const size_t d = c->d, h = c->h, V = c->V, S = c->S, hs2 = c->hs / 2;
-  const size_t dl = c->d_loc, hl = c->h_loc, Vl = c->V_loc, r = c->rank;
+// (pure: the shape, the rank and the group size are all it needs -- l2_debug_tensor_slice below hands it to a CPU test, which holds it
+//  against llama2_ts_amd/tp.py and, through that, against the numpy restatement tests/test_tp_gloo.py runs over gloo)
+static Slice tensor_slice_pure(size_t d, size_t h, size_t V, size_t S, size_t hs, size_t kvd, size_t G, size_t r, int kind) {
+  const size_t hs2 = hs / 2, dl = d / G, hl = h / G, Vl = V / G, kvl = kvd / G;
   switch (kind) {
     case L2_T_TOKEN_EMBEDDING: return {V, d, V, d, 0, 0};
     case L2_T_RMS_ATT: case L2_T_RMS_FFN: case L2_T_RMS_FINAL: return {1, d, 1, d, 0, 0};
     case L2_T_WQ: return {dl, d, d, d, r * dl, 0};  // whole heads
-    case L2_T_WK: case L2_T_WV: return {(size_t)c->kvd_loc, d, (size_t)c->kvd, d, r * (size_t)c->kvd_loc, 0};
+    case L2_T_WK: case L2_T_WV: return {kvl, d, kvd, d, r * kvl, 0};
     case L2_T_WO: return {d, dl, d, d, 0, r * dl};                                 // columns, repacked
     case L2_T_W1: case L2_T_W3: return {hl, d, h, d, r * hl, 0};
     case L2_T_W2: return {d, hl, d, h, 0, r * hl};
@@ -281,6 +284,17 @@ static Slice tensor_slice(const l2_ctx* c, int kind) {
     case L2_T_WCLS: return {Vl, d, V, d, r * Vl, 0};
     default: return {0, 0, 0, 0, 0, 0};
   }
+}
+static Slice tensor_slice(const l2_ctx* c, int kind) {
+  return tensor_slice_pure((size_t)c->d, (size_t)c->h, (size_t)c->V, (size_t)c->S, (size_t)c->hs, (size_t)c->kvd, (size_t)c->G, (size_t)c->rank, kind);
+}
+// (tests, no GPU needed) rank `rank` of `G`'s slice of one layer of tensor `kind` for the header `cfg`: out = {rows, cols, full_rows, full_cols, row0, col0}
+extern "C" int l2_debug_tensor_slice(const int32_t cfg[7], int honour_kv_heads, int kind, int rank, int G, long long out[6]) {
+  if (!cfg || !out || G < 1 || rank < 0 || rank >= G || kind < 0 || kind >= L2_T_COUNT || cfg[3] <= 0) return L2_E_ARG;
+  const size_t d = (size_t)cfg[0], H = (size_t)cfg[3], hs = d / H, kvd = honour_kv_heads ? (size_t)cfg[4] * hs : d;
+  const Slice s_ = tensor_slice_pure(d, (size_t)cfg[1], (size_t)abs(cfg[5]), (size_t)cfg[6], hs, kvd, (size_t)G, (size_t)rank, kind);
+  out[0] = (long long)s_.rows; out[1] = (long long)s_.cols; out[2] = (long long)s_.full_rows; out[3] = (long long)s_.full_cols; out[4] = (long long)s_.row0; out[5] = (long long)s_.col0;
+  return L2_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

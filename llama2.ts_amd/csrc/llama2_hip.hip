@@ -199,6 +199,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->p2p_fenced = env_int("L2_TP_FENCED", 0) ? 1 : 0;
   c->opt_push = dev_int("L2_TP_PUSH", 1) && !c->p2p_fenced;      // (the fenced form is the flag exchange)
   c->opt_awo = dev_int("L2_TP_ATTN_WO", 1);
+  c->opt_fused_combine = dev_int("L2_TP_FUSED_COMBINE", 1);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
@@ -460,6 +461,7 @@ static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs +
   if (c->opt_keep_state) { a.aux = c->k; a.aux2 = c->v; }     // RunState.k / v: the cache rows are what attention reads
   a.n = c->d; a.rows = c->d_loc + 2 * c->kvd_loc; a.dim = c->d_loc; a.kv_dim = c->kvd_loc;
   a.wp = packed_of(c, MODE_QKV, l);
+  if (l > 0 && p2p_fused(c)) a.push = c->tp_push;      // (behind the layer before's w2, whose waves combined themselves: advance the exchange's counters)
   return a;
 }
 static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (llama2.ts:270-273)
@@ -480,6 +482,7 @@ static PhaseArgs w13_args(const l2_ctx* c, int l) {   // rmsnorm + w1,w3 GEMVs +
   a.out = c->hb; a.aux = c->opt_keep_state ? c->hb2 : nullptr;
   a.n = c->d; a.rows = c->h_loc;
   a.wp = packed_of(c, MODE_W13, l);
+  if (p2p_fused(c)) a.push = c->tp_push;               // (behind wo: advance the exchange's counters and the attention + wo launch's)
   return a;
 }
 static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (llama2.ts:292-295)
@@ -499,6 +502,7 @@ static PhaseArgs cls_args(const l2_ctx* c, bool to_host) {   // final rmsnorm + 
   a.aux2 = (to_host && c->opt_zero_copy && !c->tp_path) ? c->h_logits_dev : nullptr;
   a.n = c->d; a.rows = c->V_loc;
   a.wp = packed_of(c, MODE_CLS, 0);
+  if (p2p_fused(c)) a.push = c->tp_push;               // (behind the last layer's w2)
   return a;
 }
 
@@ -929,16 +933,21 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
     return L2_OK;
   }
   set_level(c, lvl);
-  // {token,pos} in and logits out travel as plain stream copies around the replayed kernel graph
-  // (memcpy nodes inside a captured graph crash rocprofv3's kernel trace on ROCm 7.2)
-  HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  // Replayed hipGraph (or eager launches): {token, pos} of the call are fetched from pinned host memory by the step's FIRST kernel
+  // (set_tokpos_kernel, as on the library's queue) -- not by a stream copy in front of the graph launch.  Round 5 saw the blocking call hand
+  // back another step's logits under AMD_DIRECT_DISPATCH=0 (the runtime submits from a thread of its own): a graph launch there is not
+  // reliably ordered behind a copy enqueued on the same stream just before it; with the fetch INSIDE the graph there is nothing in front of
+  // it to be ordered against (tests/test_aql_gpu.py runs the L2_AQL=0 call under that setting).  Logits come back through the host-mapped
+  // buffer the classifier writes; only contexts without it (tensor parallel, L2_ZERO_COPY_LOGITS=0) copy them behind the graph.
+  int (*enq)(l2_ctx*, hipStream_t) = c->tp_path ? enqueue_forward_host : enqueue_forward_call;
+  if (c->tp_path) HIPCHK(hipMemcpyAsync(c->tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));      // (its step may hold RCCL collectives: kept as it was)
   if (c->opt_graph) {
-    if (!c->g_step[lvl]) { rc = capture(c, enqueue_forward_host, &c->g_step[lvl]); if (rc && rc != L2_RUN_EAGER) return rc; }
+    if (!c->g_step[lvl]) { rc = capture(c, enq, &c->g_step[lvl]); if (rc && rc != L2_RUN_EAGER) return rc; }
   }
   if (c->opt_graph) {
     HIPCHK(hipGraphLaunch(c->g_step[lvl], c->stream));
   } else {
-    rc = enqueue_forward_host(c, c->stream);
+    rc = enq(c, c->stream);
     if (rc) return rc;
   }
   if (!(c->opt_zero_copy && !c->tp_path))

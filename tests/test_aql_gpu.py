@@ -132,3 +132,35 @@ def test_sampled_loop_on_the_queue_equals_graph_replay(name):
     assert q.get_option(runtime.OPT_AQL_QUEUE) == 1 and g.get_option(runtime.OPT_AQL_QUEUE) == 0
     assert q.decode_greedy(1, 0, 50).tolist() == g.decode_greedy(1, 0, 50).tolist()      # (the greedy program beside the sampled ones)
     q.close(); g.close()
+
+
+@pytest.mark.parametrize("zero_copy", ["1", "0"])
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_blocking_call_without_the_queue_under_direct_dispatch_off(tmp_path, graph, zero_copy):
+    """Wherever the library's queue stands down (a profiler's tool library, L2_AQL=0, a tensor-parallel step with RCCL collectives) the
+    blocking call (llama2.ts:468) runs as a replayed hipGraph or eager launches -- also under AMD_DIRECT_DISPATCH=0, a legitimate runtime
+    setting under which round 5 saw it hand back another step's logits from the second token on (a stream copy of {token, pos} in front
+    of the graph launch).  {token, pos} are now fetched inside the step: every token of the 256-step golden, in a fresh process started
+    with that setting, with and without the host-mapped logits."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "call.py"
+    script.write_text('''
+import json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from llama2_ts_amd import configs, runtime
+gold = json.load(open(os.path.join(%r, "tests", "golden", "stories15M.json")))["argmax"]
+ctx = runtime.Context(configs.header("stories15M")); ctx.synth_fill(configs.DEFAULT_SEED)
+tok, out = 1, []
+for pos in range(256):
+    tok = runtime.argmax(ctx.forward(tok, pos, view=True)); out.append(tok)
+assert ctx.get_option(runtime.OPT_AQL_QUEUE) == 0, "the queue was in use: this run did not test the graph path"
+bad = [i for i, (a, b) in enumerate(zip(out, gold)) if a != b]
+print("first mismatch:", bad[:1], "dispatch:", ctx.dispatch_reason())
+sys.exit(1 if bad else 0)
+''' % (root, root))
+    env = dict(os.environ, AMD_DIRECT_DISPATCH="0", L2_AQL="0", L2_USE_GRAPH=graph, L2_ZERO_COPY_LOGITS=zero_copy)
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-1500:]

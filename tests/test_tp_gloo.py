@@ -119,3 +119,33 @@ def test_tp2_over_gloo_matches_single_rank_oracle(name):
     orc = O.Oracle(hdr, meta["seed"])                 # and the oracle's own TP restatement agrees
     for pos, tok in enumerate(tokens):
         assert np.abs(orc.forward_tp(tok, pos, 2) - got[pos]).max() <= 1e-5
+
+
+def test_the_librarys_shard_slices_are_the_plan_the_gloo_run_uses():
+    """tests above run a numpy restatement of the partition (llama2_ts_amd/tp.py: tensor_slice) over gloo; the LIBRARY cuts its shards with
+    tensor_slice() of csrc/ctx.hip.h.  The two must be the same function: every tensor kind, every rank of 2 / 4 / 8 groups of the shapes
+    that shard (Llama-2-7B, its 2-layer twin, tiny, stories15M at 2), through the library's pure debug hook -- no GPU needed."""
+    import ctypes as C
+    import __graft_entry__ as graft
+    from llama2_ts_amd import configs, runtime, tp
+    graft.build()
+    L = runtime.lib()
+    L.l2_debug_tensor_slice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    checked = 0
+    for name, Gs in (("llama2_7b", (2, 4, 8)), ("llama2_7b_L2", (2, 4, 8)), ("tiny", (2, 4)), ("stories15M", (2,))):
+        hdr = configs.header(name)
+        for G in Gs:
+            assert tp.shards(hdr, G)
+            for rank in range(G):
+                for kind in range(14):
+                    out = (C.c_longlong * 6)()
+                    assert L.l2_debug_tensor_slice((C.c_int32 * 7)(*hdr), 0, kind, rank, G, out) == 0
+                    rows, cols, r0, c0 = tp.tensor_slice(hdr, kind, rank, G)
+                    assert (out[0], out[1], out[4], out[5]) == (rows, cols, r0, c0), (name, G, rank, kind, list(out))
+                    checked += 1
+    assert checked == (3 + 3 + 2 + 1) * 0 + sum(G * 14 for Gs in ((2, 4, 8), (2, 4, 8), (2, 4), (2,)) for G in Gs)
+    # the column-sharded matrices cover the full width exactly once across the ranks
+    hdr = configs.header("llama2_7b")
+    for kind, full in ((5, hdr[0]), (8, hdr[1])):
+        spans = sorted((tp.tensor_slice(hdr, kind, r, 8)[3], tp.tensor_slice(hdr, kind, r, 8)[1]) for r in range(8))
+        assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] == full
