@@ -151,7 +151,7 @@ struct l2_ctx {
   unsigned* awo_ep = nullptr;               // its launch counter (advanced by the combine launch that follows)
   int opt_awo = 1;                          // L2_TP_ATTN_WO=0: attention and wo as two launches (A/B, development switch)
   TpPush* tp_push = nullptr;         // device table of the peers' granule inboxes for the GEMV epilogues (kernels.hip.h: tp_push_row)
-  int opt_fused_combine = 1;         // L2_TP_FUSED_COMBINE=0: the combine launch behind wo / w2 (round-5 form; A/B, development switch)
+  int opt_fused_combine = 0;         // L2_TP_FUSED_COMBINE=1: the pushing GEMV's own waves finish the all-reduce instead of a combine launch (development switch: create_impl says why it is off)
   bool tp_fused = false;             // the pushing GEMVs' own waves combine (tp_exchange.hip.h: p2p_publish_table)
   int opt_push = 1;                  // L2_TP_PUSH=0: partials through c->partial and the flag exchange (round-4 form; A/B, development switch)
   bool rccl_graph = false;           // the RCCL collectives of the step are captured into the per-token hipGraph (cleared if capture is refused)

@@ -199,7 +199,11 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->p2p_fenced = env_int("L2_TP_FENCED", 0) ? 1 : 0;
   c->opt_push = dev_int("L2_TP_PUSH", 1) && !c->p2p_fenced;      // (the fenced form is the flag exchange)
   c->opt_awo = dev_int("L2_TP_ATTN_WO", 1);
-  c->opt_fused_combine = dev_int("L2_TP_FUSED_COMBINE", 1);
+  // (0 = the combine launch behind wo / w2.  The fused form is built and measured -- a rank's shard step alone 1.186 -> 1.164 ms at 8 ranks,
+  // 1.672 -> 1.629 at 4, 2.624 -> 2.565 at 2: profiles/r06/tp_fused_combine_ab.txt -- and NOT the default: two ranks as processes on ONE
+  // GPU, the only multi-process group a development box can form, deadlock in it until the bounded wait gives up (each process's pushing
+  // launch fills the chip with waiting waves and keeps the other's off it), so the form could not be verified between processes at all)
+  c->opt_fused_combine = dev_int("L2_TP_FUSED_COMBINE", 0);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)

@@ -22,9 +22,14 @@ def digest(label, lines):
     j = json.loads(js[-1])
     tp = j.get("tp") or {}
     out.append("   %s  n_gpus %s  parallelism %s  value %.2f %s  ms_per_step %.4f" % (
-        (j.get("config") or {}).get("workload", "?").split(" batch-1")[0], j.get("n_gpus"), (j.get("config") or {}).get("parallelism"), j.get("value", 0.0), j.get("unit"), j.get("ms_per_step", 0.0)))
+        (j.get("config") or {}).get("workload", "?").split(" batch-1")[0], j.get("n_gpus"), (j.get("config") or {}).get("parallelism"), j.get("value") or 0.0, j.get("unit"), j.get("ms_per_step") or 0.0))
     modes = tp.get("l2_tp_mode")
     out.append("   tp.l2_tp_mode %s (%s)  devices %s  sharded %s" % (modes, "; ".join(MODES.get(m, "?") for m in (modes or [])), tp.get("devices"), tp.get("sharded")))
+    for f in tp.get("formation") or []:      # round 6: every way of forming the group is a stage of fresh worker processes with a deadline per phase
+        out.append("   stage %-8s %s in %5.1f s%s%s" % (f.get("stage"), "ok    " if f.get("ok") else "FAILED", f.get("seconds") or 0.0,
+                                                       ("  timed out on ranks %s" % f["timed_out_ranks"]) if f.get("timed_out_ranks") else "", ("  -- " + f["why"]) if f.get("why") else ""))
+    if j.get("failed"):
+        out.append("   NO MEASUREMENT: %s" % j.get("error"))
     proof = tp.get("proved_before_timing")
     if proof:
         out.append("   proved before timing: tokens %s  same on every rank %s  equal to the reference golden %s" % (proof.get("tokens"), proof.get("same_on_every_rank"), proof.get("equals_reference_golden")))
