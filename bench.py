@@ -96,13 +96,15 @@ def main():
 
     # counter passes first: they are child processes, and nothing in THIS process has touched the GPU yet
     traffic = {args.config: (None, "skipped (--no-pmc)")}
-    trace_us = {}
+    trace_us, mfma = {}, {}
     if not args.no_pmc:
         traffic[args.config] = profiler.pmc_traffic(args.config, args.seed)
         trace_us[args.config] = profiler.kernel_trace_us(args.config, args.seed)
+        mfma[args.config] = profiler.mfma_instructions(args.config, args.seed)
         if not args.no_extra and args.config == "llama2_7b":
             traffic["stories110M"] = profiler.pmc_traffic("stories110M", args.seed)
             trace_us["stories110M"] = profiler.kernel_trace_us("stories110M", args.seed)
+            mfma["stories110M"] = profiler.mfma_instructions("stories110M", args.seed)
 
     cfg = runtime.Config(hdr)
     ctx = runtime.Context(hdr, device=device)
@@ -168,7 +170,7 @@ def main():
         if configs.checkpoint_bytes(hdr) < (2 << 30):
             out["dropin_tok_s_direct_dispatch_off"] = dropin_direct_dispatch_off(args.config, args.seed)
         contract_keys(out, bpt)
-    out["roofline"] = roofline_block(ctx, cfg, K, *traffic[args.config], trace_us.get(args.config))
+    out["roofline"] = roofline_block(ctx, cfg, K, *traffic[args.config], trace_us.get(args.config), mfma.get(args.config))
     out["per_kernel"] = per_kernel_block(ctx, cfg)
     S = hdr[6]
     if not args.no_extra:
@@ -203,7 +205,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.config, hdr, args.seed)
     if not args.no_extra and args.config == "llama2_7b":
         out["stories110M"] = secondary_config("stories110M", args.seed, device, not args.no_cpu_baseline,
-                                              traffic.get("stories110M", (None, "skipped")), trace_us.get("stories110M"))
+                                              traffic.get("stories110M", (None, "skipped")), trace_us.get("stories110M"), mfma.get("stories110M"))
 
     # a timed run that decoded other tokens than the reference is not a measurement: the line is still printed (it says where
     # the first mismatch is), the exit code says no

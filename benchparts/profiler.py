@@ -65,6 +65,37 @@ def pmc_traffic(name, seed):
                         "WRITE_SIZE KiB x 1024; per launch, mean of %d)" % len(vals))
 
 
+def mfma_instructions(name, seed):
+    """The decode path issues no MFMA (batch-1 GEMV: no second dimension for a matrix core, llama2.ts:196-203) -- as a COUNTER, not a
+    sentence: one more `rocprofv3 --pmc SQ_INSTS_MFMA` pass over the same child (one whole forward + launches of the dominant kernel),
+    summed over every kernel of the library it ran.  (profiles/r06/decode_mfma_pmc_*.json: the same per kernel over 24 decoded tokens,
+    with SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES and SQ_INSTS_VALU beside it.)"""
+    if under_profiler():
+        return None, "skipped: this run is itself being profiled"
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="l2_mfma_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--pmc", "SQ_INSTS_MFMA", "--output-format", "csv", "-d", work, "-o", "p", "--",
+               sys.executable, BENCH, "--pmc-child", "--config", name, "--seed", str(seed)]
+        r = subprocess.run(cmd, cwd="/tmp", env=clean_child_env(TMPDIR="/tmp", L2_USE_GRAPH="0"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+        files = glob.glob(os.path.join(work, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 --pmc SQ_INSTS_MFMA failed (rc %d)" % r.returncode
+        total, launches = 0.0, 0
+        for row in csv.DictReader(open(files[0])):
+            if row["Counter_Name"] == "SQ_INSTS_MFMA" and "l2k::" in row["Kernel_Name"] and "synth_fill" not in row["Kernel_Name"] and "pack_kernel" not in row["Kernel_Name"]:
+                total += float(row["Counter_Value"]); launches += 1
+        if not launches:
+            return None, "no kernel of the library in the SQ_INSTS_MFMA pass"
+        return int(total), "rocprofv3 --pmc SQ_INSTS_MFMA over a child of this run: one whole forward + the dominant kernel, %d launches of the library's kernels" % launches
+    except Exception as e:   # noqa: BLE001 -- a missing profiler must not fail the benchmark
+        return None, "pmc pass: %r" % (e,)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def kernel_trace_us(name, seed):
     """Average duration of the dominant kernel as a kernel trace reports it (rocprofv3 --kernel-trace, no counters): a child of
     this script decodes 24 tokens with eager launches.  Quoted next to the HIP-event figure: on a 5 us kernel the event pair

@@ -42,7 +42,7 @@ def dispatch_note(ctx):
     return "one hipGraph replay per token (the library's AQL queue is not in use: %s)" % (why or "not taken")
 
 
-def roofline_block(ctx, cfg, K, traffic, traffic_how, trace_us=None):
+def roofline_block(ctx, cfg, K, traffic, traffic_how, trace_us=None, mfma=None):
     iters = 200 if cfg.dim * cfg.hidden_dim < (1 << 24) else 50
     kms_isolated = ctx.bench_gemv(runtime.T_W1, cfg.n_layers // 2, iters)
     kus, nlaunch = ctx.bench_dominant_in_situ(1, 0, min(K, 128))    # HIP events on every dispatch of the kernel, eager launches of the same kernels
@@ -55,6 +55,8 @@ def roofline_block(ctx, cfg, K, traffic, traffic_how, trace_us=None):
                             "an upper bound on the kernel's own time, within 2 % at 50 us, tens of percent at 5 us)",
            "how": "HIP start/stop events attached to every dispatch of this kernel inside a decode run on the library's stream (hipExtLaunchKernelGGL)",
            "isolated_back_to_back_us": round(kms_isolated * 1e3, 3)}
+    if mfma is not None:      # (benchparts/profiler.py: mfma_instructions)
+        out["mfma_insts"], out["mfma_how"] = mfma
     if trace_us:
         out["kernel_trace_us"] = trace_us
         out["frac_kernel_trace"] = round(kb / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
@@ -73,7 +75,7 @@ def per_kernel_block(ctx, cfg):
     return out
 
 
-def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None):
+def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None, mfma=None):
     """BASELINE.json's metric names stories110M next to 7B: the same measurement as a block of the same JSON line."""
     hdr = configs.header(name)
     ctx = runtime.Context(hdr, device=device)
@@ -103,7 +105,7 @@ def secondary_config(name, seed, device, with_cpu, traffic, trace_us=None):
     out["napi_dropin_tok_s"] = napi_dropin(ctx, name, seed, K)               # ... and through the N-API addon under Node (the contract's binding)
     out["dropin_tok_s_direct_dispatch_off"] = dropin_direct_dispatch_off(name, seed)
     contract_keys(out, bpt)
-    out["roofline"] = roofline_block(ctx, cfg, K, traffic[0], traffic[1], trace_us)
+    out["roofline"] = roofline_block(ctx, cfg, K, traffic[0], traffic[1], trace_us, mfma)
     out["per_kernel"] = per_kernel_block(ctx, cfg)      # back-to-back launches of each GEMV phase: us and GB/s of its matrix bytes
     S = hdr[6]
     ms = ctx.bench_decode(1, 0, S)

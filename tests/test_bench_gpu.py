@@ -42,6 +42,7 @@ def test_bench_json_contract():
     assert pr["steps_checked"] == 32 and pr["equal_to_reference_golden"] is True and pr["dropin_equal_to_reference_golden"] is True
     assert rf["kernel_trace_us"] is None or 0 < rf["kernel_trace_us"] <= rf["avg_launch_us"] * 1.2
     assert "duration_used" in rf
+    assert rf["mfma_insts"] in (0, None), rf      # the decode path issues no MFMA: a counter pass of this run (None: no rocprofv3 here)
     # `value` is the device-resident loop (a SURVEY.md 8(f1) extra) and says so; the contract's own call -- one blocking transformer() per
     # token, logits to the host -- stands next to it: through the N-API addon where Node is here, else through ctypes
     assert "`value` times THIS loop" in loop and "contract_tok_s" in loop
