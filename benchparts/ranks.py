@@ -19,7 +19,7 @@ ever reused for a second attempt:
                                                         stages that failed -- or, if every stage failed, a line that says so (value null,
                                                         exit code 1).
 
-Deadlines: L2_BENCH_STAGE_DEADLINES="start,create,prove,run" seconds (default 180,120,180,900).  Test hook (L2_TEST_HOOKS=1 only):
+Deadlines: L2_BENCH_STAGE_DEADLINES="start,create,prove,run" seconds (default 300,120,180,900).  Test hook (L2_TEST_HOOKS=1 only):
 L2_BENCH_WORKER_STUB=<script> is started instead of the worker (tests/test_bench_cpu.py: a rank that sleeps forever)."""
 import json
 import os
@@ -39,7 +39,7 @@ MARK = "@@l2 "
 
 
 def deadlines():
-    d = [180.0, 120.0, 180.0, 900.0]
+    d = [300.0, 120.0, 180.0, 900.0]      # (start: a fresh box pages the image in under the first `import torch` -- minutes, not seconds)
     s = os.environ.get("L2_BENCH_STAGE_DEADLINES", "")
     if s:
         try:
