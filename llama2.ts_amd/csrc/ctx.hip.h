@@ -151,8 +151,6 @@ struct l2_ctx {
   unsigned* awo_ep = nullptr;               // its launch counter (advanced by the combine launch that follows)
   int opt_awo = 1;                          // L2_TP_ATTN_WO=0: attention and wo as two launches (A/B, development switch)
   TpPush* tp_push = nullptr;         // device table of the peers' granule inboxes for the GEMV epilogues (kernels.hip.h: tp_push_row)
-  int opt_fused_combine = 0;         // L2_TP_FUSED_COMBINE=1: the pushing GEMV's own waves finish the all-reduce instead of a combine launch (development switch: create_impl says why it is off)
-  bool tp_fused = false;             // the pushing GEMVs' own waves combine (tp_exchange.hip.h: p2p_publish_table)
   int opt_push = 1;                  // L2_TP_PUSH=0: partials through c->partial and the flag exchange (round-4 form; A/B, development switch)
   bool rccl_graph = false;           // the RCCL collectives of the step are captured into the per-token hipGraph (cleared if capture is refused)
   unsigned long long p2p_wait_ticks = 3000000000ull;   // L2_TP_WAIT_S (default 30 s) on the 100 MHz clock
@@ -219,7 +217,8 @@ struct l2_ctx {
   bool aql_tried = false;
   int opt_aql = 1;                  // L2_AQL=0: replayed hipGraphs instead of the library's own queue (greedy loop, sampled loop and the blocking call alike)
   int aql_fence = 20;               // acquire scope + 4 * release scope + 16 * (agent acquire on a token's first launch): aql_queue.h, create_impl
-  std::string aql_note;             // why the queue is not in use, if it is not
+  std::string aql_note;             // why the queue could not be had / was given up
+  std::string dispatch_why;         // l2_dispatch_reason's text (valid until the next call)
   int opt_exact = 0, opt_graph = 1, opt_keep_state = 0;
   int opt_pf_f32 = 0;               // L2_OPT_PREFILL_F32_MFMA: the register-blocked prompt GEMMs accumulate in fp32 on v_mfma_f32_16x16x4_f32 (opt-in; prefill.hip.h)
   int opt_pollute = 0;              // L2_DEBUG_POLLUTE=1 (test hook): l1_pollute_kernel behind every launch of the step (kernels.hip.h)

@@ -187,15 +187,7 @@ static_assert(sizeof(void*) != 8 || sizeof(PhaseArgs) <= 224 + 16, "PhaseArgs: k
 
 // Tensor-parallel push (tp_exchange.hip.h): where the fp64 partial of a row goes.  gin[r] = rank r's inbox of granule pairs,
 // [2 parities][MAXG sources][n] x 16 bytes, mapped into this process (uncached memory); in a shard-timing context every "peer" is this rank.
-struct TpPush {
-  unsigned long long* gin[8]; const unsigned long long* epoch; int G, rank, n, solo;
-  // FUSED COMBINE (round 6; tp_fused_combine below): the pushing GEMV's own waves finish the exchange -- no launch behind it
-  int fused;                       // 1: wo / w2 waves wait for the G granule pairs of the rows they pushed, add them in rank order, round once, add the residual
-  unsigned long long* epoch_w;     // the pushed exchange's counters ([P2P_FB] words, all equal): advanced by the launch BEHIND the GEMV (tp_epoch_bump)
-  unsigned* awo_bump;              // launch counter of the fused attention + wo launch, advanced with the counters by the w1 / w3 launch (or null)
-  int* err;                        // host-mapped: a bounded wait gave up
-  unsigned long long wait_ticks;   // its bound on the 100 MHz clock
-};
+struct TpPush { unsigned long long* gin[8]; const unsigned long long* epoch; int G, rank, n, solo; };
 
 // One fp64 partial = two hand-off granules {low word, tag}, {high word, tag} written by ONE 16-byte system-scope store (sc0 sc1: past
 // L1 and L2, over xGMI for a peer's memory); each 8-byte half is its own flag (MI355X guide, recipe R2: 8-byte halves of a 16-byte
@@ -209,12 +201,12 @@ __device__ __forceinline__ void tp_push_store(unsigned long long* slot, double v
 // What a wave needs to push its rows, fetched ONCE when the kernel starts (the table load must not queue behind the weight stream):
 // lane r's target inbox, the group's shape, the number of this exchange (read past L1: the launch before advanced it; a scalar load
 // would see a stale copy under graph replay).
-struct PushCtx { unsigned long long* gin = nullptr; int G = 0, rank = 0, n = 0, solo = 0, fused = 0; unsigned e = 0; };
+struct PushCtx { unsigned long long* gin = nullptr; int G = 0, rank = 0, n = 0, solo = 0; unsigned e = 0; };
 __device__ __forceinline__ PushCtx tp_push_ctx(const TpPush* p, int lane) {
   PushCtx c;
   // (uniform values pinned to scalar registers: the context lives through the whole GEMV loop, where vector registers are the budget)
   c.G = __builtin_amdgcn_readfirstlane(p->G); c.rank = __builtin_amdgcn_readfirstlane(p->rank);
-  c.n = __builtin_amdgcn_readfirstlane(p->n); c.solo = __builtin_amdgcn_readfirstlane(p->solo); c.fused = __builtin_amdgcn_readfirstlane(p->fused);
+  c.n = __builtin_amdgcn_readfirstlane(p->n); c.solo = __builtin_amdgcn_readfirstlane(p->solo);
   c.gin = p->gin[c.solo ? c.rank : min(lane, c.G - 1)];
   c.e = __builtin_amdgcn_readfirstlane((unsigned)__hip_atomic_load(p->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
   return c;
@@ -222,16 +214,6 @@ __device__ __forceinline__ PushCtx tp_push_ctx(const TpPush* p, int lane) {
 // lane r < G of the wave that holds the reduced sum stores it into rank r's inbox, slot [parity of the exchange][this rank][row i]
 __device__ __forceinline__ void tp_push_row(const PushCtx& c, int i, double v, int lane) {
   if (lane < c.G) tp_push_store(c.gin + 2 * ((size_t)((c.e & 1u) * 8u + (unsigned)(c.solo ? lane : c.rank)) * (size_t)c.n + (size_t)i), v, c.e);
-}
-
-// The launch BEHIND a pushing GEMV whose waves combine themselves (w1 / w3 behind wo, the next layer's q / k / v or the classifier behind
-// w2) advances the exchange's counters: every wave of the GEMV has read them (that launch is over), the next GEMV reads the new number.
-// One wave, 64 lanes = the 64 words; w1 / w3 also advances the launch counter of the fused attention + wo launch in front of it.
-__device__ __forceinline__ void tp_epoch_bump(const TpPush* p, int lane, bool awo) {
-  unsigned long long* w = p->epoch_w;
-  const unsigned long long e = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // word 0 is the one the pushers read: all 64 follow it
-  w[lane] = e + 1ull;
-  if (awo && lane == 0 && p->awo_bump) { unsigned* b = p->awo_bump; __hip_atomic_store(b, __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // Hand-off granule of the fused QKV + attention launch (attention.hip.h): ONE naturally aligned 8-byte word {fp32 value, tag},
@@ -613,69 +595,6 @@ __device__ __forceinline__ void finish_group(const PhaseArgs& a, int g, const do
   }
 }
 
-// FUSED COMBINE of the tensor-parallel all-reduce (round 6; llama2.ts:270-273, 292-295 are the reduce points).  Until round 5 a launch of
-// its own (tp_p2p_combine_kernel, 16 workgroups) waited for the pushed partials, summed them and added the residual: two launches per
-// layer whose cost -- boundary, a cold fetch of the inbox, 4.7 us each in the eager trace -- does not shrink with the group size.  Here the
-// wave that PUSHED a row finishes it: when all its row groups are pushed it waits for the G granule pairs of each of ITS rows in the local
-// inbox (lane r polls source r: one 16-byte system-scope load per row and sweep), adds them IN RANK ORDER (every rank the same sum), rounds
-// once, adds the residual and stores x.  On a node the ranks run the same launch at the same time, so what a wave waits for is its peers'
-// copy of the row it has just computed itself: the xGMI hop, not a launch.  Slot parity, tags and the bound of the wait are the combine
-// kernel's (tp_exchange.hip.h); the exchange's counters are advanced by the launch behind this one (tp_epoch_bump).  All workgroups of a
-// pushing launch are co-resident (one per CU, or the persistent grid), so a waiting wave never keeps a peer's producer off the chip.
-template <int MODE, int R>
-__device__ __forceinline__ void tp_fused_combine(const PhaseArgs& a, const PushCtx& pc, int g0, int gstride, int groups, int lane, int token) {
-  const TpPush* p = a.push;
-  const int G = pc.G, n = pc.n;
-  const unsigned tag = pc.e;
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc(p->gin[pc.rank], 0, (unsigned)((size_t)2 * 8 * (size_t)n * 16), 0x00020000);
-  const unsigned slot = ((pc.e & 1u) * 8u + (unsigned)min(lane, G - 1)) * (unsigned)n;      // this lane's source: granule pairs of row 0
-  constexpr int NB = 2 * R;                                                                  // rows per sweep: two row groups of the wave
-  const unsigned long long bound = p->wait_ticks;
-  for (int g = g0; g < groups; g += 2 * gstride) {
-    int row[NB];
-    bool live[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int gb = g + (b / R) * gstride, i = gb * R + (b % R);
-      live[b] = gb < groups && i < a.rows;
-      row[b] = live[b] ? i : g * R;                                                          // (a dead slot re-reads the first row)
-    }
-    // residual of row b in lane b, requested before the wait (layer 0's wo: the embedding row, llama2.ts:211)
-    float xr;
-    { int ib = row[0];
-#pragma unroll
-      for (int b = 1; b < NB; ++b) ib = (lane == b) ? row[b] : ib;
-      xr = (MODE == MODE_WO && a.emb) ? a.emb[(size_t)token * a.dim + ib] : a.res.ld(ib); }
-    u32x4 gr[NB];
-    unsigned spins = 0;
-    unsigned long long t0 = 0;
-    for (;;) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) gr[b] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (slot + (unsigned)row[b]) * 16u, 0, 17));      // aux 17 = sc0 sc1
-      bool ok = true;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) ok = ok & (gr[b].y == tag) & (gr[b].w == tag);
-      if (__all(ok)) break;
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 255u) == 0) {
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        if (!t0) t0 = now;
-        else if (now - t0 > bound) { if (lane == 0) *p->err = 1; break; }
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int lo = (int)gr[b].x, hi = (int)gr[b].z;
-      double sum = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-#pragma unroll
-      for (int r = 1; r < 8; ++r)
-        if (r < G) sum += __hiloint2double(__builtin_amdgcn_readlane(hi, r), __builtin_amdgcn_readlane(lo, r));      // rank order on every rank
-      const float mv = (float)sum;                                                           // ONE rounding of the all-reduced sum (llama2.ts:201)
-      if (lane == b && live[b]) { a.out.st(row[b], xr + mv); if (a.aux) a.aux.st(row[b], mv); }
-    }
-  }
-}
-
 template <int MODE>
 __device__ __forceinline__ constexpr bool mode_has_norm() { return MODE == MODE_QKV || MODE == MODE_W13 || MODE == MODE_CLS; }
 
@@ -904,9 +823,6 @@ __device__ __forceinline__ void phase_body(const PhaseArgs& a, char* smem, const
     g = g3; ch = ch3; rg = rg3; have = have3;
   }
   finish();
-  if (pushing) { if (pctx.fused) tp_fused_combine<MODE, R>(a, pctx, g0, wstride, groups, lane, token); }
-  // (tensor parallel, fused combine: the launch behind a pushing GEMV advances the exchange's counters -- `push` is set for that duty only)
-  if (!(MODE == MODE_WO || MODE == MODE_W2)) { if (a.push && vblock == 0 && wave == 0) tp_epoch_bump(a.push, lane, MODE == MODE_W13); }
   if (MODE == MODE_CLS && a.amax) {
     // greedy loop: ONE memory-side maximum per workgroup (no value returned, nothing waits for it); the launch
     // boundary orders it before the one-wave kernel that reads the eight keys (argmax_finish_kernel)
@@ -1091,8 +1007,6 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
   STAMP(1);
   __syncthreads();
   STAMP(3);
-  // (tensor parallel, fused combine: the launch behind a pushing GEMV advances the exchange's counters -- the x wave of workgroup 0, its work done)
-  if (!(MODE == MODE_WO || MODE == MODE_W2)) { if (wave == 0 && vblock == 0 && a.push) tp_epoch_bump(a.push, lane, MODE == MODE_W13); }
   if (wave == 0 || gA0 >= groups) return;
   if (MODE == MODE_QKV || MODE == MODE_WO) { token = a.tokpos[0]; pos = a.tokpos[1]; }
   if (MODE == MODE_WO && a.emb && a.tok_out) {      // the greedy pick folded into the step (greedy_token_from_keys): layer 0 only
@@ -1160,7 +1074,6 @@ __device__ __forceinline__ void phase_small_body(const PhaseArgs& a, char* smem,
     const int g3 = nth(k + 3);
     if (g3 < groups) { issue(bufB, g3); preB = epi_prefetch<MODE, R>(a, g3, lane, token, pos); preB.tag = gtag(g3); }
   }
-  if (MODE == MODE_WO || MODE == MODE_W2) { if (pushing && pctx.fused) tp_fused_combine<MODE, R>(a, pctx, g0, gstride, groups, lane, token); }
 }
 
 template <int MODE, int XV, int R>

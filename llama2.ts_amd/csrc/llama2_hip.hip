@@ -199,11 +199,6 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->p2p_fenced = env_int("L2_TP_FENCED", 0) ? 1 : 0;
   c->opt_push = dev_int("L2_TP_PUSH", 1) && !c->p2p_fenced;      // (the fenced form is the flag exchange)
   c->opt_awo = dev_int("L2_TP_ATTN_WO", 1);
-  // (0 = the combine launch behind wo / w2.  The fused form is built and measured -- a rank's shard step alone 1.186 -> 1.164 ms at 8 ranks,
-  // 1.672 -> 1.629 at 4, 2.624 -> 2.565 at 2: profiles/r06/tp_fused_combine_ab.txt -- and NOT the default: two ranks as processes on ONE
-  // GPU, the only multi-process group a development box can form, deadlock in it until the bounded wait gives up (each process's pushing
-  // launch fills the chip with waiting waves and keeps the other's off it), so the form could not be verified between processes at all)
-  c->opt_fused_combine = dev_int("L2_TP_FUSED_COMBINE", 0);
   { const int ws = env_int("L2_TP_WAIT_S", 30); c->p2p_wait_ticks = (unsigned long long)(ws > 0 ? ws : 30) * 100000000ull; }
 
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int rc_ = fail(L2_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); l2_destroy(c); return rc_; } } while (0)
@@ -465,7 +460,6 @@ static PhaseArgs qkv_args(const l2_ctx* c, int l) {   // rmsnorm + q,k,v GEMVs +
   if (c->opt_keep_state) { a.aux = c->k; a.aux2 = c->v; }     // RunState.k / v: the cache rows are what attention reads
   a.n = c->d; a.rows = c->d_loc + 2 * c->kvd_loc; a.dim = c->d_loc; a.kv_dim = c->kvd_loc;
   a.wp = packed_of(c, MODE_QKV, l);
-  if (l > 0 && p2p_fused(c)) a.push = c->tp_push;      // (behind the layer before's w2, whose waves combined themselves: advance the exchange's counters)
   return a;
 }
 static PhaseArgs wo_args(const l2_ctx* c, int l) {    // wo GEMV + residual (llama2.ts:270-273)
@@ -486,7 +480,6 @@ static PhaseArgs w13_args(const l2_ctx* c, int l) {   // rmsnorm + w1,w3 GEMVs +
   a.out = c->hb; a.aux = c->opt_keep_state ? c->hb2 : nullptr;
   a.n = c->d; a.rows = c->h_loc;
   a.wp = packed_of(c, MODE_W13, l);
-  if (p2p_fused(c)) a.push = c->tp_push;               // (behind wo: advance the exchange's counters and the attention + wo launch's)
   return a;
 }
 static PhaseArgs w2_args(const l2_ctx* c, int l) {    // w2 GEMV + residual (llama2.ts:292-295)
@@ -506,7 +499,6 @@ static PhaseArgs cls_args(const l2_ctx* c, bool to_host) {   // final rmsnorm + 
   a.aux2 = (to_host && c->opt_zero_copy && !c->tp_path) ? c->h_logits_dev : nullptr;
   a.n = c->d; a.rows = c->V_loc;
   a.wp = packed_of(c, MODE_CLS, 0);
-  if (p2p_fused(c)) a.push = c->tp_push;               // (behind the last layer's w2)
   return a;
 }
 
@@ -1190,13 +1182,13 @@ extern "C" int l2_get_option(l2_ctx* c, int key, int* value) {
 
 extern "C" const char* l2_dispatch_reason(l2_ctx* c) {
   if (!c || aql_usable(c)) return "";
-  if (c->aql_note.empty()) {
-    if (!c->opt_aql) c->aql_note = "switched off (L2_AQL=0 / L2_OPT_AQL_QUEUE)";
-    else if (!c->opt_graph) c->aql_note = "the step is not recorded (L2_USE_GRAPH=0): eager launches";
-    else if (c->tp_path) c->aql_note = "a tensor-parallel step whose exchanges are not kernels of the library (RCCL collectives, or the loopback test group)";
-    else if (c->profile_sync) c->aql_note = "L2_PROFILE_SYNC=1";
-  }
-  return c->aql_note.c_str();
+  if (!c->opt_aql) c->dispatch_why = "switched off (L2_AQL=0 / L2_OPT_AQL_QUEUE)";
+  else if (!c->opt_graph) c->dispatch_why = "the step is not recorded (L2_USE_GRAPH=0): eager launches";
+  else if (c->tp_path && !(c->p2p && !c->loop && c->p2p_peers_ready)) c->dispatch_why = "a tensor-parallel step whose exchanges are not kernels of the library (RCCL collectives, or the loopback test group)";
+  else if (c->loop) c->dispatch_why = "the loopback test group (host barriers inside the step)";
+  else if (c->profile_sync) c->dispatch_why = "L2_PROFILE_SYNC=1";
+  else c->dispatch_why = c->aql_note;      // the queue could not be had, or was given up: why
+  return c->dispatch_why.c_str();
 }
 
 #include "bench_hooks.hip.h"

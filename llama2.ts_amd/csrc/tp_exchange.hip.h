@@ -202,17 +202,11 @@ static int p2p_publish_table(l2_ctx* c) {
   memset(&t, 0, sizeof(t));
   for (int r = 0; r < c->G && r < P2P_MAXG; ++r) t.gin[r] = c->p2p_peers.gin[r];
   t.G = c->G; t.rank = c->rank; t.n = c->d; t.solo = c->solo ? 1 : 0; t.epoch = c->p2p_epoch + P2P_FB;      // (the combine launches' own counters: p2p_combine_args)
-  // fused combine (kernels.hip.h: tp_fused_combine): the vector forms of wo / w2 only (the scalar kernels of n % 4 != 0 shards keep the combine launch)
-  t.fused = (c->opt_fused_combine && c->d % 4 == 0 && c->d_loc % 4 == 0 && c->h_loc % 4 == 0) ? 1 : 0;
-  t.epoch_w = c->p2p_epoch + P2P_FB; t.awo_bump = (c->opt_awo && c->awo_ep) ? c->awo_ep : nullptr; t.err = c->p2p_err_dev; t.wait_ticks = c->p2p_wait_ticks;
-  c->tp_fused = t.fused != 0;
   if (!c->tp_push) HIPCHK(hipMalloc(&c->tp_push, sizeof(TpPush)));
   HIPCHK(hipMemcpy(c->tp_push, &t, sizeof(t), hipMemcpyHostToDevice));
   return L2_OK;
 }
 static bool p2p_pushing(const l2_ctx* c) { return c->p2p && !c->loop && c->opt_push && c->tp_push; }
-// ... and the pushing GEMV's own waves combine (no launch behind it)
-static bool p2p_fused(const l2_ctx* c) { return p2p_pushing(c) && c->tp_fused; }
 static P2PArgs p2p_args(const l2_ctx* c, int n) {
   P2PArgs a;
   a.pr = c->p2p_peers; a.epoch = c->p2p_epoch; a.ticket = nullptr; a.err = c->p2p_err_dev;
@@ -445,7 +439,6 @@ static int tp_all_gather_logits(l2_ctx* c, hipStream_t st) {
 // runs its two halves around a host barrier instead (see tp_p2p_reduce_kernel)
 static int p2p_reduce(l2_ctx* c, hipStream_t st, const float* res_emb, float* mv_out, unsigned* bump) {
   const dim3 grid(p2p_grid(c->d));
-  if (p2p_fused(c)) return L2_OK;      // the wo / w2 launch in front has done it (kernels.hip.h: tp_fused_combine)
   if (p2p_pushing(c)) {
     l2_launch(c, tp_p2p_combine_kernel, grid, dim3(256), 0, st, p2p_combine_args(c), c->x, res_emb, mv_out, (const int*)c->tokpos, bump);
   } else if (!c->loop) {

@@ -125,40 +125,6 @@ def test_pushed_exchange_with_fewer_vocabulary_blocks_than_dim():
             del os.environ[k]
 
 
-def test_fused_combine_equals_the_combine_launch(monkeypatch):
-    """L2_TP_FUSED_COMBINE=1 (development switch, off by default: csrc/llama2_hip.hip says why): the wave that pushed a row of wo / w2 waits
-    for the G copies of it, adds them in rank order, rounds once and adds the residual -- no combine launch (llama2.ts:270-273, 292-295).
-    Where one process can run it: a 1-rank communicator against the reference's golden, and a rank alone in an 8-rank group of the 7B
-    width (sums are 8 x the partial there: meaningless, but the same bits as the combine launch's)."""
-    meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tiny.json")))
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny.npz"))
-    monkeypatch.setenv("L2_TP_FUSED_COMBINE", "1")
-    monkeypatch.setenv("L2_TP_FORCE_COMM", "1")
-    monkeypatch.setenv("L2_TP_ALLREDUCE", "p2p")
-    ctx = runtime.Context(meta["header"])
-    assert ctx.tp_mode_id() == 3
-    ctx.synth_fill(meta["seed"])
-    for pos, tok in enumerate(meta["tokens_fed"][:24]):
-        got = np.array(ctx.forward(tok, pos), copy=True)
-        assert np.abs(got - g["logits"][pos]).max() <= 1e-4 and runtime.argmax(got) == meta["argmax"][pos]
-    assert ctx.decode_greedy(1, 0, 48).tolist() == meta["argmax"][:48]
-    ctx.close()
-    monkeypatch.delenv("L2_TP_FORCE_COMM")
-    monkeypatch.delenv("L2_TP_ALLREDUCE")
-    hdr = configs.header("llama2_7b_L2")
-    runs = {}
-    for fused in ("0", "1"):
-        monkeypatch.setenv("L2_TP_FUSED_COMBINE", fused)
-        for G in (2, 8):
-            solo = runtime.Context(hdr, tp_rank=0, tp_size=G, nccl_id=runtime.TP_SOLO_ID)
-            solo.synth_fill(1)
-            a = solo.decode_greedy(1, 0, 160).tolist()          # crosses the attention split level (144 rows)
-            assert solo.decode_greedy(1, 0, 160).tolist() == a
-            runs[(fused, G)] = a
-            solo.close()
-    assert runs[("0", 2)] == runs[("1", 2)] and runs[("0", 8)] == runs[("1", 8)]
-
-
 def _run_group(name, G, n_forward, n_greedy, exact=False, collective="p2p"):
     """G ranks of one tensor-parallel group as G host threads on one device (L2_TP_LOOPBACK test hook in
     llama2_hip.hip: the collectives become device sums/copies between thread barriers; everything else is the
