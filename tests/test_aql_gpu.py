@@ -164,3 +164,38 @@ sys.exit(1 if bad else 0)
     env = dict(os.environ, AMD_DIRECT_DISPATCH="0", L2_AQL="0", L2_USE_GRAPH=graph, L2_ZERO_COPY_LOGITS=zero_copy)
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-1500:]
+
+
+def test_dispatch_reason_and_the_position_check():
+    """l2_dispatch_reason says why the library's queue is not in use without touching l2_last_error (which is for failures); L2_OPT_CHECK_POS
+    makes the reference's calling convention -- pos = 0, 1, 2, ... (llama2.ts:464, 496) -- an enforced one: a position that skips ahead of
+    the rows the cache holds is L2_E_STATE, re-feeding an earlier position or restarting at 0 is not."""
+    ctx = runtime.Context(configs.header("tiny"))
+    ctx.synth_fill(configs.DEFAULT_SEED)
+    toks = ctx.decode_greedy(1, 0, 8).tolist()
+    assert ctx.get_option(runtime.OPT_AQL_QUEUE) == 1 and ctx.dispatch_reason() == ""
+    ctx.set_option(runtime.OPT_AQL_QUEUE, 0)
+    assert "switched off" in ctx.dispatch_reason()
+    ctx.set_option(runtime.OPT_AQL_QUEUE, 1)
+    ctx.set_option(runtime.OPT_USE_GRAPH, 0)
+    assert "not recorded" in ctx.dispatch_reason() and ctx.decode_greedy(1, 0, 8).tolist() == toks
+    ctx.set_option(runtime.OPT_USE_GRAPH, 1)
+    assert ctx.dispatch_reason() == "" and ctx.decode_greedy(1, 0, 8).tolist() == toks
+    # positions
+    assert ctx.get_option(runtime.OPT_CHECK_POS) == 0
+    ctx.forward(1, 20)                                     # default: any position is accepted (rows 8 .. 19 are whatever the cache holds)
+    ctx.set_option(runtime.OPT_CHECK_POS, 1)
+    ctx.forward(1, 0)                                      # a restart
+    for pos in range(1, 6):
+        ctx.forward(toks[pos - 1], pos)
+    ctx.forward(toks[2], 3)                                # re-feeding an earlier position
+    with pytest.raises(runtime.L2Error) as e:
+        ctx.forward(toks[3], 6)                            # rows 0 .. 3 are written: 6 skips row 4 and 5 of THIS sequence
+    assert e.value.code == -4 and "skips ahead" in str(e.value)
+    ctx.forward(toks[3], 4)
+    assert ctx.decode_greedy(toks[4], 5, 10).tolist()      # the device loop writes rows 5 .. 14
+    ctx.forward(1, 15)
+    with pytest.raises(runtime.L2Error):
+        ctx.prefill([1, 2, 3], 30)
+    ctx.prefill([1, 2, 3], 16)
+    ctx.close()
