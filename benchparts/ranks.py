@@ -165,7 +165,19 @@ def failure_line(args, world, notes, formation):
 
 
 def supervise(args, argv):
-    """This process is one rank of the launcher (torch.distributed.run).  It stays a CPU-only supervisor."""
+    """This process is one rank of the launcher (torch.distributed.run).  It stays a CPU-only supervisor.  Whatever goes wrong in the
+    supervision itself (a rendezvous that fails, a store that dies) still ends with a line on rank 0 and a non-zero exit code."""
+    try:
+        return _supervise(args, argv)
+    except Exception as e:      # noqa: BLE001 -- the line must appear
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(failure_line(args, int(os.environ.get("WORLD_SIZE", "1")), ["the supervisor of rank 0 failed: %s: %s" % (type(e).__name__, e)], []), flush=True)
+        return 1
+
+
+def _supervise(args, argv):
     import datetime
     import torch.distributed as dist
     from llama2_ts_amd import configs  # noqa: F401  (no GPU call: the module is tables only)
