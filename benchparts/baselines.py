@@ -13,7 +13,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from llama2_ts_amd import configs, runtime  # noqa: E402
+from llama2_ts_amd import configs  # noqa: E402
 
 from .common import golden_argmax, host_cpu_model  # noqa: E402
 

@@ -9,7 +9,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from llama2_ts_amd import configs, runtime  # noqa: E402
+from llama2_ts_amd import configs  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DOMINANT = "rmsnorm + w1/w3 GEMV + SwiGLU (llama2.ts:276-289)"

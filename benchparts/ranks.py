@@ -180,7 +180,6 @@ def supervise(args, argv):
 def _supervise(args, argv):
     import datetime
     import torch.distributed as dist
-    from llama2_ts_amd import configs  # noqa: F401  (no GPU call: the module is tables only)
     dl = deadlines()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=sum(dl.values()) + 120))

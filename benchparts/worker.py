@@ -15,8 +15,6 @@ import sys
 import threading
 import time
 
-import numpy as np
-
 from .common import HBM_PEAK_GBS, ROOT, avg_bytes_per_token, parity_block, under_profiler
 from .ranks import MARK, deadlines
 from .single import committed_prediction, dispatch_note
