@@ -223,6 +223,7 @@ struct l2_ctx {
   int opt_pf_f32 = 0;               // L2_OPT_PREFILL_F32_MFMA: the register-blocked prompt GEMMs accumulate in fp32 on v_mfma_f32_16x16x4_f32 (opt-in; prefill.hip.h)
   int opt_pollute = 0;              // L2_DEBUG_POLLUTE=1 (test hook): l1_pollute_kernel behind every launch of the step (kernels.hip.h)
   float* pollute_sink = nullptr;
+  int debug_fail_aql = 0;           // L2_DEBUG_FAIL_AQL_RUN=n (test hook): the n-th run on the queue reports a failure (the recovery path, llama2_hip.hip: aql_give_up)
   int opt_pos_check = 0;            // L2_CHECK_POS=1: l2_forward refuses a position that does not continue the sequence (llama2.ts:464, 496)
   int next_pos = 0;
   bool ran_forward = false;

@@ -190,6 +190,7 @@ static int create_impl(const int32_t cfg[7], int device, int rank, int G, const 
   c->profile_sync = dev_int("L2_PROFILE_SYNC", 0);
   c->opt_aql = env_int("L2_AQL", 1);
   c->opt_pollute = hook_int("L2_DEBUG_POLLUTE");
+  c->debug_fail_aql = hook_int("L2_DEBUG_FAIL_AQL_RUN");
   c->opt_pos_check = env_int("L2_CHECK_POS", 0);
   // fences between the launches of a run on the library's own queue: no acquire, an agent-scope release, and an agent-scope acquire
   // on the first launch of every token (kernels.hip.h: the coherence rule).  L2_AQL_FENCE=<scope> sets both (1 = what a hipGraph
@@ -875,6 +876,13 @@ static int aql_record_level(l2_ctx* c, int lvl, int (*enq)(l2_ctx*, hipStream_t)
 // A run on the queue failed (no progress within L2_QUEUE_WAIT_S, or the runtime reported a queue error): the ring may still hold its
 // packets, so the queue is never submitted to again -- it is destroyed with its recordings and the context goes on with HIP launches
 // (aql_tried stays set; the note says why).  The failed call itself reports the error.
+// (test hook, L2_TEST_HOOKS only: L2_DEBUG_FAIL_AQL_RUN=n makes the n-th run on the queue REPORT a failure after it has completed, so that the
+// recovery below -- queue retired, recordings dropped, the context going on with hipGraphs -- is exercised without hanging a GPU)
+static int aql_run_c(l2_ctx* c, int ntok, AqlProgram* const* per, double* us) {
+  const int rc = aql_run(c->aql, ntok, per, c->aql_fence, us);
+  if (!rc && c->debug_fail_aql > 0 && --c->debug_fail_aql == 0) return -1;
+  return rc;
+}
 static int aql_give_up(l2_ctx* c) {
   const int rc = fail(L2_E_HIP, "AQL queue: %s", aql_last_error(c->aql));
   c->aql_note = std::string("given up after a failed run: ") + aql_last_error(c->aql);
@@ -895,7 +903,7 @@ static int run_greedy_aql(l2_ctx* c, int pos0, int steps, bool timed, float* ms)
   for (int s = 0; s < steps; ++s) per[s] = c->aql_greedy[split_level(c, pos0 + s)];
   if (steps > 0 && c->aql_last) per.push_back(c->aql_last);      // the run's last pick
   double us = 0.0;
-  if (aql_run(c->aql, (int)per.size(), per.data(), c->aql_fence, timed ? &us : nullptr)) return aql_give_up(c);      // (only a timed run spins on the completion signal)
+  if (aql_run_c(c, (int)per.size(), per.data(), timed ? &us : nullptr)) return aql_give_up(c);      // (only a timed run spins on the completion signal)
   if (timed && ms) *ms = (float)(us * 1e-3);
   c->ran_forward = true;
   return check_p2p(c);
@@ -921,7 +929,7 @@ extern "C" int l2_forward(l2_ctx* c, int token, int pos, float* logits_out) {
     // the library's own queue: {token, pos} read from pinned host memory by the first launch, logits written straight into the
     // host's buffer by the classifier, one doorbell, one signal
     HIPCHK(hipStreamSynchronize(c->stream));      // (uploads, an earlier graph's work)
-    if (aql_run(c->aql, 1, &c->aql_step[lvl], c->aql_fence, nullptr)) return aql_give_up(c);
+    if (aql_run_c(c, 1, &c->aql_step[lvl], nullptr)) return aql_give_up(c);
     c->ran_forward = true;
     rc = check_p2p(c);
     if (rc) return rc;
@@ -1038,7 +1046,7 @@ extern "C" int l2_decode_sample(l2_ctx* c, int first_token, int pos0, int steps,
       else per[s] = c->aql_sample[lvl][mode];
     }
     if (ok) {
-      if (aql_run(c->aql, steps, per.data(), c->aql_fence, nullptr)) return aql_give_up(c);
+      if (aql_run_c(c, steps, per.data(), nullptr)) return aql_give_up(c);
       HIPCHK(hipMemcpyAsync(rng_state, c->samp.rng, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipMemcpyAsync(tokens_out, c->d_tokens, (size_t)steps * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));

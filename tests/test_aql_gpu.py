@@ -199,3 +199,29 @@ def test_dispatch_reason_and_the_position_check():
         ctx.prefill([1, 2, 3], 30)
     ctx.prefill([1, 2, 3], 16)
     ctx.close()
+
+
+def test_a_failed_run_retires_the_queue_and_the_context_goes_on_with_graphs(monkeypatch):
+    """aql_run gives a run up when the queue makes no progress for L2_QUEUE_WAIT_S (or the runtime reports a queue error): the call fails, the
+    queue -- whose ring may still hold the run's packets -- is destroyed with its recordings, and the context goes on with replayed hipGraphs.
+    The hook makes the third run on the queue REPORT a failure after it completed (no GPU is hung for a test): that call raises, the next ones
+    decode the reference's tokens through graphs, and l2_dispatch_reason says why (l2_last_error is left to the failure)."""
+    monkeypatch.setenv("L2_DEBUG_FAIL_AQL_RUN", "3")
+    name = "stories15M"
+    want = gold_tokens(name)
+    ctx = runtime.Context(configs.header(name))
+    ctx.synth_fill(configs.DEFAULT_SEED)
+    assert ctx.decode_greedy(1, 0, 64).tolist() == want[:64] and ctx.get_option(runtime.OPT_AQL_QUEUE) == 1      # run 1
+    assert runtime.argmax(ctx.forward(1, 0)) == want[0]                                                          # run 2 (the blocking call)
+    with pytest.raises(runtime.L2Error) as e:
+        ctx.decode_greedy(1, 0, 64)                                                                              # run 3: reported as failed
+    assert e.value.code == -3 and "AQL queue" in str(e.value)
+    assert ctx.get_option(runtime.OPT_AQL_QUEUE) == 0 and "given up after a failed run" in ctx.dispatch_reason()
+    assert ctx.decode_greedy(1, 0, 256).tolist() == want[:256]                                                   # hipGraphs from here on
+    tok = 1
+    for pos in range(16):
+        tok = runtime.argmax(ctx.forward(tok, pos))
+        assert tok == want[pos]
+    toks, _ = ctx.decode_sample(1, 0, 32, 0.0, 1.0, 5)
+    assert toks.tolist() == want[:32]
+    ctx.close()
