@@ -46,9 +46,9 @@ PLAN = {
     "stories110M": (1024, [0, 39, 127, 128, 129, 255, 256, 257, 299, 511, 512, 513, 1023], False, None),
     # ... and at head_size 128 (7B width, 2 layers; ~1 tok/s in the reference: about an hour)
     "llama2_7b_L2": (2048, [0, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 559, 1023, 1024, 1919, 1920, 1984, 2047], False, None),
-    # the real thing: all 32 layers, the 256 steps bench.py times by default (27 GB synthetic checkpoint in /tmp, ~10 s per token
-    # in the reference: about 45 minutes)
-    "llama2_7b": (256, [0, 2, 19, 63, 127, 255], False, None),
+    # the real thing: all 32 layers -- the 256 steps bench.py times by default and on through every attention split level of the full model
+    # (round 6: 1024 steps; 27 GB synthetic checkpoint in /tmp, ~10 s per token in the reference: about three hours)
+    "llama2_7b": (1024, [0, 2, 19, 63, 127, 143, 144, 145, 255, 256, 257, 511, 512, 513, 1023], False, None),
     # whole-CLI goldens (stdout text): the reference runs with the repo's SYNTHETIC tokenizer.bin in its cwd
     "cli_greedy": (48, [], False, None, ["-t", "0", "-s", "1"], True),
     "cli_prompt": (40, [], False, "wetds oyn fra uynia", ["-t", "0", "-s", "1"], True),

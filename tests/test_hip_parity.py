@@ -163,9 +163,10 @@ def test_random_shapes_match_the_oracle(built, hdr):
 
 
 def test_full_llama2_7b_matches_reference_golden(built):
-    """BASELINE.json config 4 itself -- all 32 layers, 27 GB of weights: the 256 steps bench.py times by default, run by the
-    real reference (10 s per token, the whole file in host memory: 47 minutes), every argmax through the drop-in call, logits at
-    positions 0, 2, 19, 63, 127 and 255, then the same 256 tokens from the device-resident loop."""
+    """BASELINE.json config 4 itself -- all 32 layers, 27 GB of weights: the 256 steps bench.py times by default (round 4: 47 minutes of the
+    real reference at 10 s per token, the whole file in host memory) and, where the fixture holds them (round 6: 1024 steps, three hours), on
+    through every attention split level of the full model: every argmax through the drop-in call, logits at the kept positions (0, 2, 19, 63,
+    127, 255 and both sides of 144, 256, 512), then the same tokens from the device-resident loop."""
     meta, g = load_gold("llama2_7b")
     ctx = runtime.Context(meta["header"])
     ctx.synth_fill(meta["seed"])
@@ -176,7 +177,7 @@ def test_full_llama2_7b_matches_reference_golden(built):
         if pos in keep:
             assert np.abs(got - g["logits"][keep[pos]]).max() <= TOL, pos
     n = len(meta["argmax"])
-    assert n >= 256 and meta["logit_positions"] == [0, 2, 19, 63, 127, 255]
+    assert n >= 256 and set([0, 2, 19, 63, 127, 255]) <= set(meta["logit_positions"])
     assert ctx.decode_greedy(1, 0, n).tolist() == meta["argmax"]
     ctx.close()
 
