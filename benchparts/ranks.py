@@ -229,6 +229,7 @@ def _supervise(args, argv):
                 if line is None:
                     notes.append("%s: every rank finished but rank 0 printed no result line" % label)
                     ok = False
+                    formation[-1]["ok"], formation[-1]["why"] = False, "rank 0 printed no result line"
                 else:
                     j = json.loads(line)
                     if name == "file":
@@ -281,7 +282,12 @@ def spawn_ranks(args, argv):
         out, _ = proc.communicate(timeout=bound)
         rc = proc.returncode
     except subprocess.TimeoutExpired:
-        kill_group(proc)
+        try:
+            proc.terminate()                      # the launcher forwards SIGTERM to its ranks (their workers die with them: PR_SET_PDEATHSIG) ...
+            proc.wait(timeout=20)
+        except Exception:      # noqa: BLE001
+            pass
+        kill_group(proc)                          # ... and whatever is left of its process group goes the hard way
         out, _ = proc.communicate()
         rc = 1
         print("bench.py: the launcher of the %d ranks did not end within %.0f s and was killed" % (n, bound), file=sys.stderr)
