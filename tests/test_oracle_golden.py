@@ -29,7 +29,7 @@ def bits(a):
 
 # Steps of each fixture the default CPU suite replays (the fixtures of the two big shapes cover their whole context
 # window -- 1024 and 2048 reference steps -- which is an hour of oracle time; L2_ORACLE_FULL=1 replays everything,
-# and adds the 3-step fixture of the full 32-layer Llama-2-7B, 27 GB of host memory).  Last full replay: see DESIGN.md.
+# and adds the 1024-step fixture of the full 32-layer Llama-2-7B: 27 GB of host memory, over an hour of oracle time).  Last full replay: DESIGN.md section 2.
 FULL = os.environ.get("L2_ORACLE_FULL") == "1"
 STEP_CAP = {} if FULL else {"stories110M": 48, "llama2_7b_L2": 6}
 NAMES = ["tiny", "ragged", "tinylong", "stories15M", "stories15M_prompt", "stories110M", "llama2_7b_L2"] + (["llama2_7b"] if FULL else [])
