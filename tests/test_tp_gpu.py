@@ -310,16 +310,21 @@ print("rank", rank, "ok", flush=True)
     # attention + wo launch).  Three attempts; a group of four or eight processes that still cannot be kept resident is SKIPPED
     # with that reason (two processes must pass), anything else fails.
     markers = ("never raised its flag", "did not arrive", "failed its self-test", "exchange timed out", "hand-off granule inside a fused launch never arrived")
+    # (round 6: ONE rank whose bounded wait gave up poisons the attempt for all of them -- it goes on pushing rows of a step whose results are
+    # invalid, with valid tags, so its peers add garbage and fail their golden check without any error of their own: an attempt in which ANY rank
+    # reports a bounded wait says nothing about the others)
+    def co_residency(outputs):
+        return bool(outputs) and any(any(m in b for m in markers) for b in outputs)
     bad = run_group(meet)
     for attempt in (2, 3):
-        if not (bad and all(any(m in b for m in markers) for b in bad)):
+        if not co_residency(bad):
             break
         import warnings
         warnings.warn("process group of %d on one GPU: a bounded wait gave up (co-residency); attempt %d" % (G, attempt))
         again = tmp_path / ("meet%d" % attempt)
         again.mkdir()
         bad = run_group(again)
-    if bad and G >= 4 and all(any(m in b for m in markers) for b in bad):
+    if G >= 4 and co_residency(bad):
         pytest.skip("this box does not keep the kernels of %d processes resident together on its one GPU: bounded waits gave up on three attempts "
                     "(a property of the one-GPU stand-in -- the product runs one rank per GPU; the 2-process group, which must pass, covers the mechanism)" % G)
     assert not bad, bad[0]
