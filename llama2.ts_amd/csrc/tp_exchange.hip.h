@@ -479,7 +479,10 @@ static int check_p2p(l2_ctx* c) {   // after a stream sync: did a peer-to-peer w
     hipMemsetAsync(c->gran_ep + c->H_loc, 0, 4, c->stream);                                      // the device-side "a wait gave up" words: armed again
     if (c->awo_ep) { hipMemsetAsync(c->awo_ep + 1, 0, 4, c->stream); hipMemsetAsync(c->awo_gran, 0, (size_t)c->d_loc * 8, c->stream); }
     hipStreamSynchronize(c->stream);
-    return fail(L2_E_HIP, "a hand-off granule inside a fused launch never arrived (bounded wait gave up); the step's results are invalid");
+    // a tensor-parallel rank has pushed the rows of that invalid step to its peers with valid tags: they have added garbage without an error of
+    // their own, so the group's state is no longer the reference's -- this rank fails fast from now on (its peers time out at their next exchange)
+    if (c->tp_path) c->broken = true;
+    return fail(L2_E_HIP, "a hand-off granule inside a fused launch never arrived (bounded wait gave up); the step's results are invalid%s", c->tp_path ? " and so are its peers' (the context is unusable)" : "");
   }
   if (c->p2p_err && *c->p2p_err) {
     *c->p2p_err = 0;
